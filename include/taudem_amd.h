@@ -1,0 +1,208 @@
+/* taudem_amd - C ABI of the MI355X (gfx950) implementation of TauDEM's D8 / D-infinity
+ * flow-direction and contributing-area hot path.
+ *
+ * TauDEM (dtarb/TauDEM 5.4.0) has no library or FFI surface: its boundary is one C++ function per
+ * command-line tool that reads rasters, computes and writes rasters.  This header exports that
+ * boundary twice:
+ *
+ *   (1) in-memory entry points (tdx_<tool> / tdx_<tool>_dev) that replace the COMPUTE part of each
+ *       reference tool function - the region between "dem.read(...)" and "fel.write(...)":
+ *         tdx_pitremove        <- flood()     src/flood.cpp:132-482   (decl. src/flood.h:1-2)
+ *         tdx_d8flowdir        <- setdird8()  src/d8.cpp:227-320      (decl. src/d8.h:5)
+ *         tdx_aread8           <- aread8()    src/aread8.cpp:175-307  (decl. src/aread8.h:3)
+ *         tdx_dinfflowdir      <- setdir()    src/dinf.cpp:156-243    (decl. src/tardemlib.h:70)
+ *         tdx_areadinf         <- area()      src/areadinf.cpp:138-268 (decl. src/areadinf.h:2)
+ *         tdx_dinfdecayaccum   <- dmarea()    src/dinfdecayaccum.cpp:165-294 (:61-62)
+ *       Rasters are row-major, x fastest, row 0 = north (src/linearpart.h:506); dtypes and nodata
+ *       conventions are the reference's (SURVEY.md 8b "Output conventions").
+ *       The *_dev variants take DEVICE pointers (HBM-resident inputs/outputs, the benchmark path);
+ *       the plain variants take HOST pointers and do the PCIe copies themselves.
+ *
+ *   (2) file-level entry points (tdx_tool_*) with the argument lists of the reference's tool
+ *       functions (same order and meaning, `bool` spelled `int`), reading and writing GeoTIFF, so
+ *       the reference's *mn.cpp mains (and the ArcGIS/python wrappers that shell out to them) can
+ *       bind to this library unchanged.  See INTEGRATION.md.
+ *
+ * Error convention follows the reference: 0 = ok, 1 = input rasters do not match
+ * (src/flood.cpp:83, src/aread8.cpp:168); the reference's MPI_Abort codes are returned instead of
+ * aborting (21 file open src/tiffIO.cpp:69, 22 no writable driver src/tiffIO.cpp:313, 5 outlets
+ * src/aread8.cpp:125); library-specific failures are negative.  tdx_last_error() gives the text.
+ */
+#ifndef TAUDEM_AMD_H
+#define TAUDEM_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDX_OK 0
+#define TDX_ERR_MISMATCH 1
+#define TDX_ERR_OUTLETS 5
+#define TDX_ERR_FILE 21
+#define TDX_ERR_DRIVER 22
+#define TDX_ERR_ARG (-1)
+#define TDX_ERR_HIP (-2)
+#define TDX_ERR_NOGPU (-3)
+#define TDX_ERR_NOMEM (-999) /* src/linearpart.h:155 */
+
+/* nodata conventions of the reference's outputs */
+#define TDX_FEL_NODATA (-3.0e38f)      /* src/flood.cpp:136 */
+#define TDX_P_NODATA ((int16_t)-32768) /* src/d8.cpp:231 */
+#define TDX_SLOPE_NODATA (-1.0f)       /* src/d8.cpp:278 */
+#define TDX_AREA_NODATA (-1.0f)        /* src/aread8.cpp:193,310 */
+#define TDX_ANG_NODATA (-3.402823466e+38f) /* MISSINGFLOAT = -FLT_MAX, src/commonLib.h:80 */
+
+typedef struct tdx_context tdx_context;
+
+/* Per-call statistics (all optional: pass NULL).  Times are milliseconds measured with HIP events
+ * on the context's stream; counts mirror what the reference prints to stderr. */
+typedef struct tdx_stats {
+    double ms_total;        /* whole call, device side (first enqueue .. last completion)          */
+    double ms_kernel[8];    /* per kernel class, see TDX_K_* below                                   */
+    int64_t launches[8];    /* launches per kernel class                                             */
+    int64_t rounds;         /* pitremove: relaxation rounds; aread*: outer rounds                    */
+    int64_t flats_initial;  /* "All slopes evaluated. %ld flats to resolve."  src/d8.cpp:296         */
+    int64_t flats_left;     /* flats remaining after the last resolveflats iteration                 */
+    int64_t flat_iterations;/* calls of resolveflats  src/d8.cpp:305-316                             */
+    int64_t levels_fall;    /* BFS levels of incfall (sum over iterations)                           */
+    int64_t levels_rise;    /* BFS levels of incrise (sum over iterations)                           */
+    int64_t cells_evaluated;/* aread8/areadinf/decay: cells that received a value                    */
+} tdx_stats;
+
+/* kernel classes for ms_kernel[] / launches[] */
+#define TDX_K_STENCIL 0  /* streaming 3x3 stencils: seeds, slope pass, in-degree                      */
+#define TDX_K_RELAX 1    /* pitremove tile relaxation                                                  */
+#define TDX_K_BFS 2      /* flat resolution frontier sweeps                                            */
+#define TDX_K_FLATDIR 3  /* setFlow2 / SET2 on flats + bookkeeping                                     */
+#define TDX_K_ACCUM 4    /* dependency-driven accumulation sweep                                       */
+#define TDX_K_MISC 5     /* fills, compaction, copies                                                  */
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Creates a context bound to HIP device `device` (one context per GPU / per process rank).
+ * Fails with TDX_ERR_NOGPU when no HIP device is available: there is no CPU fallback. */
+int tdx_context_create(int device, tdx_context** ctx);
+void tdx_context_destroy(tdx_context* ctx);
+const char* tdx_last_error(const tdx_context* ctx); /* ctx may be NULL: last error of the calling thread */
+int tdx_synchronize(tdx_context* ctx);
+void* tdx_stream(tdx_context* ctx);                  /* the hipStream_t all work is enqueued on */
+const char* tdx_version(void);
+int tdx_device_count(void);
+
+/* device memory helpers so that callers without a HIP binding (ctypes, cgo ...) can stage data */
+int tdx_device_alloc(tdx_context* ctx, uint64_t bytes, void** dptr);
+int tdx_device_free(tdx_context* ctx, void* dptr);
+int tdx_copy_to_device(tdx_context* ctx, void* dptr, const void* host, uint64_t bytes);
+int tdx_copy_to_host(tdx_context* ctx, void* host, const void* dptr, uint64_t bytes);
+
+/* ---- PitRemove ---------------------------------------------------------------------------- */
+/* fel = pit-filled dem.  mask: optional depression mask (cells == 1 keep their elevation,
+ * src/flood.cpp:249), NULL if unused.  fourway != 0 = the -4way flag (src/flood.cpp:68-70). */
+int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t nx, int64_t ny, float dem_nodata,
+                      const int16_t* d_mask, int fourway, float* d_fel, tdx_stats* stats);
+int tdx_pitremove(tdx_context* ctx, const float* dem, int64_t nx, int64_t ny, float dem_nodata,
+                  const int16_t* mask, int fourway, float* fel, tdx_stats* stats);
+
+/* ---- D8FlowDir ---------------------------------------------------------------------------- */
+/* dxc, dyc: HOST arrays of ny per-row cell sizes in metres (src/linearpart.h:516-534);
+ * p: int16 D8 codes 1..8, 0 unresolved flat, -32768 nodata; sd8: slope, -1 nodata (may be NULL). */
+int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                      const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats);
+int tdx_d8flowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,
+                  const double* dxc, const double* dyc, int16_t* p, float* sd8, tdx_stats* stats);
+
+/* ---- AreaD8 ------------------------------------------------------------------------------- */
+/* w: optional weight grid (NULL = unit weights).  contcheck: 1 = edge contamination (default),
+ * 0 = the -nc flag.  Outlets: n_outlets < 0 = no outlets; otherwise HOST arrays of global
+ * column/row indices as produced by tiffIO::geoToGlobalXY (src/tiffIO.cpp:580-588). */
+int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
+                   const float* d_w, float w_nodata, int contcheck,
+                   const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                   float* d_ad8, tdx_stats* stats);
+int tdx_aread8(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata,
+               const float* w, float w_nodata, int contcheck,
+               const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+               float* ad8, tdx_stats* stats);
+
+/* ---- DinfFlowDir -------------------------------------------------------------------------- */
+int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                        const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats);
+int tdx_dinfflowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,
+                    const double* dxc, const double* dyc, float* ang, float* slp, tdx_stats* stats);
+
+/* ---- AreaDinf / DinfDecayAccum ------------------------------------------------------------ */
+int tdx_areadinf_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                     const double* dxc, const double* dyc, const float* d_w, int contcheck,
+                     const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                     float* d_sca, tdx_stats* stats);
+int tdx_areadinf(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                 const double* dxc, const double* dyc, const float* w, int contcheck,
+                 const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                 float* sca, tdx_stats* stats);
+int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                           const double* dxc, const double* dyc, const float* d_dm, float dm_nodata,
+                           const float* d_w, int contcheck,
+                           const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                           float* d_dsca, tdx_stats* stats);
+int tdx_dinfdecayaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                       const double* dxc, const double* dyc, const float* dm, float dm_nodata,
+                       const float* w, int contcheck,
+                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                       float* dsca, tdx_stats* stats);
+
+/* ---- synthetic benchmark input (not in the reference) -------------------------------------- */
+/* Fills d_out (nx*ny float32) with the seeded fractal surface of taudem_amd/csrc/synth_dem.h for
+ * the window whose top-left global cell is (x0,y0).  Bit-identical to the host generator. */
+int tdx_synth_dem_dev(tdx_context* ctx, uint64_t seed, int64_t nx, int64_t ny, int64_t x0, int64_t y0,
+                      int64_t base_wavelength, float* d_out);
+
+/* ---- raster files (GeoTIFF / BigTIFF), host side -------------------------------------------- */
+typedef struct tdx_raster_info {
+    int64_t nx, ny;
+    double geotransform[6];
+    double nodata;        /* -9999 when the file declares none (src/tiffIO.cpp:161-167) */
+    int32_t has_nodata;
+    int32_t geographic;   /* 1: per-row dxc/dyc follow src/tiffIO.cpp:127-143 */
+    double dxA, dyA;      /* src/tiffIO.cpp:155-156 */
+} tdx_raster_info;
+#define TDX_DT_I16 0
+#define TDX_DT_I32 1
+#define TDX_DT_F32 2
+int tdx_raster_info_read(const char* path, tdx_raster_info* info);
+/* data: nx*ny of `dtype` (converted like GDALRasterIO); dxc/dyc: optional ny doubles each */
+int tdx_raster_read(const char* path, int dtype, void* data, double* dxc, double* dyc);
+/* georef_from: optional path of the raster whose geotransform/projection are copied
+ * (src/tiffIO.cpp:344-349).  lzw != 0 writes COMPRESS=LZW like the reference. */
+int tdx_raster_write(const char* path, int dtype, const void* data, int64_t nx, int64_t ny, double nodata,
+                     const char* georef_from, int lzw);
+/* variant that creates georeferencing from scratch (synthetic inputs) */
+int tdx_raster_write_geo(const char* path, int dtype, const void* data, int64_t nx, int64_t ny, double nodata,
+                         const double* geotransform, int geographic, int lzw);
+
+/* ---- file-level tool functions (argument lists of the reference's tool functions) ---------- */
+/* int flood(char*,char*,char*,int,bool,bool,bool,char*)            src/flood.h:1-2 */
+int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* sfdrfile, int usesfdr,
+                       int verbose, int is_4Point, int use_mask, const char* maskfile);
+/* int setdird8(char*,char*,char*,char*,int)                        src/d8.h:5 */
+int tdx_tool_d8flowdir(const char* demfile, const char* pointfile, const char* slopefile,
+                       const char* flowfile, int useflowfile);
+/* int aread8(char*,char*,char*,char*,int,int,char*,int,int,int)    src/aread8.h:3 */
+int tdx_tool_aread8(const char* pfile, const char* afile, const char* datasrc, const char* lyrname,
+                    int uselyrname, int lyrno, const char* wfile, int useOutlets, int usew, int contcheck);
+/* int setdir(char*,char*,char*,char*,int)                          src/dinf.cpp:109 */
+int tdx_tool_dinfflowdir(const char* demfile, const char* angfile, const char* slopefile,
+                         const char* flowfile, int useflowfile);
+/* int area(char*,char*,char*,char*,int,int,char*,int,int,int)      src/areadinf.h:2 */
+int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* datasrc, const char* lyrname,
+                      int uselyrname, int lyrno, const char* wfile, int useOutlets, int usew, int contcheck);
+/* int dmarea(char*,char*,char*,char*,char*,int,int,char*,int,int,int) src/dinfdecayaccum.cpp:61-62 */
+int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const char* dmfile, const char* datasrc,
+                            const char* lyrname, int uselyrname, int lyrno, const char* wfile,
+                            int useOutlets, int usew, int contcheck);
+/* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */
+int tdx_tool_set_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAUDEM_AMD_H */

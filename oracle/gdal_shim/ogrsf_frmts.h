@@ -1,0 +1,2 @@
+/* test infrastructure: see gdal.h */
+#include "gdal.h"

@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE - ctypes wrapper of the CPU restatement (oracle/taudem_oracle.c) and a runner
+for the real reference tools built into oracle/_ref/.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing
+under taudem_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libtaudem_oracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement (and, when /root/reference is present, the reference tools)."""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "taudem_oracle.c")):
+        subprocess.run(["make", "-C", HERE, "restatement"], check=True, capture_output=True)
+    if os.path.isdir("/root/reference/src"):
+        subprocess.run(["make", "-C", HERE, "ref", "-j8"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.orc_prop.restype = C.c_double
+        _lib.orc_prop.argtypes = [C.c_float, C.c_int, C.c_double, C.c_double]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _f64(a, n):
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (n,)))
+
+
+def _outl(outlets):
+    if outlets is None:
+        return None, None, 0, 0, ()
+    ox = np.ascontiguousarray(np.asarray(outlets[0], dtype=np.int32))
+    oy = np.ascontiguousarray(np.asarray(outlets[1], dtype=np.int32))
+    return _p(ox), _p(oy), int(ox.size), 1, (ox, oy)
+
+
+def synth_dem(n_or_shape, seed=1234, x0=0, y0=0, base_wavelength=None):
+    if isinstance(n_or_shape, int):
+        ny = nx = n_or_shape
+    else:
+        ny, nx = n_or_shape
+    if base_wavelength is None:
+        base_wavelength = 2
+        while base_wavelength * 2 < max(nx, ny):
+            base_wavelength *= 2
+    out = np.empty((ny, nx), dtype=np.float32)
+    lib().orc_synth_dem(C.c_uint64(seed), C.c_long(nx), C.c_long(ny), C.c_long(x0), C.c_long(y0), C.c_long(base_wavelength), _p(out))
+    return out
+
+
+def pitremove(dem, nodata=-9999.0, mask=None, fourway=False):
+    dem = np.ascontiguousarray(dem, dtype=np.float32)
+    ny, nx = dem.shape
+    fel = np.empty_like(dem)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.int16)
+    lib().orc_pitremove(_p(dem), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(mask), C.c_int(int(fourway)), _p(fel))
+    return fel
+
+
+def d8flowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0):
+    fel = np.ascontiguousarray(fel, dtype=np.float32)
+    ny, nx = fel.shape
+    p = np.empty((ny, nx), dtype=np.int16)
+    sd8 = np.empty((ny, nx), dtype=np.float32)
+    st = (C.c_long * 8)()
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_d8flowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(p), _p(sd8), st)
+    stats = {"flats_initial": st[0], "flat_iterations": st[1], "flats_left": st[2], "sweeps_fall": st[3], "sweeps_rise": st[4]}
+    return p, sd8, stats
+
+
+def aread8(p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=True, outlets=None):
+    p = np.ascontiguousarray(p, dtype=np.int16)
+    ny, nx = p.shape
+    ad8 = np.empty((ny, nx), dtype=np.float32)
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    lib().orc_aread8(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(weights), C.c_float(weights_nodata), C.c_int(int(contcheck)),
+                     ox, oy, C.c_int(no), C.c_int(use), _p(ad8))
+    return ad8
+
+
+def dinfflowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0):
+    fel = np.ascontiguousarray(fel, dtype=np.float32)
+    ny, nx = fel.shape
+    ang = np.empty((ny, nx), dtype=np.float32)
+    slp = np.empty((ny, nx), dtype=np.float32)
+    st = (C.c_long * 8)()
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinfflowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(ang), _p(slp), st)
+    return ang, slp, {"flats_initial": st[0], "flat_iterations": st[1], "flats_left": st[2]}
+
+
+def areadinf(ang, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None):
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    ny, nx = ang.shape
+    sca = np.empty((ny, nx), dtype=np.float32)
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_areadinf(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(weights),
+                       C.c_int(int(contcheck)), ox, oy, C.c_int(no), C.c_int(use), _p(sca))
+    return sca
+
+
+def dinfdecayaccum(ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None):
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    dm = np.ascontiguousarray(dm, dtype=np.float32)
+    ny, nx = ang.shape
+    out = np.empty((ny, nx), dtype=np.float32)
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinfdecayaccum(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(dm),
+                             C.c_float(dm_nodata), _p(weights), C.c_int(int(contcheck)), ox, oy, C.c_int(no), C.c_int(use), _p(out))
+    return out
+
+
+def prop(a, k, dx, dy):
+    return lib().orc_prop(C.c_float(a), C.c_int(k), C.c_double(dx), C.c_double(dy))
+
+
+# ---------------------------------------------------------------------------------------------
+# the real reference tools (oracle/_ref, built from /root/reference by oracle/Makefile)
+# ---------------------------------------------------------------------------------------------
+def ref_available(tool="pitremove"):
+    return os.path.exists(os.path.join(REF_DIR, tool))
+
+
+def run_ref(tool, args, ranks=1, timeout=3600, cwd=None):
+    """Runs oracle/_ref/<tool> (under mpiexec when ranks > 1).  Returns (stdout, stderr, seconds dict)."""
+    exe = os.path.join(REF_DIR, tool)
+    cmd = [exe] + [str(a) for a in args]
+    if ranks > 1:
+        cmd = [MPIEXEC, "-n", str(ranks)] + cmd
+    env = dict(os.environ)
+    env["PATH"] = "/opt/conda/bin:" + env.get("PATH", "")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=cwd)
+    if r.returncode != 0:
+        raise RuntimeError(f"{tool} failed ({r.returncode}): {r.stdout[-2000:]} {r.stderr[-2000:]}")
+    times = {}
+    for key in ("Compute time", "Compute Slope time", "Resolve Flat time", "Total time", "Data read time", "Read time", "Write time"):
+        m = re.search(re.escape(key) + r":\s*([0-9.eE+-]+)", r.stdout)
+        if m:
+            times[key] = float(m.group(1))
+    return r.stdout, r.stderr, times

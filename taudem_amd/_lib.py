@@ -1,0 +1,154 @@
+"""ctypes binding of libtaudem_amd.so (the C ABI declared in include/taudem_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C taudem_amd/csrc``.  There is
+no CPU fallback: if the library is missing the import fails loudly, and compute entry points fail
+with ``TDX_ERR_NOGPU`` when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtaudem_amd.so")
+
+TDX_OK = 0
+TDX_ERR_MISMATCH = 1
+TDX_ERR_OUTLETS = 5
+TDX_ERR_FILE = 21
+TDX_ERR_DRIVER = 22
+TDX_ERR_ARG = -1
+TDX_ERR_HIP = -2
+TDX_ERR_NOGPU = -3
+TDX_ERR_NOMEM = -999
+
+TDX_DT_I16, TDX_DT_I32, TDX_DT_F32 = 0, 1, 2
+
+K_STENCIL, K_RELAX, K_BFS, K_FLATDIR, K_ACCUM, K_MISC = 0, 1, 2, 3, 4, 5
+KERNEL_CLASSES = {"stencil": K_STENCIL, "relax": K_RELAX, "bfs": K_BFS, "flatdir": K_FLATDIR, "accum": K_ACCUM, "misc": K_MISC}
+
+
+class TdxStats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double),
+        ("ms_kernel", C.c_double * 8),
+        ("launches", C.c_int64 * 8),
+        ("rounds", C.c_int64),
+        ("flats_initial", C.c_int64),
+        ("flats_left", C.c_int64),
+        ("flat_iterations", C.c_int64),
+        ("levels_fall", C.c_int64),
+        ("levels_rise", C.c_int64),
+        ("cells_evaluated", C.c_int64),
+    ]
+
+    def as_dict(self):
+        d = {
+            "ms_total": self.ms_total,
+            "rounds": self.rounds,
+            "flats_initial": self.flats_initial,
+            "flats_left": self.flats_left,
+            "flat_iterations": self.flat_iterations,
+            "levels_fall": self.levels_fall,
+            "levels_rise": self.levels_rise,
+            "cells_evaluated": self.cells_evaluated,
+        }
+        for name, k in KERNEL_CLASSES.items():
+            d["ms_" + name] = self.ms_kernel[k]
+            d["launches_" + name] = self.launches[k]
+        return d
+
+
+class TdxRasterInfo(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int64),
+        ("ny", C.c_int64),
+        ("geotransform", C.c_double * 6),
+        ("nodata", C.c_double),
+        ("has_nodata", C.c_int32),
+        ("geographic", C.c_int32),
+        ("dxA", C.c_double),
+        ("dyA", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/taudem_amd.h declares
+_P = C.c_void_p
+_I64 = C.c_int64
+_F = C.c_float
+_SIGNATURES = {
+    "tdx_context_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "tdx_context_destroy": (None, [_P]),
+    "tdx_last_error": (C.c_char_p, [_P]),
+    "tdx_synchronize": (C.c_int, [_P]),
+    "tdx_stream": (_P, [_P]),
+    "tdx_version": (C.c_char_p, []),
+    "tdx_device_count": (C.c_int, []),
+    "tdx_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "tdx_device_free": (C.c_int, [_P, _P]),
+    "tdx_copy_to_device": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "tdx_copy_to_host": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "tdx_pitremove_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, C.c_int, _P, _P]),
+    "tdx_pitremove": (C.c_int, [_P, _P, _I64, _I64, _F, _P, C.c_int, _P, _P]),
+    "tdx_d8flowdir_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_d8flowdir": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_aread8_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_aread8": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfflowdir_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_dinfflowdir": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_areadinf_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_areadinf": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfdecayaccum_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfdecayaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_synth_dem_dev": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _I64, _I64, _P]),
+    "tdx_raster_info_read": (C.c_int, [C.c_char_p, C.POINTER(TdxRasterInfo)]),
+    "tdx_raster_read": (C.c_int, [C.c_char_p, C.c_int, _P, _P, _P]),
+    "tdx_raster_write": (C.c_int, [C.c_char_p, C.c_int, _P, _I64, _I64, C.c_double, C.c_char_p, C.c_int]),
+    "tdx_raster_write_geo": (C.c_int, [C.c_char_p, C.c_int, _P, _I64, _I64, C.c_double, _P, C.c_int, C.c_int]),
+    "tdx_tool_pitremove": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "tdx_tool_d8flowdir": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    "tdx_tool_aread8": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "tdx_tool_dinfflowdir": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    "tdx_tool_areadinf": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "tdx_tool_dinfdecayaccum": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "tdx_tool_set_device": (C.c_int, [C.c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError with a build hint if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C taudem_amd/csrc` (hipcc, --offload-arch=gfx950). taudem_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class TdxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"taudem_amd error {code}: {msg}")
+        self.code = code
+
+
+def last_error(ctx=None):
+    s = load().tdx_last_error(ctx)
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(rc, ctx=None):
+    if rc != TDX_OK:
+        raise TdxError(rc, last_error(ctx) or last_error(None))

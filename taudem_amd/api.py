@@ -1,0 +1,271 @@
+"""In-memory interface to the HIP hot path (one :class:`Context` per GPU / process rank).
+
+Every method accepts either numpy arrays (host buffers: the library stages them over PCIe) or torch
+CUDA tensors on the context's device (HBM-resident: no copies, the benchmark path).  Array layout,
+dtypes and nodata conventions are the reference's (include/taudem_amd.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TdxStats, check
+
+FEL_NODATA = np.float32(-3.0e38)            # src/flood.cpp:136
+P_NODATA = np.int16(-32768)                 # src/d8.cpp:231
+SLOPE_NODATA = np.float32(-1.0)             # src/d8.cpp:278
+AREA_NODATA = np.float32(-1.0)              # src/aread8.cpp:193
+ANG_NODATA = np.float32(-3.402823466e38)    # MISSINGFLOAT, src/commonLib.h:80
+
+
+def _is_torch(x):
+    return x is not None and type(x).__module__.startswith("torch")
+
+
+def _f64(a, n):
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (n,)))
+    return a
+
+
+class Context:
+    """Owns a HIP stream, a scratch arena and timing events on one device."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.tdx_context_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tdx_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _ptr(self, a, dtype, shape=None, name="array"):
+        """(pointer, is_device) for a numpy array or torch cuda tensor; validates dtype/contiguity."""
+        if a is None:
+            return None, None
+        if _is_torch(a):
+            import torch
+
+            want = {np.float32: torch.float32, np.int16: torch.int16, np.int32: torch.int32}[dtype]
+            if not a.is_cuda or a.device.index != self.device:
+                raise ValueError(f"{name}: tensor must live on cuda:{self.device}")
+            if a.dtype != want or not a.is_contiguous():
+                raise ValueError(f"{name}: need contiguous {want}")
+            if shape is not None and tuple(a.shape) != tuple(shape):
+                raise ValueError(f"{name}: shape {tuple(a.shape)} != {tuple(shape)}")
+            return C.c_void_p(a.data_ptr()), True
+        if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous:
+            raise ValueError(f"{name}: need C-contiguous numpy {np.dtype(dtype)}")
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(a.shape)} != {tuple(shape)}")
+        return C.c_void_p(a.ctypes.data), False
+
+    def _out(self, like, dtype, shape):
+        if _is_torch(like):
+            import torch
+
+            td = {np.float32: torch.float32, np.int16: torch.int16}[dtype]
+            return torch.empty(shape, dtype=td, device=like.device)
+        return np.empty(shape, dtype=dtype)
+
+    def _sync_torch(self, *arrs):
+        if any(_is_torch(a) for a in arrs):
+            import torch
+
+            torch.cuda.synchronize(self.device)
+
+    @staticmethod
+    def _outlets(outlets):
+        if outlets is None:
+            return None, None, -1, ()
+        ox = np.ascontiguousarray(np.asarray(outlets[0], dtype=np.int32))
+        oy = np.ascontiguousarray(np.asarray(outlets[1], dtype=np.int32))
+        if ox.shape != oy.shape or ox.ndim != 1:
+            raise ValueError("outlets: need two equal-length 1-D index arrays (columns, rows)")
+        return C.c_void_p(ox.ctypes.data), C.c_void_p(oy.ctypes.data), int(ox.size), (ox, oy)
+
+    def _pick(self, dev, name):
+        return getattr(self._lib, name + ("_dev" if dev else ""))
+
+    # ---- stages ---------------------------------------------------------------------------
+    def pitremove(self, dem, nodata=-9999.0, mask=None, fourway=False, out=None, stats=False):
+        """fel = flood(dem)  (src/flood.cpp:50)."""
+        ny, nx = dem.shape
+        fel = out if out is not None else self._out(dem, np.float32, (ny, nx))
+        pz, dev = self._ptr(dem, np.float32, name="dem")
+        pm, mdev = self._ptr(mask, np.int16, (ny, nx), "mask")
+        pf, fdev = self._ptr(fel, np.float32, (ny, nx), "fel")
+        if fdev != dev or (mask is not None and mdev != dev):
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(dem, mask)
+        check(self._pick(dev, "tdx_pitremove")(self._h, pz, nx, ny, float(nodata), pm, int(bool(fourway)), pf, C.byref(st)), self._h)
+        return (fel, st.as_dict()) if stats else fel
+
+    def d8flowdir(self, fel, nodata=float(FEL_NODATA), dx=1.0, dy=1.0, want_slope=True, out=None, stats=False):
+        """p, sd8 = setdird8(fel)  (src/d8.cpp:181).  dx, dy: scalars or per-row arrays (metres)."""
+        ny, nx = fel.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        p = out[0] if out is not None else self._out(fel, np.int16, (ny, nx))
+        sd8 = (out[1] if out is not None else self._out(fel, np.float32, (ny, nx))) if want_slope else None
+        pz, dev = self._ptr(fel, np.float32, name="fel")
+        pp, pdev = self._ptr(p, np.int16, (ny, nx), "p")
+        ps, _ = self._ptr(sd8, np.float32, (ny, nx), "sd8")
+        if pdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(fel)
+        check(self._pick(dev, "tdx_d8flowdir")(self._h, pz, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                pp, ps, C.byref(st)), self._h)
+        res = (p, sd8) if want_slope else (p, None)
+        return (res + (st.as_dict(),)) if stats else res
+
+    def aread8(self, p, nodata=int(P_NODATA), weights=None, weights_nodata=-9999.0, contcheck=True, outlets=None, out=None, stats=False):
+        """ad8 = aread8(p)  (src/aread8.cpp:56).  outlets: (columns, rows) global indices or None."""
+        ny, nx = p.shape
+        ad8 = out if out is not None else self._out(p, np.float32, (ny, nx))
+        pp, dev = self._ptr(p, np.int16, name="p")
+        pw, wdev = self._ptr(weights, np.float32, (ny, nx), "weights")
+        pa, adev = self._ptr(ad8, np.float32, (ny, nx), "ad8")
+        if adev != dev or (weights is not None and wdev != dev):
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(p, weights)
+        check(self._pick(dev, "tdx_aread8")(self._h, pp, nx, ny, int(nodata), pw, float(weights_nodata), int(bool(contcheck)), ox, oy, no, pa,
+                                             C.byref(st)), self._h)
+        del keep
+        return (ad8, st.as_dict()) if stats else ad8
+
+    def dinfflowdir(self, fel, nodata=float(FEL_NODATA), dx=1.0, dy=1.0, out=None, stats=False):
+        """ang, slp = setdir(fel)  (src/dinf.cpp:109)."""
+        ny, nx = fel.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        ang = out[0] if out is not None else self._out(fel, np.float32, (ny, nx))
+        slp = out[1] if out is not None else self._out(fel, np.float32, (ny, nx))
+        pz, dev = self._ptr(fel, np.float32, name="fel")
+        pa, adev = self._ptr(ang, np.float32, (ny, nx), "ang")
+        ps, _ = self._ptr(slp, np.float32, (ny, nx), "slp")
+        if adev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(fel)
+        check(self._pick(dev, "tdx_dinfflowdir")(self._h, pz, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                  pa, ps, C.byref(st)), self._h)
+        return (ang, slp, st.as_dict()) if stats else (ang, slp)
+
+    def areadinf(self, ang, nodata=float(ANG_NODATA), dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None, out=None, stats=False):
+        """sca = area(ang)  (src/areadinf.cpp:53)."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        sca = out if out is not None else self._out(ang, np.float32, (ny, nx))
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        pw, wdev = self._ptr(weights, np.float32, (ny, nx), "weights")
+        ps, sdev = self._ptr(sca, np.float32, (ny, nx), "sca")
+        if sdev != dev or (weights is not None and wdev != dev):
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(ang, weights)
+        check(self._pick(dev, "tdx_areadinf")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pw,
+                                               int(bool(contcheck)), ox, oy, no, ps, C.byref(st)), self._h)
+        del keep
+        return (sca, st.as_dict()) if stats else sca
+
+    def dinfdecayaccum(self, ang, dm, nodata=float(ANG_NODATA), dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True,
+                       outlets=None, out=None, stats=False):
+        """dsca = dmarea(ang, dm)  (src/dinfdecayaccum.cpp:61)."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        dsca = out if out is not None else self._out(ang, np.float32, (ny, nx))
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        pd, ddev = self._ptr(dm, np.float32, (ny, nx), "dm")
+        pw, wdev = self._ptr(weights, np.float32, (ny, nx), "weights")
+        ps, sdev = self._ptr(dsca, np.float32, (ny, nx), "dsca")
+        if sdev != dev or ddev != dev or (weights is not None and wdev != dev):
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(ang, dm, weights)
+        check(self._pick(dev, "tdx_dinfdecayaccum")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                     pd, float(dm_nodata), pw, int(bool(contcheck)), ox, oy, no, ps, C.byref(st)), self._h)
+        del keep
+        return (dsca, st.as_dict()) if stats else dsca
+
+    def synth_dem(self, n_or_shape, seed=1234, x0=0, y0=0, base_wavelength=None, out=None):
+        """Seeded fractal DEM generated on the device (torch tensor on cuda:<device>)."""
+        import torch
+
+        if isinstance(n_or_shape, int):
+            ny = nx = int(n_or_shape)
+        else:
+            ny, nx = n_or_shape
+        if base_wavelength is None:
+            base_wavelength = synth_base_wavelength(max(nx, ny))
+        t = out if out is not None else torch.empty((ny, nx), dtype=torch.float32, device=f"cuda:{self.device}")
+        torch.cuda.synchronize(self.device)
+        check(self._lib.tdx_synth_dem_dev(self._h, int(seed), nx, ny, int(x0), int(y0), int(base_wavelength), C.c_void_p(t.data_ptr())), self._h)
+        return t
+
+
+def synth_base_wavelength(n: int) -> int:
+    """Largest power of two < n (at least 2): tdx_synth_base_wl() of csrc/synth_dem.h."""
+    wl = 2
+    while wl * 2 < n:
+        wl *= 2
+    return wl
+
+
+# ---- raster files ---------------------------------------------------------------------------
+_NP2DT = {np.dtype(np.int16): _lib.TDX_DT_I16, np.dtype(np.int32): _lib.TDX_DT_I32, np.dtype(np.float32): _lib.TDX_DT_F32}
+
+
+def raster_info(path):
+    info = _lib.TdxRasterInfo()
+    check(_lib.load().tdx_raster_info_read(str(path).encode(), C.byref(info)))
+    return {
+        "nx": info.nx, "ny": info.ny, "geotransform": tuple(info.geotransform), "nodata": info.nodata,
+        "has_nodata": bool(info.has_nodata), "geographic": bool(info.geographic), "dxA": info.dxA, "dyA": info.dyA,
+    }
+
+
+def read_raster(path, dtype=np.float32):
+    """Returns (array, info dict incl. per-row 'dxc'/'dyc')."""
+    info = raster_info(path)
+    a = np.empty((info["ny"], info["nx"]), dtype=dtype)
+    dxc = np.empty(info["ny"], dtype=np.float64)
+    dyc = np.empty(info["ny"], dtype=np.float64)
+    check(_lib.load().tdx_raster_read(str(path).encode(), _NP2DT[np.dtype(dtype)], C.c_void_p(a.ctypes.data), C.c_void_p(dxc.ctypes.data),
+                                      C.c_void_p(dyc.ctypes.data)))
+    info["dxc"], info["dyc"] = dxc, dyc
+    return a, info
+
+
+def write_raster(path, a, nodata, like=None, geotransform=None, geographic=False, lzw=False):
+    a = np.ascontiguousarray(a)
+    ny, nx = a.shape
+    lib = _lib.load()
+    if like is not None:
+        check(lib.tdx_raster_write(str(path).encode(), _NP2DT[a.dtype], C.c_void_p(a.ctypes.data), nx, ny, float(nodata), str(like).encode(), int(lzw)))
+    else:
+        gt = np.asarray(geotransform if geotransform is not None else (0.0, 1.0, 0.0, float(ny), 0.0, -1.0), dtype=np.float64)
+        check(lib.tdx_raster_write_geo(str(path).encode(), _NP2DT[a.dtype], C.c_void_p(a.ctypes.data), nx, ny, float(nodata),
+                                       C.c_void_p(gt.ctypes.data), int(bool(geographic)), int(lzw)))

@@ -1,0 +1,364 @@
+// File-level tool functions: same argument lists, banners, timing blocks and error codes as the
+// reference's tool functions, with the compute part on the GPU.  One process drives one device here;
+// multi-GPU strips are orchestrated one process per GPU by taudem_amd/dist.py over RCCL.
+//   tdx_tool_pitremove       <- flood()     src/flood.cpp:50-526
+//   tdx_tool_d8flowdir       <- setdird8()  src/d8.cpp:181-355
+//   tdx_tool_aread8          <- aread8()    src/aread8.cpp:56-322
+//   tdx_tool_dinfflowdir     <- setdir()    src/dinf.cpp:109-284
+//   tdx_tool_areadinf        <- area()      src/areadinf.cpp:53-300
+//   tdx_tool_dinfdecayaccum  <- dmarea()    src/dinfdecayaccum.cpp:61-324
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.hpp"
+#include "geotiff.hpp"
+#include "outlets.hpp"
+
+#define TDVERSION "5.4.0"   /* src/commonLib.h:63 */
+
+namespace {
+
+int g_tool_device = -1;
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int tool_device() {
+    if (g_tool_device >= 0) return g_tool_device;
+    const char* e = getenv("TAUDEM_AMD_DEVICE");
+    return e ? atoi(e) : 0;
+}
+bool want_lzw() {
+    const char* e = getenv("TAUDEM_AMD_COMPRESS");
+    if (e && (strcmp(e, "NONE") == 0 || strcmp(e, "none") == 0)) return false;
+    return true;   // the reference writes COMPRESS=LZW (src/tiffIO.cpp:316-318)
+}
+
+struct Raster {
+    tdx::RasterInfo info;
+    std::vector<float> f;
+    std::vector<int16_t> s;
+};
+
+// tiffIO constructor + CreateNewPartition prints + read (src/tiffIO.cpp:54-183, src/createpart.h:49-87)
+int load_raster(const char* path, tdx::DType type, Raster& r) {
+    tdx::TiffReader rd;
+    if (!rd.open(path)) {
+        printf("Error opening file %s.\n", path);
+        fflush(stdout);
+        g_tdx_thread_error = rd.error();
+        return TDX_ERR_FILE;
+    }
+    r.info = rd.info();
+    if (!r.info.geographic) printf("Input file %s has projected coordinate system.\n", path);
+    else printf("Input file %s has geographic coordinate system.\n", path);
+    const size_t n = size_t(r.info.nx) * size_t(r.info.ny);
+    printf("Nodata value input to create partition from file: %lf\n", r.info.nodata);
+    bool ok;
+    if (type == tdx::DType::F32) {
+        printf("Nodata value recast to float used in partition raster: %f\n", (float)r.info.nodata);
+        r.f.resize(n);
+        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.f.data());
+    } else {
+        printf("Nodata value recast to int16_t used in partition raster: %d\n", (int16_t)r.info.nodata);
+        r.s.resize(n);
+        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.s.data());
+    }
+    fflush(stdout);
+    if (!ok) { printf("Error opening file %s.\n", path); g_tdx_thread_error = rd.error(); return TDX_ERR_FILE; }
+    return TDX_OK;
+}
+
+// tiffIO::compareTiff (src/tiffIO.cpp:449-541)
+bool compare_rasters(const tdx::RasterInfo& a, const char* an, const tdx::RasterInfo& b, const char* bn) {
+    const double tol = 0.0001;
+    if (a.nx != b.nx) { printf("Columns do not match: %d %d\n", int(a.nx), int(b.nx)); return false; }
+    if (a.ny != b.ny) { printf("Rows do not match: %d %d\n", int(a.ny), int(b.ny)); return false; }
+    if (std::fabs(a.dxA() - b.dxA()) > tol) { printf("dx does not match: %lf %lf\n", a.dxA(), b.dxA()); return false; }
+    if (std::fabs(a.dyA() - b.dyA()) > tol) { printf("dy does not match: %lf %lf\n", a.dyA(), b.dyA()); return false; }
+    if (std::fabs(a.xleftedge - b.xleftedge) > 0.0) {
+        printf("Warning! Left edge does not match exactly:\n %lf in file %s\n %lf in file %s\n", a.xleftedge, an, b.xleftedge, bn);
+    }
+    if (std::fabs(a.ytopedge - b.ytopedge) > 0.0) {
+        printf("Warning! Top edge does not match exactly:\n %lf in file %s\n %lf in file %s\n", a.ytopedge, an, b.ytopedge, bn);
+    }
+    return true;
+}
+
+int save_raster(const char* path, tdx::DType type, const void* data, const tdx::RasterInfo& like, double nodata) {
+    std::string name = path;
+    if (tdx::resolve_output_name(name) != 0) { printf("GDAL driver is not available\n"); fflush(stdout); return TDX_ERR_DRIVER; }
+    const size_t cb = tdx::dtype_size(type);
+    const double fileGB = double(cb) * double(like.nx) * double(like.ny) / 1000000000.0;
+    if (fileGB > 4.0) printf("Setting BIGTIFF, File: %s, Anticipated size (GB):%.2f\n", name.c_str(), fileGB);
+    tdx::TiffWriter wr;
+    if (!wr.create(name, like.nx, like.ny, type, nodata, &like, want_lzw())) { printf("Error opening file %s.\n", name.c_str()); g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
+    const size_t rowbytes = size_t(like.nx) * cb;
+    for (int64_t y = 0; y < like.ny; y += 256) {
+        const int64_t nrows = std::min<int64_t>(256, like.ny - y);
+        if (!wr.write_rows(y, nrows, static_cast<const char*>(data) + size_t(y) * rowbytes)) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
+    }
+    if (!wr.close()) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
+    return TDX_OK;
+}
+
+struct CtxGuard {
+    tdx_context* c = nullptr;
+    int rc;
+    CtxGuard() { rc = tdx_context_create(tool_device(), &c); if (rc != TDX_OK) fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(nullptr)); }
+    ~CtxGuard() { tdx_context_destroy(c); }
+};
+
+// outlets: readoutlets + geoToGlobalXY (src/aread8.cpp:114-136,179-189)
+int load_outlets(const char* datasrc, const tdx::RasterInfo& ri, std::vector<int32_t>& ox, std::vector<int32_t>& oy) {
+    std::vector<double> x, y; std::vector<int> id; std::string err;
+    if (!tdx::read_outlets(datasrc, x, y, id, err)) {
+        printf("Error Opening OGR Data Source .\n");
+        printf("Error opening shapefile. Exiting \n");
+        fflush(stdout);
+        g_tdx_thread_error = err;
+        return TDX_ERR_OUTLETS;
+    }
+    printf("Warning: Spatial References of Outlet feature and Raster data are missing.\n");
+    ox.resize(x.size()); oy.resize(x.size());
+    for (size_t i = 0; i < x.size(); i++) {
+        int gx, gy;
+        tdx::geo_to_global_xy(x[i], y[i], ri.xleftedge, ri.ytopedge, ri.dlon, ri.dlat, gx, gy);
+        ox[i] = gx; oy[i] = gy;
+    }
+    return TDX_OK;
+}
+
+void print_gpu_stats(const char* tool, const tdx_stats& st, int64_t cells) {
+    if (!getenv("TAUDEM_AMD_STATS")) return;
+    fprintf(stderr, "{\"tool\": \"%s\", \"cells\": %lld, \"device_ms\": %.3f, \"mcells_per_s\": %.3f, \"rounds\": %lld, \"flats\": %lld, "
+                    "\"levels_fall\": %lld, \"levels_rise\": %lld}\n",
+            tool, (long long)cells, st.ms_total, st.ms_total > 0 ? double(cells) / st.ms_total / 1000.0 : 0.0, (long long)st.rounds,
+            (long long)st.flats_initial, (long long)st.levels_fall, (long long)st.levels_rise);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdx_tool_set_device(int device) { g_tool_device = device; return TDX_OK; }
+
+int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* /*sfdrfile*/, int /*usesfdr*/,
+                       int verbose, int is_4Point, int use_mask, const char* maskfile) {
+    printf("PitRemove version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster dem, mask;
+    int rc = load_raster(demfile, tdx::DType::F32, dem);
+    if (rc != TDX_OK) return rc;
+    if (use_mask) {
+        rc = load_raster(maskfile, tdx::DType::I16, mask);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(dem.info, demfile, mask.info, maskfile)) {
+            printf("Error: depression mask and input DEM are not similar. Files must have the same number of rows/columns.\n");
+            fflush(stdout);
+            return TDX_ERR_MISMATCH;
+        }
+    }
+    const double readt = now_s();
+    if (verbose) { printf("Header read\nData read\n"); if (use_mask) printf("Process: 0, Using depression mask data...\n"); fflush(stdout); }
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<float> fel(dem.f.size());
+    tdx_stats st;
+    rc = tdx_pitremove(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, use_mask ? mask.s.data() : nullptr,
+                       is_4Point, fel.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    if (verbose) printf("Process: 0, Pass: %lld, Remaining: 0\n", (long long)st.rounds);
+    const double computet = now_s();
+    const float felNodata = -3.0e38f;
+    rc = save_raster(felfile, tdx::DType::F32, fel.data(), dem.info, (double)felNodata);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processes: %d\nHeader read time: %f\nData read time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n",
+           1, 0.0, readt - begint, computet - readt, writet - computet, writet - begint);
+    print_gpu_stats("pitremove", st, dem.info.nx * dem.info.ny);
+    return 0;
+}
+
+int tdx_tool_d8flowdir(const char* demfile, const char* pointfile, const char* slopefile, const char* /*flowfile*/, int useflowfile) {
+    printf("D8FlowDir version %s\n", TDVERSION);
+    fflush(stdout);
+    if (useflowfile == 1) {
+        // the reference's -sfdr branch reads an int32 partition through the int16 accessor and aborts
+        // (src/d8.cpp:119,239-241 -> src/partition.h:100-107): treated as unsupported, same exit code
+        printf("Attempt to access short grid with incorrect data type\n");
+        return 41;
+    }
+    const double begint = now_s();
+    Raster dem;
+    int rc = load_raster(demfile, tdx::DType::F32, dem);
+    if (rc != TDX_OK) return rc;
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    const size_t n = dem.f.size();
+    std::vector<int16_t> p(n);
+    std::vector<float> sd8(n);
+    tdx_stats st;
+    rc = tdx_d8flowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
+                       p.data(), sd8.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    fprintf(stderr, "All slopes evaluated. %ld flats to resolve.\n", (long)st.flats_initial);
+    if (st.flat_iterations > 0 && st.flats_left > 0) fprintf(stderr, "Iteration complete. Number of flats remaining: %ld\n", (long)st.flats_left);
+    rc = save_raster(slopefile, tdx::DType::F32, sd8.data(), dem.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    const double writeSlopet = now_s();
+    rc = save_raster(pointfile, tdx::DType::I16, p.data(), dem.info, -32768.0);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    const double slope_s = st.ms_kernel[TDX_K_STENCIL] / 1000.0;
+    printf("Processors: %d\nHeader read time: %f\nData read time: %f\nCompute Slope time: %f\nWrite Slope time: %f\nResolve Flat time: %f\nWrite Flat time: %f\nTotal time: %f\n",
+           1, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
+    print_gpu_stats("d8flowdir", st, dem.info.nx * dem.info.ny);
+    return 0;
+}
+
+int tdx_tool_aread8(const char* pfile, const char* afile, const char* datasrc, const char* /*lyrname*/, int /*uselyrname*/, int /*lyrno*/,
+                    const char* wfile, int useOutlets, int usew, int contcheck) {
+    {   // existence probe of the reference (src/aread8.cpp:62-86)
+        FILE* fp = fopen(pfile, "r");
+        if (!fp) { fprintf(stderr, "Error: Input file %s does not exist.\n", pfile); return TDX_ERR_FILE; }
+        fclose(fp);
+    }
+    printf("AreaD8 version %s\n", TDVERSION);
+    const double begint = now_s();
+    Raster p, w;
+    int rc = load_raster(pfile, tdx::DType::I16, p);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, p.info, ox, oy); if (rc != TDX_OK) return rc; }
+    if (usew == 1) {
+        rc = load_raster(wfile, tdx::DType::F32, w);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(p.info, pfile, w.info, wfile)) { printf("File sizes do not match\n%s\n", wfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    }
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<float> a(p.s.size());
+    tdx_stats st;
+    rc = tdx_aread8(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, usew ? w.f.data() : nullptr, usew ? (float)w.info.nodata : 0.f,
+                    contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, a.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(afile, tdx::DType::F32, a.data(), p.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Number of Processes: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    print_gpu_stats("aread8", st, p.info.nx * p.info.ny);
+    return 0;
+}
+
+int tdx_tool_dinfflowdir(const char* demfile, const char* angfile, const char* slopefile, const char* /*flowfile*/, int /*useflowfile*/) {
+    printf("DinfFlowDir version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster dem;
+    int rc = load_raster(demfile, tdx::DType::F32, dem);
+    if (rc != TDX_OK) return rc;
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    const size_t n = dem.f.size();
+    std::vector<float> ang(n), slp(n);
+    tdx_stats st;
+    rc = tdx_dinfflowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
+                         ang.data(), slp.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    fprintf(stderr, "All slopes evaluated. %ld flats to resolve.\n", (long)st.flats_initial);
+    rc = save_raster(slopefile, tdx::DType::F32, slp.data(), dem.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    const double writeSlopet = now_s();
+    rc = save_raster(angfile, tdx::DType::F32, ang.data(), dem.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    const double slope_s = st.ms_kernel[TDX_K_STENCIL] / 1000.0;
+    printf("Processors: %d\nHeader read time: %f\nData read time: %f\nCompute Slope time: %f\nWrite Slope time: %f\nResolve Flat time: %f\nWrite Flat time: %f\nTotal time: %f\n",
+           1, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
+    print_gpu_stats("dinfflowdir", st, dem.info.nx * dem.info.ny);
+    return 0;
+}
+
+int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* datasrc, const char* /*lyrname*/, int /*uselyrname*/, int /*lyrno*/,
+                      const char* wfile, int useOutlets, int usew, int contcheck) {
+    printf("AreaDinf version %s\n", TDVERSION);
+    const double begint = now_s();
+    Raster ang, w;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, ang.info, ox, oy); if (rc != TDX_OK) return rc; }
+    if (usew == 1) {
+        rc = load_raster(wfile, tdx::DType::F32, w);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(ang.info, angfile, w.info, wfile)) return TDX_ERR_MISMATCH;   // src/areadinf.cpp:134
+    }
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<float> sca(ang.f.size());
+    tdx_stats st;
+    rc = tdx_areadinf(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
+                      usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr,
+                      useOutlets ? int64_t(ox.size()) : -1, sca.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(scafile, tdx::DType::F32, sca.data(), ang.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    print_gpu_stats("areadinf", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
+int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const char* dmfile, const char* datasrc, const char* /*lyrname*/,
+                            int /*uselyrname*/, int /*lyrno*/, const char* wfile, int useOutlets, int usew, int contcheck) {
+    printf("DinfDecayAccum version %s\n", TDVERSION);
+    const double begint = now_s();
+    Raster ang, dm, w;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, ang.info, ox, oy); if (rc != TDX_OK) return rc; }
+    rc = load_raster(dmfile, tdx::DType::F32, dm);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, dm.info, dmfile)) { printf("File sizes do not match\n%s\n", dmfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    if (usew == 1) {
+        rc = load_raster(wfile, tdx::DType::F32, w);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(ang.info, angfile, w.info, wfile)) { printf("File sizes do not match\n%s\n", wfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    }
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<float> out(ang.f.size());
+    tdx_stats st;
+    rc = tdx_dinfdecayaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
+                            dm.f.data(), (float)dm.info.nodata, usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr,
+                            useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, out.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(adecfile, tdx::DType::F32, out.data(), ang.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    print_gpu_stats("dinfdecayaccum", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+#include "context.hpp"
+
+#include <cstring>
+
+thread_local std::string g_tdx_thread_error;
+
+void* tdx_context::scratch(int slot, size_t bytes) {
+    if (slots.size() < size_t(TDX_S_COUNT)) slots.resize(size_t(TDX_S_COUNT));
+    Slot& s = slots[size_t(slot)];
+    if (bytes == 0) bytes = 16;
+    if (s.bytes >= bytes) return s.p;
+    if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+    size_t want = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&s.p, want);
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+        g_tdx_thread_error = err;
+        s.p = nullptr;
+        return nullptr;
+    }
+    s.bytes = want;
+    return s.p;
+}
+
+hipEvent_t tdx_context::get_event() {
+    if (events_used == event_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        event_pool.push_back(e);
+    }
+    return event_pool[events_used++];
+}
+
+void tdx_context::begin_call(tdx_stats* st) {
+    cur_stats = st;
+    timing = (st != nullptr);
+    spans.clear();
+    events_used = 0;
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        ev_begin = get_event();
+        (void)hipEventRecord(ev_begin, stream);
+    }
+}
+
+void tdx_context::span_begin(int kclass) {
+    if (!timing) return;
+    Span s;
+    s.a = get_event(); s.b = get_event(); s.kclass = kclass;
+    (void)hipEventRecord(s.a, stream);
+    spans.push_back(s);
+}
+
+void tdx_context::span_end() {
+    if (!timing || spans.empty()) return;
+    (void)hipEventRecord(spans.back().b, stream);
+}
+
+void tdx_context::end_call() {
+    if (timing) {
+        ev_end = get_event();
+        (void)hipEventRecord(ev_end, stream);
+    }
+    (void)hipStreamSynchronize(stream);
+    if (timing && cur_stats) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev_begin, ev_end);
+        cur_stats->ms_total = ms;
+        for (const Span& s : spans) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) cur_stats->ms_kernel[s.kclass] += t;
+        }
+    }
+    timing = false;
+    cur_stats = nullptr;
+}
+
+extern "C" {
+
+const char* tdx_version(void) { return "taudem_amd 0.1.0 (TauDEM 5.4.0 hot path, gfx950)"; }
+
+int tdx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tdx_context_create(int device, tdx_context** out) {
+    if (!out) return TDX_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_tdx_thread_error = "no HIP device available: taudem_amd has no CPU fallback";
+        return TDX_ERR_NOGPU;
+    }
+    if (device < 0 || device >= n) { g_tdx_thread_error = "bad device index"; return TDX_ERR_ARG; }
+    tdx_context* c = new tdx_context;
+    c->device = device;
+    TDX_HIP_CHECK(c, hipSetDevice(device));
+    TDX_HIP_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 64 * sizeof(uint64_t), hipHostMallocDefault));
+    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 64 * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 64 * sizeof(uint64_t)));
+    c->slots.resize(size_t(TDX_S_COUNT));
+    *out = c;
+    return TDX_OK;
+}
+
+void tdx_context_destroy(tdx_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->slots) if (s.p) (void)hipFree(s.p);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
+    if (c->d_mail) (void)hipFree(c->d_mail);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* tdx_last_error(const tdx_context* c) { return c ? c->err.c_str() : g_tdx_thread_error.c_str(); }
+
+int tdx_synchronize(tdx_context* c) {
+    if (!c) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TDX_OK;
+}
+
+void* tdx_stream(tdx_context* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int tdx_device_alloc(tdx_context* c, uint64_t bytes, void** dptr) {
+    if (!c || !dptr) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipSetDevice(c->device));
+    TDX_HIP_CHECK(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return TDX_OK;
+}
+int tdx_device_free(tdx_context* c, void* dptr) {
+    if (!c) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipFree(dptr));
+    return TDX_OK;
+}
+int tdx_copy_to_device(tdx_context* c, void* dptr, const void* host, uint64_t bytes) {
+    if (!c) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+    TDX_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TDX_OK;
+}
+int tdx_copy_to_host(tdx_context* c, void* host, const void* dptr, uint64_t bytes) {
+    if (!c) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    TDX_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Per-GPU execution context shared by all stages: device, stream, error text, a reusable scratch
+// arena (so that steady-state calls do not hipMalloc) and HIP-event timing per kernel class.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/taudem_amd.h"
+
+#define TDX_NUM_KCLASS 8
+
+struct tdx_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cus = 256;
+
+    // ---- scratch arena: named slots that only grow; freed with the context ----
+    struct Slot { void* p = nullptr; size_t bytes = 0; };
+    std::vector<Slot> slots;
+    void* scratch(int slot, size_t bytes);   // returns nullptr + sets err on failure
+
+    // pinned host mailbox for small device->host readbacks (counters, flags)
+    uint64_t* h_mail = nullptr;              // 64 words, hipHostMalloc
+    uint64_t* d_mail = nullptr;              // 64 words of device memory
+
+    // ---- timing ----
+    struct Span { hipEvent_t a, b; int kclass; };
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::vector<Span> spans;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timing = false;
+    tdx_stats* cur_stats = nullptr;
+
+    hipEvent_t get_event();
+    void begin_call(tdx_stats* st);
+    void end_call();                          // synchronises, fills stats
+    void span_begin(int kclass);
+    void span_end();
+};
+
+extern thread_local std::string g_tdx_thread_error;
+
+#define TDX_HIP_CHECK(ctx, expr)                                                                   \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+            g_tdx_thread_error = (ctx)->err;                                                       \
+            return TDX_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+// RAII helper: times everything enqueued in its scope under one kernel class
+struct TdxSpan {
+    tdx_context* c;
+    TdxSpan(tdx_context* ctx, int kclass) : c(ctx) { c->span_begin(kclass); }
+    ~TdxSpan() { c->span_end(); }
+};
+
+// scratch slot ids (one namespace for all stages; stages never run concurrently on a context)
+enum {
+    TDX_S_A = 0, TDX_S_B, TDX_S_C, TDX_S_D, TDX_S_E, TDX_S_F, TDX_S_G, TDX_S_H, TDX_S_I, TDX_S_J,
+    TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_COUNT
+};
+
+static inline int tdx_fail(tdx_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    g_tdx_thread_error = msg;
+    return code;
+}

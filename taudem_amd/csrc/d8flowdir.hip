@@ -1,0 +1,279 @@
+// D8FlowDir on gfx950: replaces the compute part of setdird8() (src/d8.cpp:227-320).
+//
+//   d8_slope_kernel      setPosDir + setFlow + calcSlope (src/d8.cpp:359-409, 103-177) as one 3x3
+//                        stencil: fel -> p, sd8.  dontCross() cannot fire in the first pass and the
+//                        "neighbour points back" branch is unreachable, so the
+//                        pass is a pure per-cell function of the 3x3 window.
+//   flat resolution      resolveflats (src/d8.cpp:459-680).  The reference re-sweeps every flat cell
+//                        once per level (N^1.5); both of its relaxations are breadth-first levels, so
+//                        they run here as frontier BFS with one launch per level:
+//                          incfall: elev2(c) = level at which c stops incrementing
+//                                   level 1  = a non-crossing neighbour is <= and has a direction
+//                                   level 2 += an equal, non-crossing neighbour that is NOT a flat cell
+//                                              and has no direction (its elev2 stays 1 < st for st>=2)
+//                                   level t  = 1 + min level over equal, non-crossing flat neighbours
+//                          incrise: q(c) = BFS level from cells with a strictly higher neighbour through
+//                                   8-connected flat cells; s(c) = Tr - q(c) + 1
+//                        The sweep counts T, Tr of the reference's loops are reconstructed from the
+//                        level counts (they leak into the artificial elevations of pits and into s).
+//   d8_setflow2_kernel   setFlow2 (src/d8.cpp:412-454) per flat cell on the artificial surface
+//   outer iteration      while flats decrease: overwrite the WHOLE elevation grid with (float)elev2
+//                        (src/d8.cpp:669-675) and repeat (src/d8.cpp:300-317)
+#include "context.hpp"
+#include "device_common.hpp"
+#include "flats.hpp"
+
+namespace {
+
+using namespace tdxk;
+
+__global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, float nodata,
+                                                       const double* __restrict__ fact, int16_t* __restrict__ P,
+                                                       float* __restrict__ SD8, unsigned long long* __restrict__ nflat) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool flat = false;
+    if (x < nx && y < ny) {
+        const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+        int16_t p = TDX_P_NODATA;
+        float sd = -1.0f;
+        const float z0 = Z[idx];
+        const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
+        if (!edge && !is_nodata_f(z0, nodata)) {
+            float zn[9];
+            bool con = false;
+#pragma unroll
+            for (int k = 1; k <= 8; k++) {
+                zn[k] = Z[size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k))];
+                con = con || is_nodata_f(zn[k], nodata);
+            }
+            if (!con) {
+                const double* f = fact + size_t(y) * 9;
+                float smax = 0.f;
+                int dir = 0;
+                const int order[8] = {1, 3, 5, 7, 2, 4, 6, 8};
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int k = order[o];
+                    const float slope = (float)(f[k] * (double)(z0 - zn[k]));
+                    if (slope > smax) { smax = slope; dir = k; }
+                }
+                p = int16_t(dir);
+                flat = (dir == 0);
+                // calcSlope: elevDiff * fact[j][dir]; dir == 0 -> (z0 - z0) * fact[j][0] = 0
+                sd = (dir == 0) ? 0.0f : (float)((z0 - zn[dir]) * f[dir]);
+            }
+        }
+        P[idx] = p;
+        if (SD8) SD8[idx] = sd;
+    }
+    const unsigned long long b = __ballot(flat);
+    if (b && __lane_id() == __ffsll((long long)b) - 1) atomicAdd(nflat, (unsigned long long)__popcll(b));
+}
+
+// D8 dontCross (src/d8.cpp:54-100) for an interior cell at linear index c
+__device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, size_t c, int nx, int k) {
+    switch (k) {
+        case 2: return P[c + 1] == 4 || P[c - nx] == 8;
+        case 4: return P[c - nx] == 6 || P[c - 1] == 2;
+        case 6: return P[c + nx] == 4 || P[c - 1] == 8;
+        case 8: return P[c + 1] == 6 || P[c + nx] == 2;
+        default: return false;
+    }
+}
+
+struct D8Traits {
+    const int16_t* P;
+    __device__ __forceinline__ bool dont_cross(size_t c, int nx, int k) const { return dont_cross_d8(P, c, nx, k); }
+    // "adjacent cell drains": flowDir in 1..8 (src/d8.cpp:537)
+    __device__ __forceinline__ bool has_direction(size_t n) const { const int16_t v = P[n]; return v > 0 && v < 9; }
+};
+
+// Collect flat cells (p == 0) into the list; initialise lvl/rq: -1 = not a flat cell, 0 = flat, unvisited
+__global__ __launch_bounds__(256) void d8_collect_flats_kernel(const int16_t* __restrict__ P, size_t n, int32_t* __restrict__ lvl,
+                                                               int32_t* __restrict__ rq, uint32_t* __restrict__ list,
+                                                               unsigned long long* __restrict__ counter) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    bool f = false;
+    if (i < n) {
+        f = (P[i] == 0);
+        lvl[i] = f ? 0 : -1;
+        rq[i] = f ? 0 : -1;
+    }
+    wave_append(f, uint32_t(i), list, counter);
+}
+
+// setFlow2 (src/d8.cpp:412-454) for every cell of the flat list
+__global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restrict__ Z, int nx, const double* __restrict__ fact,
+                                                          const uint32_t* __restrict__ list, unsigned long long nq,
+                                                          const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+                                                          FlatLevels fl, int16_t* __restrict__ P) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const size_t c = list[q];
+    const int y = int(c / size_t(nx));
+    const double* f = fact + size_t(y) * 9;
+    const int e2c = int(flat_elev2(lvl[c], rq[c], fl));
+    const float z0 = Z[c];
+    float smax = 0.f;
+    int16_t dir = P[c];   // 0, or nodata for a cell marked as pit in this iteration
+    const int order[8] = {1, 3, 5, 7, 2, 4, 6, 8};
+    for (int o = 0; o < 8; o++) {
+        const int k = order[o];
+        const size_t n = size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k));
+        if (rq[n] > 0) {   // dn > 0: neighbour is a marked flat cell
+            const int e2n = int(flat_elev2(lvl[n], rq[n], fl));
+            const float slope = (float)(f[k] * (double)(e2c - e2n));
+            if (slope > smax) { dir = int16_t(k); smax = slope; }
+        } else {
+            const float ed = z0 - Z[n];
+            if (ed >= 0) { dir = int16_t(k); break; }
+        }
+    }
+    P[c] = dir;
+}
+
+// Q' = cells of Q still 0
+__global__ __launch_bounds__(256) void d8_recollect_kernel(const int16_t* __restrict__ P, const uint32_t* __restrict__ list,
+                                                           unsigned long long nq, uint32_t* __restrict__ out,
+                                                           unsigned long long* __restrict__ counter) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    bool f = false;
+    uint32_t c = 0;
+    if (q < nq) { c = list[q]; f = (P[c] == 0); }
+    wave_append(f, c, out, counter);
+}
+
+__global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
+                                                           const int32_t* __restrict__ lvl, int16_t* __restrict__ P) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const size_t c = list[q];
+    if (lvl[c] == 0) P[c] = TDX_P_NODATA;   // never stopped incrementing: enclosed pit (src/d8.cpp:559-585)
+}
+
+}  // namespace
+
+int tdx_build_fact_table(tdx_context* ctx, int64_t ny, const double* dxc, const double* dyc, double** d_fact_out) {
+    // fact[j][k] = 1/sqrt((d1*dx)^2 + (d2*dy)^2) in double on the host (src/d8.cpp:369-377); index 0 = 0
+    static const int hd1[9] = {0, 1, 1, 0, -1, -1, -1, 0, 1};
+    static const int hd2[9] = {0, 0, -1, -1, -1, 0, 1, 1, 1};
+    std::vector<double> fact(size_t(ny) * 9, 0.0);
+    for (int64_t m = 0; m < ny; m++)
+        for (int k = 1; k <= 8; k++)
+            fact[size_t(m) * 9 + size_t(k)] = (double)(1. / sqrt(hd1[k] * hd1[k] * dxc[m] * dxc[m] + hd2[k] * hd2[k] * dyc[m] * dyc[m]));
+    double* d_fact = static_cast<double*>(ctx->scratch(TDX_S_J, fact.size() * sizeof(double)));
+    if (!d_fact) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_fact, fact.data(), fact.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // `fact` is a local
+    *d_fact_out = d_fact;
+    return TDX_OK;
+}
+
+extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                                 const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_p || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_d8flowdir_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int inx = int(nx), iny = int(ny);
+    const size_t n = size_t(nx) * size_t(ny);
+    double* d_fact = nullptr;
+    int rc = tdx_build_fact_table(ctx, ny, dxc, dyc, &d_fact);
+    if (rc != TDX_OK) return rc;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+
+    ctx->begin_call(stats);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        dim3 grid((inx + 63) / 64, (iny + 3) / 4);
+        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_fact, d_p, d_sd8, d_cnt);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    unsigned long long total = ctx->h_mail[0];
+    if (stats) { stats->flats_initial = int64_t(total); stats->flats_left = int64_t(total); }
+
+    if (total > 0) {
+        // working storage for flat resolution
+        int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+        int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+        uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(total) * 4));
+        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
+        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, size_t(total) * 4));
+        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_F, size_t(total) * 4));
+        uint32_t* s2 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(total) * 4));
+        uint32_t* ra = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(total) * 4));
+        if (!lvl || !rq || !qlist || !qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
+        float* zwork = nullptr;            // allocated only if a second iteration is needed
+        const float* zcur = d_fel;
+        FlatBuffers fbuf{lvl, rq, fa, fb, s2, ra};
+
+        // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503)
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(d8_collect_flats_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, n, lvl, rq, qlist, d_cnt);
+        unsigned long long nq = total;
+        unsigned long long last = total;
+        bool first = true;
+        for (;;) {
+            if (!first) {
+                // later calls: elev2 / dn are re-created (src/d8.cpp:483-486): reset markers of the new Q
+                rc = flats_reset_markers(ctx, n, qlist, nq, lvl, rq);
+                if (rc != TDX_OK) return rc;
+            }
+            first = false;
+            FlatLevels fl;
+            D8Traits tr{d_p};
+            rc = flats_bfs<D8Traits>(ctx, tr, zcur, inx, iny, qlist, nq, fbuf, &fl, stats);
+            if (rc != TDX_OK) return rc;
+            {
+                TdxSpan sp(ctx, TDX_K_FLATDIR);
+                if (fl.has_pits)
+                    hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
+                hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+                hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
+            }
+            total = ctx->h_mail[0];
+            if (stats) { stats->flat_iterations++; stats->flats_left = int64_t(total); }
+            if (!(total > 0 && total < last)) break;     // src/d8.cpp:307
+            // another iteration: elevDEM := (float)elev2 for ALL cells (src/d8.cpp:669-675)
+            if (!zwork) {
+                zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4));
+                if (!zwork) return TDX_ERR_NOMEM;
+            }
+            rc = flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);
+            if (rc != TDX_OK) return rc;
+            zcur = zwork;
+            std::swap(qlist, qnext);
+            nq = total;
+            last = total;
+        }
+    }
+    TDX_HIP_CHECK(ctx, hipGetLastError());
+    ctx->end_call();
+    return TDX_OK;
+}
+
+extern "C" int tdx_d8flowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,
+                             const double* dxc, const double* dyc, int16_t* p, float* sd8, tdx_stats* stats) {
+    if (!ctx || !fel || !p || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_d8flowdir: bad argument");
+    const size_t n = size_t(nx) * size_t(ny);
+    float* d_z = static_cast<float*>(ctx->scratch(TDX_S_IO0, n * 4));
+    int16_t* d_p = static_cast<int16_t*>(ctx->scratch(TDX_S_IO1, n * 2));
+    float* d_s = sd8 ? static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4)) : nullptr;
+    if (!d_z || !d_p || (sd8 && !d_s)) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_z, fel, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = tdx_d8flowdir_dev(ctx, d_z, nx, ny, fel_nodata, dxc, dyc, d_p, d_s, stats);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(p, d_p, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (sd8) TDX_HIP_CHECK(ctx, hipMemcpyAsync(sd8, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
+}

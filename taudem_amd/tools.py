@@ -1,0 +1,56 @@
+"""File-level tool functions with the names and argument lists of the reference's tool functions
+(the interface the reference's ``*mn.cpp`` mains and the ArcGIS ``pyfiles/*.py`` wrappers drive):
+
+    flood      src/flood.h:1-2            setdird8  src/d8.h:5          aread8  src/aread8.h:3
+    setdir     src/dinf.cpp:109           area      src/areadinf.h:2    dmarea  src/dinfdecayaccum.cpp:61-62
+
+They read GeoTIFF inputs, run the HIP hot path on one GPU and write GeoTIFF outputs; return codes are
+the reference's (0 ok, 1 mismatch; 21/22/5 where the reference would MPI_Abort with that code).
+"""
+from __future__ import annotations
+
+from . import _lib
+
+
+def _b(s):
+    return (s or "").encode()
+
+
+def set_device(device: int):
+    return _lib.load().tdx_tool_set_device(int(device))
+
+
+def flood(demfile, felfile, sfdrfile="", usesfdr=0, verbose=False, is_4Point=False, use_mask=False, maskfile=""):
+    return _lib.load().tdx_tool_pitremove(_b(demfile), _b(felfile), _b(sfdrfile), int(usesfdr), int(verbose), int(is_4Point), int(use_mask), _b(maskfile))
+
+
+def setdird8(demfile, pointfile, slopefile, flowfile="", useflowfile=0):
+    return _lib.load().tdx_tool_d8flowdir(_b(demfile), _b(pointfile), _b(slopefile), _b(flowfile), int(useflowfile))
+
+
+def aread8(pfile, afile, datasrc="", lyrname="", uselyrname=0, lyrno=0, wfile="", useOutlets=0, usew=0, contcheck=1):
+    return _lib.load().tdx_tool_aread8(_b(pfile), _b(afile), _b(datasrc), _b(lyrname), int(uselyrname), int(lyrno), _b(wfile), int(useOutlets),
+                                      int(usew), int(contcheck))
+
+
+def setdir(demfile, angfile, slopefile, flowfile="", useflowfile=0):
+    return _lib.load().tdx_tool_dinfflowdir(_b(demfile), _b(angfile), _b(slopefile), _b(flowfile), int(useflowfile))
+
+
+def area(angfile, scafile, datasrc="", lyrname="", uselyrname=0, lyrno=0, wfile="", useOutlets=0, usew=0, contcheck=1):
+    return _lib.load().tdx_tool_areadinf(_b(angfile), _b(scafile), _b(datasrc), _b(lyrname), int(uselyrname), int(lyrno), _b(wfile),
+                                        int(useOutlets), int(usew), int(contcheck))
+
+
+def dmarea(angfile, adecfile, dmfile, datasrc="", lyrname="", uselyrname=0, lyrno=0, wfile="", useOutlets=0, usew=0, contcheck=1):
+    return _lib.load().tdx_tool_dinfdecayaccum(_b(angfile), _b(adecfile), _b(dmfile), _b(datasrc), _b(lyrname), int(uselyrname), int(lyrno),
+                                              _b(wfile), int(useOutlets), int(usew), int(contcheck))
+
+
+def nameadd(arg: str, suff: str) -> str:
+    """nameadd() of src/commonLib.cpp:53-73: insert `suff` before the extension of `arg`."""
+    dot = arg.rfind(".")
+    if dot < 0:
+        return arg + suff
+    ext = arg[dot:]
+    return arg[:dot] + suff + ("" if "." in suff else ext)
