@@ -129,6 +129,15 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C taudem_amd/csrc` (hipcc, --offload-arch=gfx950). taudem_amd has no CPU fallback."
         )
+    # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.
+    # If torch is importable, load it FIRST so that this library binds to the already-loaded runtime
+    # (same SONAME) instead of pulling /opt/rocm's copy in beside it - with two HSA runtimes in one
+    # process whichever initialises second sees "no HIP GPUs".  torch is plumbing here (device memory,
+    # streams, torch.distributed), not a dependency of the C ABI itself.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less hosts use the system ROCm runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError = header/library mismatch: fail loudly

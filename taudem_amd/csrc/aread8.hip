@@ -22,6 +22,10 @@ namespace {
 using namespace tdxk;
 
 constexpr int32_t CNT_NOT_PART = 0x40000000;   // never reaches 0: the reference's int16 counter wraps instead (src/aread8.cpp:266-268)
+// A cell with no contributor is a SOURCE.  It must stay distinguishable from a cell whose counter was
+// driven to 0 by its contributors (that cell is evaluated by its last contributor's lane, and its own
+// lane may start later and must not evaluate it again), so sources carry a value no decrement produces.
+constexpr int32_t CNT_SOURCE = -1;
 
 // in-degree as in initNeighborD8up (src/commonLib.cpp:251-282)
 __device__ __forceinline__ int d8_indegree(const int16_t* __restrict__ P, int nx, int ny, int x, int y, int16_t nodata) {
@@ -45,7 +49,10 @@ __global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restric
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     const int16_t p = P[idx];
     int32_t c = CNT_NOT_PART;
-    if (!is_nodata_s(p, nodata) && p >= 0 && p <= 8) c = d8_indegree(P, nx, ny, x, y, nodata);
+    if (!is_nodata_s(p, nodata) && p >= 0 && p <= 8) {
+        c = d8_indegree(P, nx, ny, x, y, nodata);
+        if (c == 0) c = CNT_SOURCE;
+    }
     cnt[idx] = c;
     A[idx] = TDX_AREA_NODATA;
 }
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void ad8_outlet_expand_kernel(const int16_t* _
         }
         wave_append(push, uint32_t(n), fout, counter);
     }
-    if (live) cnt[c] = indeg;
+    if (live) cnt[c] = indeg ? indeg : CNT_SOURCE;
 }
 
 __global__ __launch_bounds__(256) void ad8_outlet_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout,
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
     size_t idx = 0;
     if (x < nx && y < ny) {
         idx = size_t(y) * size_t(nx) + size_t(x);
-        go = (cnt[idx] == 0);                   // source: participates and has no contributor
+        go = (cnt[idx] == CNT_SOURCE);          // participates and has no contributor
     }
     while (go) {
         const float a = ad8_evaluate(P, Wt, w_nodata, A, nx, ny, x, y, idx, nodata, contcheck);
@@ -158,12 +165,7 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
             }
         }
     }
-    if (nevaluated) {
-        // one atomic per wave
-        unsigned long long tot = done;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-        if (__lane_id() == 0 && tot) atomicAdd(nevaluated, tot);
-    }
+    (void)done; (void)nevaluated;
 }
 
 }  // namespace

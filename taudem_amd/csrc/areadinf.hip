@@ -1,10 +1,398 @@
-// placeholder - implemented after the D8 path is parity-green
+// AreaDinf and DinfDecayAccum on gfx950: replace the compute parts of area() (src/areadinf.cpp:151-265)
+// and dmarea() (src/dinfdecayaccum.cpp:178-291) plus initNeighborDinfup() (src/commonLib.cpp:92-238).
+//
+// Same dependency-driven evaluation as AreaD8 (aread8.hip): a cell is evaluated, by PULLING its
+// contributors in k = 1..8 order with the reference's mixed float/double arithmetic, at the moment its
+// last contributor finishes.  D-infinity splits flow between up to two downslope neighbours
+// (prop(), src/commonLib.cpp:76-91), so the lane that finishes a cell may release two cells: it
+// continues into the first and parks the second on a small private stack (overflow goes to a global
+// list that a follow-up launch drains).
+//
+// prop() needs atan2(dy,dx) only through the per-row table aref[] - computed on the host with the host
+// libm (one value per row); everything else is exactly-rounded +,-,/ on the device.
 #include "context.hpp"
-extern "C" int tdx_areadinf_dev(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, const float*, int,
-                                const int32_t*, const int32_t*, int64_t, float*, tdx_stats*) { return tdx_fail(ctx, TDX_ERR_ARG, "not implemented yet"); }
-extern "C" int tdx_areadinf(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, const float*, int,
-                            const int32_t*, const int32_t*, int64_t, float*, tdx_stats*) { return tdx_fail(ctx, TDX_ERR_ARG, "not implemented yet"); }
-extern "C" int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, const float*, float,
-                                      const float*, int, const int32_t*, const int32_t*, int64_t, float*, tdx_stats*) { return tdx_fail(ctx, TDX_ERR_ARG, "not implemented yet"); }
-extern "C" int tdx_dinfdecayaccum(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, const float*, float,
-                                  const float*, int, const int32_t*, const int32_t*, int64_t, float*, tdx_stats*) { return tdx_fail(ctx, TDX_ERR_ARG, "not implemented yet"); }
+#include "device_common.hpp"
+
+namespace {
+using namespace tdxk;
+
+#define TDX_PI 3.14159265359   /* src/commonLib.h:76 */
+constexpr int32_t CNT_NOT_PART = 0x40000000;
+constexpr int32_t CNT_SOURCE = -1;
+constexpr int WALK_STACK = 8;
+
+struct RowProp { double a2; double dx; };   // a2 = atan2(dyc[j], dxc[j]) from the host libm
+
+// aref[i] of prop() (src/commonLib.cpp:78-79)
+__device__ __forceinline__ double aref_at(int i, double a2) {
+    switch (i) {
+        case 0: return -a2;
+        case 1: return 0.;
+        case 2: return a2;
+        case 3: return (double)(0.5 * TDX_PI);
+        case 4: return TDX_PI - a2;
+        case 5: return (double)TDX_PI;
+        case 6: return TDX_PI + a2;
+        case 7: return (double)(1.5 * TDX_PI);
+        case 8: return 2. * TDX_PI - a2;
+        default: return (double)(2. * TDX_PI);
+    }
+}
+
+// prop() (src/commonLib.cpp:76-91)
+__device__ __forceinline__ double prop_dev(float a, int k, double a2) {
+    double p = 0.;
+    if (k <= 0) k = k + 8;
+    if (k == 1 && a > TDX_PI) a = (float)(a - 2.0 * TDX_PI);
+    const double lo = aref_at(k - 1, a2), mid = aref_at(k, a2), hi = aref_at(k + 1, a2);
+    if (a > lo && a < hi) {
+        if (a > mid) p = (hi - a) / (hi - mid);
+        else p = (a - lo) / (mid - lo);
+    }
+    if (p < 1e-5) return -1.;
+    return p;
+}
+
+// does neighbour k of (x,y) drain into (x,y)?  returns the proportion (>0) or a value <= 0
+__device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny, int x, int y,
+                                              int k, float nodata, size_t* nidx, bool* missing) {
+    const int xn = x + d1(k), yn = y + d2(k);
+    *missing = false;
+    if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { *missing = true; return -1.; }
+    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+    const float an = ANG[n];
+    if (is_nodata_f(an, nodata)) { *missing = true; return -1.; }
+    *nidx = n;
+    return prop_dev(an, (k + 4) % 8, rows[yn].a2);
+}
+
+__global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata,
+                                                         const RowProp* __restrict__ rows, int32_t* __restrict__ cnt,
+                                                         float* __restrict__ OUT, float out_nodata) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    int32_t c = CNT_NOT_PART;
+    if (!is_nodata_f(ANG[idx], nodata)) {
+        c = 0;
+        for (int k = 1; k <= 8; k++) {
+            size_t n; bool miss;
+            const float p = (float)inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);   // `float p` in the reference (commonLib.cpp:99)
+            if (!miss && p > 0.0f) c++;
+        }
+        if (c == 0) c = CNT_SOURCE;
+    }
+    cnt[idx] = c;
+    OUT[idx] = out_nodata;
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void dinf_outlet_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout,
+                                                               int nx, int ny, int32_t* __restrict__ mark, uint32_t* __restrict__ fout,
+                                                               unsigned long long* __restrict__ counter) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    bool push = false;
+    uint32_t c = 0;
+    if (o < nout) {
+        const int x = ox[o], y = oy[o];
+        if (x >= 0 && x < nx && y >= 0 && y < ny) {
+            c = uint32_t(size_t(y) * size_t(nx) + size_t(x));
+            push = (atomicCAS(&mark[c], 0, 1) == 0);
+        }
+    }
+    wave_append(push, c, fout, counter);
+}
+
+// upstream closure of the outlets (src/commonLib.cpp:165-233)
+__global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata,
+                                                                 const RowProp* __restrict__ rows, const uint32_t* __restrict__ fin,
+                                                                 unsigned long long nin, int32_t* __restrict__ cnt, int32_t* __restrict__ mark,
+                                                                 uint32_t* __restrict__ fout, unsigned long long* __restrict__ counter) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < nin;
+    const size_t c = live ? size_t(fin[q]) : 0;
+    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
+    int indeg = 0;
+    for (int k = 1; k <= 8; k++) {
+        bool push = false;
+        size_t n = 0;
+        if (live) {
+            bool miss;
+            const float p = (float)inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
+            if (!miss && p > 0.f) { indeg++; push = (atomicCAS(&mark[n], 0, 1) == 0); }
+        }
+        wave_append(push, uint32_t(n), fout, counter);
+    }
+    if (live) cnt[c] = indeg ? indeg : CNT_SOURCE;
+}
+
+// ---- flow algebra ---------------------------------------------------------------------------------
+struct AreaAlg {   // src/areadinf.cpp:187-217
+    const float* W;
+    __device__ __forceinline__ float evaluate(const float* __restrict__ ANG, const RowProp* __restrict__ rows, float* __restrict__ OUT,
+                                              int nx, int ny, int x, int y, size_t idx, float nodata, int contcheck) const {
+        float areares = 0.f;
+        bool con = false;
+        for (int k = 1; k <= 8; k++) {
+            size_t n; bool miss;
+            const double p = inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
+            if (miss) { con = true; continue; }
+            if (p > 0.0) {
+                const float v = ld_agent(&OUT[n]);
+                if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
+                else areares = (float)(areares + p * v);
+            }
+        }
+        if (W) areares = areares + W[idx];
+        else areares = (float)(areares + rows[y].dx);
+        return (con && contcheck == 1) ? TDX_AREA_NODATA : areares;
+    }
+};
+
+struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
+    const float* W;
+    const float* DM;
+    float dm_nodata;
+    __device__ __forceinline__ float evaluate(const float* __restrict__ ANG, const RowProp* __restrict__ rows, float* __restrict__ OUT,
+                                              int nx, int ny, int x, int y, size_t idx, float nodata, int contcheck) const {
+        float acc = W ? W[idx] : (float)rows[y].dx;
+        bool con = false;
+        for (int k = 1; k <= 8; k++) {
+            size_t n; bool miss;
+            const double p = inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
+            if (miss) { con = true; continue; }
+            if (p > 0.) {
+                const float area = ld_agent(&OUT[n]);
+                const float dm = DM[n];
+                if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
+                else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
+            }
+        }
+        return (con && contcheck == 1) ? TDX_ANG_NODATA : acc;
+    }
+};
+
+// walk from `start` (a ready cell) downstream while this lane keeps being the last contributor
+template <class Alg>
+__device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
+                                                        float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+                                                        uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
+                                                        unsigned long long ovf_cap, size_t start) {
+    uint32_t stack[WALK_STACK];
+    int sp = 0;
+    unsigned long long done = 0;
+    size_t idx = start;
+    bool go = true;
+    while (go) {
+        const int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
+        const float v = alg.evaluate(ANG, rows, OUT, nx, ny, x, y, idx, nodata, contcheck);
+        st_agent(&OUT[idx], v);
+        done++;
+        drain_stores();
+        go = false;
+        const float ang = ANG[idx];
+        const double a2 = rows[y].a2;
+        for (int k = 1; k <= 8; k++) {
+            const double p = prop_dev(ang, k, a2);
+            if (p > 0.0) {
+                const int xn = x + d1(k), yn = y + d2(k);
+                if (xn >= 0 && xn < nx && yn >= 0 && yn < ny) {
+                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == 1) {
+                        if (!go) { idx = n; go = true; }
+                        else if (sp < WALK_STACK) stack[sp++] = uint32_t(n);
+                        else {
+                            const unsigned long long slot = atomicAdd(ovf_count, 1ull);
+                            if (slot < ovf_cap) ovf[slot] = uint32_t(n);
+                        }
+                    }
+                }
+            }
+        }
+        if (!go && sp > 0) { idx = stack[--sp]; go = true; }
+    }
+    return done;
+}
+
+template <class Alg>
+__global__ __launch_bounds__(256) void dinf_walk_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
+                                                        float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+                                                        uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
+                                                        unsigned long long ovf_cap) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    if (cnt[idx] != CNT_SOURCE) return;
+    dinf_walk(alg, ANG, rows, nx, ny, nodata, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, idx);
+}
+
+template <class Alg>
+__global__ __launch_bounds__(256) void dinf_walk_list_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
+                                                             float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+                                                             const uint32_t* __restrict__ list, unsigned long long nlist,
+                                                             uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
+                                                             unsigned long long ovf_cap) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nlist) return;
+    dinf_walk(alg, ANG, rows, nx, ny, nodata, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, size_t(list[q]));
+}
+
+template <class Alg>
+int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata, const double* dxc, const double* dyc,
+                   int contcheck, const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_out, float out_nodata,
+                   tdx_stats* stats) {
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "outlets missing");
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int inx = int(nx), iny = int(ny);
+    const size_t n = size_t(nx) * size_t(ny);
+    std::vector<RowProp> rows;
+    rows.resize(size_t(ny));
+    for (int64_t j = 0; j < ny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
+    RowProp* d_rows = static_cast<RowProp*>(ctx->scratch(TDX_S_J, rows.size() * sizeof(RowProp)));
+    int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+    const unsigned long long ovf_cap = n / 4 + 1024;
+    uint32_t* ovfa = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ovf_cap) * 4));
+    uint32_t* ovfb = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ovf_cap) * 4));
+    if (!d_rows || !cnt || !ovfa || !ovfb) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowProp), hipMemcpyHostToDevice, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+    const dim3 grid2d((inx + 63) / 64, (iny + 3) / 4);
+
+    ctx->begin_call(stats);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    if (n_outlets < 0) {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, cnt, d_out, out_nodata);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    } else {
+        TdxSpan sp(ctx, TDX_K_BFS);
+        int32_t* mark = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
+        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, n * 4));
+        int32_t* d_ox = static_cast<int32_t*>(ctx->scratch(TDX_S_E, size_t(n_outlets ? n_outlets : 1) * 4));
+        int32_t* d_oy = static_cast<int32_t*>(ctx->scratch(TDX_S_F, size_t(n_outlets ? n_outlets : 1) * 4));
+        if (!mark || !fa || !fb || !d_ox || !d_oy) return TDX_ERR_NOMEM;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, cnt, CNT_NOT_PART, n);
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_out, out_nodata, n);
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(mark, 0, n * 4, s));
+        unsigned long long ncur = 0;
+        if (n_outlets > 0) {
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_ox, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oy, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(dinf_outlet_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_ox, d_oy, int(n_outlets),
+                               inx, iny, mark, fa, d_cnt);
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            ncur = ctx->h_mail[0];
+        }
+        uint32_t *cur = fa, *nxt = fb;
+        while (ncur > 0) {
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(dinf_outlet_expand_kernel, dim3(tdx_blocks_for(ncur, 256)), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows,
+                               cur, ncur, cnt, mark, nxt, d_cnt);
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            ncur = ctx->h_mail[0];
+            std::swap(cur, nxt);
+            if (stats) stats->launches[TDX_K_BFS]++;
+        }
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+    }
+    int64_t rounds = 0;
+    {
+        TdxSpan sp(ctx, TDX_K_ACCUM);
+        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, ang_nodata, contcheck, cnt, d_out,
+                           ovfa, d_cnt, ovf_cap);
+        rounds++;
+        uint32_t *lst = ovfa, *nxt = ovfb;
+        for (;;) {   // drain cells that did not fit a lane's private stack
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            const unsigned long long novf = ctx->h_mail[0];
+            if (novf == 0) break;
+            if (novf > ovf_cap) return tdx_fail(ctx, TDX_ERR_NOMEM, "D-infinity accumulation overflow list exhausted");
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, ang_nodata,
+                               contcheck, cnt, d_out, lst, novf, nxt, d_cnt, ovf_cap);
+            std::swap(lst, nxt);
+            rounds++;
+        }
+        if (stats) stats->launches[TDX_K_ACCUM] += rounds;
+    }
+    TDX_HIP_CHECK(ctx, hipGetLastError());
+    tdx_stats* st = stats;
+    ctx->end_call();
+    if (st) st->rounds = rounds;
+    return TDX_OK;
+}
+
+}  // namespace
+
+extern "C" int tdx_areadinf_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                                const double* dxc, const double* dyc, const float* d_w, int contcheck,
+                                const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_sca, tdx_stats* stats) {
+    if (!ctx || !d_ang || !d_sca || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_areadinf_dev: bad argument");
+    AreaAlg alg{d_w};
+    return run_dinf_accum(ctx, alg, d_ang, nx, ny, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets, d_sca, TDX_AREA_NODATA, stats);
+}
+
+extern "C" int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                                      const double* dxc, const double* dyc, const float* d_dm, float dm_nodata, const float* d_w, int contcheck,
+                                      const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_dsca, tdx_stats* stats) {
+    if (!ctx || !d_ang || !d_dm || !d_dsca || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfdecayaccum_dev: bad argument");
+    DecayAlg alg{d_w, d_dm, dm_nodata};
+    return run_dinf_accum(ctx, alg, d_ang, nx, ny, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets, d_dsca, TDX_ANG_NODATA, stats);
+}
+
+extern "C" int tdx_areadinf(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                            const double* dxc, const double* dyc, const float* w, int contcheck,
+                            const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* sca, tdx_stats* stats) {
+    if (!ctx || !ang || !sca || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_areadinf: bad argument");
+    const size_t n = size_t(nx) * size_t(ny);
+    float* d_a = static_cast<float*>(ctx->scratch(TDX_S_IO0, n * 4));
+    float* d_s = static_cast<float*>(ctx->scratch(TDX_S_IO1, n * 4));
+    float* d_w = w ? static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4)) : nullptr;
+    if (!d_a || !d_s || (w && !d_w)) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_a, ang, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (w) TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_w, w, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = tdx_areadinf_dev(ctx, d_a, nx, ny, ang_nodata, dxc, dyc, d_w, contcheck, outlet_x, outlet_y, n_outlets, d_s, stats);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(sca, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
+}
+
+extern "C" int tdx_dinfdecayaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                                  const double* dxc, const double* dyc, const float* dm, float dm_nodata, const float* w, int contcheck,
+                                  const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* dsca, tdx_stats* stats) {
+    if (!ctx || !ang || !dm || !dsca || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfdecayaccum: bad argument");
+    const size_t n = size_t(nx) * size_t(ny);
+    float* d_a = static_cast<float*>(ctx->scratch(TDX_S_IO0, n * 4));
+    float* d_s = static_cast<float*>(ctx->scratch(TDX_S_IO1, n * 4));
+    float* d_d = static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4));
+    float* d_w = w ? static_cast<float*>(ctx->scratch(TDX_S_IO3, n * 4)) : nullptr;
+    if (!d_a || !d_s || !d_d || (w && !d_w)) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_a, ang, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_d, dm, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (w) TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_w, w, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = tdx_dinfdecayaccum_dev(ctx, d_a, nx, ny, ang_nodata, dxc, dyc, d_d, dm_nodata, d_w, contcheck, outlet_x, outlet_y, n_outlets, d_s, stats);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(dsca, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
+}

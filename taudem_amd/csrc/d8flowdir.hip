@@ -27,48 +27,77 @@ namespace {
 
 using namespace tdxk;
 
+constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-thread block
+
+// One lane walks down a column segment keeping the 3x3 window in registers (3 loads per new row).
+// Besides p and sd8 it initialises the flat-resolution markers (lvl/rq: 0 flat, -1 otherwise) and
+// appends the flat cells to `qlist` with ONE atomic per block.
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
-                                                       float* __restrict__ SD8, unsigned long long* __restrict__ nflat) {
+                                                       float* __restrict__ SD8, int32_t* __restrict__ lvl, int32_t* __restrict__ rq,
+                                                       uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool flat = false;
-    if (x < nx && y < ny) {
-        const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-        int16_t p = TDX_P_NODATA;
-        float sd = -1.0f;
-        const float z0 = Z[idx];
-        const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
-        if (!edge && !is_nodata_f(z0, nodata)) {
-            float zn[9];
-            bool con = false;
+    const int ybase = blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
+    const bool colok = x < nx;
+    const int xm = x > 0 ? x - 1 : x, xp = (x < nx - 1) ? x + 1 : (colok ? x : nx - 1);
+    const int xc = colok ? x : nx - 1;
+    auto ldrow = [&](int y, float& a, float& b, float& c) {
+        if (y >= 0 && y < ny) {
+            const float* r = Z + size_t(y) * size_t(nx);
+            a = r[xm]; b = r[xc]; c = r[xp];
+        } else { a = b = c = nodata; }
+    };
+    float n0, n1, n2, c0, c1, c2, s0, s1, s2;
+    ldrow(ybase - 1, n0, n1, n2);
+    ldrow(ybase, c0, c1, c2);
+    unsigned flatmask = 0;
 #pragma unroll
-            for (int k = 1; k <= 8; k++) {
-                zn[k] = Z[size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k))];
-                con = con || is_nodata_f(zn[k], nodata);
-            }
-            if (!con) {
-                const double* f = fact + size_t(y) * 9;
-                float smax = 0.f;
-                int dir = 0;
-                const int order[8] = {1, 3, 5, 7, 2, 4, 6, 8};
-#pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    const int k = order[o];
-                    const float slope = (float)(f[k] * (double)(z0 - zn[k]));
-                    if (slope > smax) { smax = slope; dir = k; }
-                }
-                p = int16_t(dir);
-                flat = (dir == 0);
-                // calcSlope: elevDiff * fact[j][dir]; dir == 0 -> (z0 - z0) * fact[j][0] = 0
-                sd = (dir == 0) ? 0.0f : (float)((z0 - zn[dir]) * f[dir]);
-            }
-        }
-        P[idx] = p;
-        if (SD8) SD8[idx] = sd;
+    for (int r = 0; r < SLOPE_ROWS; r++) {
+        const int y = ybase + r;
+        ldrow(y + 1, s0, s1, s2);
+        if (colok && y < ny) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            int16_t p = TDX_P_NODATA;
+            float sd = -1.0f;
+            const float z0 = c1;
+            const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
+            if (!edge && !is_nodata_f(z0, nodata)) {
+                const bool con = is_nodata_f(n0, nodata) || is_nodata_f(n1, nodata) || is_nodata_f(n2, nodata) || is_nodata_f(c0, nodata) ||
+                                 is_nodata_f(c2, nodata) || is_nodata_f(s0, nodata) || is_nodata_f(s1, nodata) || is_nodata_f(s2, nodata);
+                if (!con) {
+                    const double* f = fact + size_t(y) * 9;
+                    // fact[j][k]: 1/dx for E,W; 1/dy for N,S; 1/diag for the diagonals (src/d8.cpp:375)
+                    const double fE = f[1], fN = f[3], fD = f[2];
+                    float smax = 0.f;
+                    int dir = 0;
+                    // candidate order 1,3,5,7 then 2,4,6,8; strict '>' keeps the first maximum (src/d8.cpp:113-148).
+                    // calcSlope re-evaluates elevDiff*fact[j][dir] = the winning slope itself; dir == 0 -> 0.
+#define TDX_D8_TRY(K, F, ZN)                                           \
+    {                                                                  \
+        const float slope = (float)((F) * (double)(z0 - (ZN)));        \
+        if (slope > smax) { smax = slope; dir = K; }                   \
     }
-    const unsigned long long b = __ballot(flat);
-    if (b && __lane_id() == __ffsll((long long)b) - 1) atomicAdd(nflat, (unsigned long long)__popcll(b));
+                    TDX_D8_TRY(1, fE, c2) TDX_D8_TRY(3, fN, n1) TDX_D8_TRY(5, fE, c0) TDX_D8_TRY(7, fN, s1)
+                    TDX_D8_TRY(2, fD, n2) TDX_D8_TRY(4, fD, n0) TDX_D8_TRY(6, fD, s0) TDX_D8_TRY(8, fD, s2)
+#undef TDX_D8_TRY
+                    p = int16_t(dir);
+                    if (dir == 0) flatmask |= (1u << r);
+                    sd = smax;
+                }
+            }
+            P[idx] = p;
+            if (SD8) SD8[idx] = sd;
+            const int32_t mk = (p == 0) ? 0 : -1;
+            lvl[idx] = mk;
+            rq[idx] = mk;
+        }
+        n0 = c0; n1 = c1; n2 = c2;
+        c0 = s0; c1 = s1; c2 = s2;
+    }
+    unsigned long long pos = block_reserve(unsigned(__popc(flatmask)), nflat);
+#pragma unroll
+    for (int r = 0; r < SLOPE_ROWS; r++)
+        if (flatmask & (1u << r)) qlist[pos++] = uint32_t(size_t(ybase + r) * size_t(nx) + size_t(x));
 }
 
 // D8 dontCross (src/d8.cpp:54-100) for an interior cell at linear index c
@@ -88,20 +117,6 @@ struct D8Traits {
     // "adjacent cell drains": flowDir in 1..8 (src/d8.cpp:537)
     __device__ __forceinline__ bool has_direction(size_t n) const { const int16_t v = P[n]; return v > 0 && v < 9; }
 };
-
-// Collect flat cells (p == 0) into the list; initialise lvl/rq: -1 = not a flat cell, 0 = flat, unvisited
-__global__ __launch_bounds__(256) void d8_collect_flats_kernel(const int16_t* __restrict__ P, size_t n, int32_t* __restrict__ lvl,
-                                                               int32_t* __restrict__ rq, uint32_t* __restrict__ list,
-                                                               unsigned long long* __restrict__ counter) {
-    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-    bool f = false;
-    if (i < n) {
-        f = (P[i] == 0);
-        lvl[i] = f ? 0 : -1;
-        rq[i] = f ? 0 : -1;
-    }
-    wave_append(f, uint32_t(i), list, counter);
-}
 
 // setFlow2 (src/d8.cpp:412-454) for every cell of the flat list
 __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restrict__ Z, int nx, const double* __restrict__ fact,
@@ -133,15 +148,23 @@ __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restric
     P[c] = dir;
 }
 
-// Q' = cells of Q still 0
+// Q' = cells of Q still 0 (8 list entries per lane, one atomic per block)
 __global__ __launch_bounds__(256) void d8_recollect_kernel(const int16_t* __restrict__ P, const uint32_t* __restrict__ list,
                                                            unsigned long long nq, uint32_t* __restrict__ out,
                                                            unsigned long long* __restrict__ counter) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    bool f = false;
-    uint32_t c = 0;
-    if (q < nq) { c = list[q]; f = (P[c] == 0); }
-    wave_append(f, c, out, counter);
+    const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
+    uint32_t keep[8];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned long long q = base + (unsigned long long)i * 256;
+        if (q < nq) {
+            const uint32_t c = list[q];
+            if (P[c] == 0) keep[cnt++] = c;
+        }
+    }
+    unsigned long long pos = block_reserve(cnt, counter);
+    for (unsigned i = 0; i < cnt; i++) out[pos + i] = keep[i];
 }
 
 __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
@@ -183,13 +206,18 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
     int rc = tdx_build_fact_table(ctx, ny, dxc, dyc, &d_fact);
     if (rc != TDX_OK) return rc;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+    // flat-resolution markers and the flat queue are produced by the slope pass itself
+    int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+    int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+    uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
+    if (!lvl || !rq || !qlist) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (iny + 3) / 4);
-        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_fact, d_p, d_sd8, d_cnt);
+        dim3 grid((inx + 63) / 64, (iny + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_fact, d_p, d_sd8, lvl, rq, qlist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -199,22 +227,17 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
 
     if (total > 0) {
         // working storage for flat resolution
-        int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-        int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
-        uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(total) * 4));
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
         uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, size_t(total) * 4));
         uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_F, size_t(total) * 4));
         uint32_t* s2 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(total) * 4));
         uint32_t* ra = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(total) * 4));
-        if (!lvl || !rq || !qlist || !qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
+        if (!qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
         float* zwork = nullptr;            // allocated only if a second iteration is needed
         const float* zcur = d_fel;
         FlatBuffers fbuf{lvl, rq, fa, fb, s2, ra};
 
-        // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503)
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(d8_collect_flats_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, n, lvl, rq, qlist, d_cnt);
+        // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
         unsigned long long nq = total;
         unsigned long long last = total;
         bool first = true;
@@ -235,7 +258,7 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
                     hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
                 hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-                hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
+                hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
                 TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);

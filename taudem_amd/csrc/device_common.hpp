@@ -40,6 +40,40 @@ __device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t*
     }
 }
 
+
+// Block-wide (256 threads, all must call) reservation of list slots: thread contributes `c` items and
+// gets the index of its first item; ONE global atomic per block.  A single hot counter sustains only
+// ~90 M atomics/s on MI355X, so full-grid passes must reserve per block, not per wave.
+__device__ __forceinline__ unsigned long long block_reserve(unsigned c, unsigned long long* __restrict__ counter) {
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned long long s_base;
+    const int lane = int(threadIdx.x & 63), w = int(threadIdx.x >> 6);
+    unsigned v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    __syncthreads();                       // previous use of s_wave / s_base is over
+    if (lane == 63) s_wave[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned wave_off = 0;
+    for (int i = 0; i < w; i++) wave_off += s_wave[i];
+    return s_base + wave_off + (v - c);
+}
+
+// Sharded event counter: 32 counters one cache line apart; the host (or a reader kernel) sums them.
+constexpr int kCounterShards = 32;
+constexpr int kCounterStride = 16;   // in unsigned long long = 128 bytes
+__device__ __forceinline__ void sharded_add(unsigned long long* __restrict__ shards, unsigned long long v) {
+    if (v) atomicAdd(shards + size_t(blockIdx.x + blockIdx.y * 7u) % kCounterShards * kCounterStride, v);
+}
+
 // agent-scope relaxed accessors: sc1 loads/stores that bypass the per-CU L1 and are coherent
 // across the 8 XCD L2s (MI355X_MICROARCH.md, inter-workgroup visibility)
 __device__ __forceinline__ float ld_agent(const float* p) {

@@ -1,8 +1,333 @@
-// placeholder - implemented after the D8 path is parity-green
+// DinfFlowDir on gfx950: replaces the compute part of setdir() (src/dinf.cpp:156-243).
+//
+//   dinf_slope_kernel   setPosDirDinf + SET2 + VSLOPE (src/dinf.cpp:530-595, 317-373, 286-313): eight
+//                       triangular facets per cell in fp64, steepest facet -> angle (f32) and slope (f32)
+//   flat resolution     same incfall/incrise breadth-first sweeps as D8 (flats.hpp) with the D-infinity
+//                       tests: "has a direction" = angle >= 0 (src/dinf.cpp:678), flat = angle < 0 and not
+//                       nodata (src/dinf.cpp:636-641), and the reference's dontCross that compares the
+//                       FLOAT angle of the cardinal neighbours with 2,4,6,8 (src/dinf.cpp:58-105, sic)
+//   dinf_set2flat_kernel the 4-case SET2 overload on real / artificial elevations (src/dinf.cpp:375-528)
+//
+// fp64 arithmetic is +,-,*,/,sqrt (exactly rounded; the library is built with -ffp-contract=off like
+// the x86-64 reference build) plus atan2.  AD = atan2(D2,D1) depends only on the row's cell size and is
+// taken from a host table computed with the host libm; the per-facet atan2(S2,S1) uses the device libm,
+// which can differ from glibc in the last ulp of the DOUBLE - visible in the float32 angle only when that
+// ulp straddles a float32 rounding boundary (tests allow 1 float32 ulp on `ang`; facet choice and slope
+// are compared exactly).
 #include "context.hpp"
-extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, float*, float*, tdx_stats*) {
-    return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir: not implemented yet");
+#include "device_common.hpp"
+#include "flats.hpp"
+
+namespace {
+using namespace tdxk;
+
+#define TDX_PI 3.14159265359   /* src/commonLib.h:76 */
+
+// facet tables (src/dinf.cpp:328-335)
+__device__ __constant__ const int kID1[9] = {0, 1, 2, 2, 1, 1, 2, 2, 1};
+__device__ __constant__ const int kID2[9] = {0, 2, 1, 1, 2, 2, 1, 1, 2};
+__device__ __constant__ const int kI1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0};
+__device__ __constant__ const int kI2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1};
+__device__ __constant__ const int kJ1[9] = {0, 1, 0, 0, -1, -1, 0, 0, 1};
+__device__ __constant__ const int kJ2[9] = {0, 1, 1, -1, -1, -1, -1, 1, 1};
+__device__ __constant__ const float kANGC[9] = {0, 0.f, 1.f, 1.f, 2.f, 2.f, 3.f, 3.f, 4.f};
+__device__ __constant__ const float kANGF[9] = {0, 1.f, -1.f, 1.f, -1.f, 1.f, -1.f, 1.f, -1.f};
+
+// per-row geometry: DXX[1]=dx, DXX[2]=dy, DD, AD12 = atan2(dy,dx) [D1=dx,D2=dy], AD21 = atan2(dx,dy)
+struct RowGeom { double dx, dy, dd, ad12, ad21; };
+
+// VSLOPE (src/dinf.cpp:286-313); AD supplied from the host table
+__device__ __forceinline__ void vslope(double E0, double E1, double E2, double D1, double D2, double DD, double AD, double& S, double& A) {
+    double S1 = 0, S2 = 0;
+    if (D1 != 0) S1 = (E0 - E1) / D1;
+    if (D2 != 0) S2 = (E1 - E2) / D2;
+    if (S2 == 0 && S1 == 0) A = 0;
+    else A = atan2(S2, S1);
+    if (A < 0.) { A = 0.; S = S1; }
+    else if (A > AD) { A = AD; S = (E0 - E2) / DD; }
+    else S = sqrt(S1 * S1 + S2 * S2);
 }
-extern "C" int tdx_dinfflowdir(tdx_context* ctx, const float*, int64_t, int64_t, float, const double*, const double*, float*, float*, tdx_stats*) {
-    return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir: not implemented yet");
+
+__device__ __forceinline__ void facet_geom(const RowGeom& g, int K, double& D1, double& D2, double& AD) {
+    const bool one = (kID1[K] == 1);
+    D1 = one ? g.dx : g.dy;
+    D2 = one ? g.dy : g.dx;
+    AD = one ? g.ad12 : g.ad21;
+}
+
+__global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict__ Z, int nx, int ny, float nodata,
+                                                         const RowGeom* __restrict__ geom, float* __restrict__ ANG,
+                                                         float* __restrict__ SLP, unsigned long long* __restrict__ nflat) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool flat = false;
+    if (x < nx && y < ny) {
+        const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+        float ang = TDX_ANG_NODATA, slp = -1.0f;
+        const float z0 = Z[idx];
+        const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
+        if (!edge && !is_nodata_f(z0, nodata)) {
+            bool con = false;
+#pragma unroll
+            for (int k = 1; k <= 8; k++) con = con || is_nodata_f(Z[size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k))], nodata);
+            if (!con) {
+                const RowGeom g = geom[y];
+                double SMAX = 0., AMAX = 0.;
+                int KD = 0;
+                for (int K = 1; K <= 8; K++) {
+                    // SET2(I=row, J=col): E1 at (row+I1, col+J1), E2 at (row+I2, col+J2)
+                    const double a = (double)z0;
+                    const double b = (double)Z[size_t(y + kI1[K]) * size_t(nx) + size_t(x + kJ1[K])];
+                    const double c = (double)Z[size_t(y + kI2[K]) * size_t(nx) + size_t(x + kJ2[K])];
+                    double D1, D2, AD, S, A;
+                    facet_geom(g, K, D1, D2, AD);
+                    vslope(a, b, c, D1, D2, g.dd, AD, S, A);
+                    if (S > SMAX) { SMAX = S; KD = K; AMAX = A; }
+                }
+                ang = -1.f;
+                if (KD > 0) ang = (float)(kANGC[KD] * (TDX_PI / 2) + kANGF[KD] * AMAX);
+                slp = (float)SMAX;
+                flat = (ang == -1.f);
+            }
+        }
+        ANG[idx] = ang;
+        SLP[idx] = slp;
+    }
+    (void)block_reserve(flat ? 1u : 0u, nflat);   // one atomic per block
+}
+
+struct DinfTraits {
+    const float* ANG;
+    // dinf.cpp:58-105: float angle of the cardinal neighbours compared with the D8 codes 2,4,6,8
+    __device__ __forceinline__ bool dont_cross(size_t c, int nx, int k) const {
+        switch (k) {
+            case 2: return ANG[c + 1] == 4 || ANG[c - nx] == 8;
+            case 4: return ANG[c - nx] == 6 || ANG[c - 1] == 2;
+            case 6: return ANG[c + nx] == 4 || ANG[c - 1] == 8;
+            case 8: return ANG[c + 1] == 6 || ANG[c + nx] == 2;
+            default: return false;
+        }
+    }
+    __device__ __forceinline__ bool has_direction(size_t n) const { return ANG[n] >= 0.0f; }
+};
+
+__device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, TDX_ANG_NODATA) && a < 0.0f; }
+
+// flat queue + markers (8 cells per lane, one atomic per block)
+__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t n, int32_t* __restrict__ lvl,
+                                                                 int32_t* __restrict__ rq, uint32_t* __restrict__ list,
+                                                                 unsigned long long* __restrict__ counter) {
+    const size_t base = size_t(blockIdx.x) * (256 * 8) + threadIdx.x;
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t c = base + size_t(i) * 256;
+        if (c < n) {
+            const bool f = dinf_is_flat(ANG[c]);
+            lvl[c] = f ? 0 : -1;
+            rq[c] = f ? 0 : -1;
+            if (f) mask |= 1u << i;
+        }
+    }
+    unsigned long long pos = block_reserve(unsigned(__popc(mask)), counter);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (mask & (1u << i)) list[pos++] = uint32_t(base + size_t(i) * 256);
+}
+
+__global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
+                                                             const int32_t* __restrict__ lvl, float* __restrict__ ANG) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const size_t c = list[q];
+    if (lvl[c] == 0) ANG[c] = TDX_ANG_NODATA;   // src/dinf.cpp:723
+}
+
+// SET2 overload (src/dinf.cpp:375-528) for every cell of the flat list
+__global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restrict__ Z, int nx, const RowGeom* __restrict__ geom,
+                                                            const uint32_t* __restrict__ list, unsigned long long nq,
+                                                            const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+                                                            FlatLevels fl, float* __restrict__ ANG) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const size_t c0 = list[q];
+    const int y = int(c0 / size_t(nx));
+    const RowGeom g = geom[y];
+    double SMAX = 0.0, AKD = 0.0;
+    int KD = 0;
+    bool diagOutFound = false;
+    const double a = (double)Z[c0];
+    const int16_t a1 = flat_elev2(lvl[c0], rq[c0], fl);
+    for (int K = 1; K <= 8; K++) {
+        const size_t n1 = size_t(ptrdiff_t(c0) + ptrdiff_t(kI1[K]) * nx + kJ1[K]);
+        const size_t n2 = size_t(ptrdiff_t(c0) + ptrdiff_t(kI2[K]) * nx + kJ2[K]);
+        const bool in1 = rq[n1] > 0, in2 = rq[n2] > 0;   // dn > 0
+        double D1, D2, AD, S = 0, A = 0;
+        facet_geom(g, K, D1, D2, AD);
+        if (!in1 && !in2) {
+            const double b = (double)Z[n1], cc = (double)Z[n2];
+            vslope(a, b, cc, D1, D2, g.dd, AD, S, A);
+            if (S >= 0.0) {
+                if (b > a) { if (!diagOutFound) { diagOutFound = true; KD = K; AKD = A; } }
+                else { KD = K; AKD = A; break; }
+            }
+        } else if (!in1 && in2) {
+            const double b = (double)Z[n1];
+            if (a >= b) { KD = K; AKD = 0.0; break; }
+            const int16_t c1 = flat_elev2(lvl[n2], rq[n2], fl);
+            const int16_t b1 = a1 > c1 ? a1 : c1;
+            vslope((double)a1, (double)b1, (double)c1, D1, D2, g.dd, AD, S, A);
+            if (S > SMAX) { SMAX = S; KD = K; AKD = A; }
+        } else if (in1 && !in2) {
+            const double cc = (double)Z[n2];
+            if (a >= cc) {
+                if (!diagOutFound) { KD = K; AKD = AD; diagOutFound = true; }   // ANGLE[K] = atan2(DXX[ID2],DXX[ID1]) = AD
+            } else {
+                const int16_t b1 = flat_elev2(lvl[n1], rq[n1], fl);
+                const int16_t c1 = a1 > b1 ? a1 : b1;
+                vslope((double)a1, (double)b1, (double)c1, D1, D2, g.dd, AD, S, A);
+                if (S > SMAX) { SMAX = S; KD = K; AKD = A; }
+            }
+        } else {
+            const int16_t b1 = flat_elev2(lvl[n1], rq[n1], fl);
+            const int16_t c1 = flat_elev2(lvl[n2], rq[n2], fl);
+            vslope((double)a1, (double)b1, (double)c1, D1, D2, g.dd, AD, S, A);
+            if (S > SMAX) { SMAX = S; KD = K; AKD = A; }
+        }
+    }
+    float ang = ANG[c0];
+    if (!is_nodata_f(ang, TDX_ANG_NODATA)) ang = -1.f;
+    if (KD > 0) {
+        const float t = (float)(kANGC[KD] * (TDX_PI / 2) + kANGF[KD] * AKD);
+        if (t >= 0.0f) ang = t;
+    }
+    ANG[c0] = ang;
+}
+
+__global__ __launch_bounds__(256) void dinf_recollect_kernel(const float* __restrict__ ANG, const uint32_t* __restrict__ list,
+                                                             unsigned long long nq, uint32_t* __restrict__ out,
+                                                             unsigned long long* __restrict__ counter) {
+    const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
+    uint32_t keep[8];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned long long q = base + (unsigned long long)i * 256;
+        if (q < nq) {
+            const uint32_t c = list[q];
+            if (dinf_is_flat(ANG[c])) keep[cnt++] = c;
+        }
+    }
+    unsigned long long pos = block_reserve(cnt, counter);
+    for (unsigned i = 0; i < cnt; i++) out[pos + i] = keep[i];
+}
+
+}  // namespace
+
+extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                                   const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_ang || !d_slp || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int inx = int(nx), iny = int(ny);
+    const size_t n = size_t(nx) * size_t(ny);
+    // per-row geometry on the host (sqrt and atan2 from the host libm, src/dinf.cpp:575-576, 300, 466)
+    std::vector<RowGeom> geom;
+    geom.resize(size_t(ny));
+    for (int64_t j = 0; j < ny; j++) {
+        RowGeom g;
+        g.dx = dxc[j]; g.dy = dyc[j];
+        g.dd = sqrt(dxc[j] * dxc[j] + dyc[j] * dyc[j]);
+        g.ad12 = atan2(dyc[j], dxc[j]);
+        g.ad21 = atan2(dxc[j], dyc[j]);
+        geom[size_t(j)] = g;
+    }
+    RowGeom* d_geom = static_cast<RowGeom*>(ctx->scratch(TDX_S_J, geom.size() * sizeof(RowGeom)));
+    if (!d_geom) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_geom, geom.data(), geom.size() * sizeof(RowGeom), hipMemcpyHostToDevice, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+
+    ctx->begin_call(stats);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        dim3 grid((inx + 63) / 64, (iny + 3) / 4);
+        hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_geom, d_ang, d_slp, d_cnt);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    unsigned long long total = ctx->h_mail[0];
+    if (stats) { stats->flats_initial = int64_t(total); stats->flats_left = int64_t(total); }
+
+    if (total > 0) {
+        int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+        int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+        uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(total) * 4));
+        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
+        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, size_t(total) * 4));
+        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_F, size_t(total) * 4));
+        uint32_t* s2 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(total) * 4));
+        uint32_t* ra = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(total) * 4));
+        if (!lvl || !rq || !qlist || !qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
+        float* zwork = nullptr;
+        const float* zcur = d_fel;
+        FlatBuffers fbuf{lvl, rq, fa, fb, s2, ra};
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(n, 2048)), dim3(256), 0, s, d_ang, n, lvl, rq, qlist, d_cnt);
+        unsigned long long nq = total, last = total;
+        bool first = true;
+        int rc;
+        for (;;) {
+            if (!first) { rc = flats_reset_markers(ctx, n, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
+            first = false;
+            FlatLevels fl;
+            DinfTraits tr{d_ang};
+            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, inx, iny, qlist, nq, fbuf, &fl, stats);
+            if (rc != TDX_OK) return rc;
+            {
+                TdxSpan sp(ctx, TDX_K_FLATDIR);
+                if (fl.has_pits)
+                    hipLaunchKernelGGL(dinf_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
+                hipLaunchKernelGGL(dinf_set2flat_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+                hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_cnt);
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
+            }
+            total = ctx->h_mail[0];
+            if (stats) { stats->flat_iterations++; stats->flats_left = int64_t(total); }
+            if (!(total > 0 && total < last)) break;     // src/dinf.cpp:230
+            if (!zwork) { zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4)); if (!zwork) return TDX_ERR_NOMEM; }
+            rc = flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);   // src/dinf.cpp:822-828
+            if (rc != TDX_OK) return rc;
+            zcur = zwork;
+            std::swap(qlist, qnext);
+            nq = total; last = total;
+        }
+    }
+    TDX_HIP_CHECK(ctx, hipGetLastError());
+    ctx->end_call();
+    return TDX_OK;
+}
+
+extern "C" int tdx_dinfflowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,
+                               const double* dxc, const double* dyc, float* ang, float* slp, tdx_stats* stats) {
+    if (!ctx || !fel || !ang || !slp || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir: bad argument");
+    const size_t n = size_t(nx) * size_t(ny);
+    float* d_z = static_cast<float*>(ctx->scratch(TDX_S_IO0, n * 4));
+    float* d_a = static_cast<float*>(ctx->scratch(TDX_S_IO1, n * 4));
+    float* d_s = static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4));
+    if (!d_z || !d_a || !d_s) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_z, fel, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = tdx_dinfflowdir_dev(ctx, d_z, nx, ny, fel_nodata, dxc, dyc, d_a, d_s, stats);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ang, d_a, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(slp, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
 }

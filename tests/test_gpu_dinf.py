@@ -1,0 +1,93 @@
+"""GPU parity of the D-infinity path (DinfFlowDir -> AreaDinf -> DinfDecayAccum) through the C ABI.
+
+Tolerances (BASELINE.json north_star): slope, facet choice and flat handling are exact; the angle may
+differ by one float32 ulp where the device atan2 and glibc atan2 round a double differently; areas are
+compared bit-exactly when fed the reference's own angles and within 1e-6 relative end to end."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, describe_diff, golden_cases, load_golden, outlets_to_indices
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+ANG_ND = np.float32(-3.402823466e38)
+
+
+@pytest.fixture(scope="module", params=CASES)
+def g(request):
+    return load_golden(request.param)
+
+
+def ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    return np.abs(ai - bi)
+
+
+def check_angles(ang, ang_ref, what):
+    special = (ang_ref == ANG_ND) | (ang_ref == -1.0)
+    assert np.array_equal(ang[special].view(np.uint32), ang_ref[special].view(np.uint32)), f"{what}: nodata/flat pattern differs"
+    assert np.array_equal((ang == ANG_ND) | (ang == -1.0), special), f"{what}: nodata/flat pattern differs"
+    d = ulp_diff(ang[~special], ang_ref[~special])
+    assert d.max(initial=0) <= 1, f"{what}: angle differs by {d.max()} ulp"
+    return int((d > 0).sum())
+
+
+def test_golden_dinfflowdir(g, ctx):
+    ang, slp, st = ctx.dinfflowdir(np.ascontiguousarray(g["fel"]), -3.0e38, g["dxc"], g["dyc"], stats=True)
+    assert bits_equal(slp, g["slp"]), describe_diff(slp, g["slp"], "slp")
+    nd = check_angles(ang, g["ang"], "ang")
+    assert nd <= max(2, ang.size // 10000), f"{nd} angles differ by 1 ulp"
+
+
+@pytest.mark.parametrize("key,kw", [("sca", {}), ("sca_nc", {"contcheck": False}), ("sca_w_nc", {"w": True, "contcheck": False}),
+                                    ("sca_outlets_nc", {"o": True, "contcheck": False})])
+def test_golden_areadinf(g, ctx, key, kw):
+    s = ctx.areadinf(np.ascontiguousarray(g["ang"]), float(ANG_ND), g["dxc"], g["dyc"], weights=np.ascontiguousarray(g["w"]) if kw.get("w") else None,
+                     contcheck=kw.get("contcheck", True), outlets=outlets_to_indices(g) if kw.get("o") else None)
+    assert bits_equal(s, g[key]), describe_diff(s, g[key], key)
+
+
+@pytest.mark.parametrize("key,kw", [("dsca", {}), ("dsca_w_nc", {"w": True, "contcheck": False}), ("dsca_outlets_nc", {"o": True, "contcheck": False})])
+def test_golden_dinfdecayaccum(g, ctx, key, kw):
+    s = ctx.dinfdecayaccum(np.ascontiguousarray(g["ang"]), np.ascontiguousarray(g["dm"]), float(ANG_ND), -9999.0, g["dxc"], g["dyc"],
+                           weights=np.ascontiguousarray(g["w"]) if kw.get("w") else None, contcheck=kw.get("contcheck", True),
+                           outlets=outlets_to_indices(g) if kw.get("o") else None)
+    assert bits_equal(s, g[key]), describe_diff(s, g[key], key)
+
+
+@pytest.mark.parametrize("shape,seed", [((64, 64), 1), ((3, 3), 2), ((257, 301), 5), ((1000, 777), 7)])
+def test_dinf_pipeline_vs_oracle(shape, seed, ctx, oracle):
+    dem = oracle.synth_dem(shape, seed)
+    fel = oracle.pitremove(dem, -9999.0)
+    ang_o, slp_o, st_o = oracle.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    ang, slp, st = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    assert st["flats_initial"] == st_o["flats_initial"] and st["flats_left"] == st_o["flats_left"]
+    assert bits_equal(slp, slp_o), describe_diff(slp, slp_o, "slp")
+    check_angles(ang, ang_o, "ang")
+    # areas from the ORACLE's angles: bit-exact
+    for cc in (True, False):
+        s_o = oracle.areadinf(ang_o, float(ANG_ND), 30.0, 30.0, contcheck=cc)
+        s = ctx.areadinf(ang_o, float(ANG_ND), 30.0, 30.0, contcheck=cc)
+        assert bits_equal(s, s_o), describe_diff(s, s_o, f"sca contcheck={cc}")
+    rng = np.random.default_rng(seed)
+    dm = (0.9 + 0.1 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+    d_o = oracle.dinfdecayaccum(ang_o, dm, float(ANG_ND), -9999.0, 30.0, 30.0, contcheck=False)
+    d = ctx.dinfdecayaccum(ang_o, dm, float(ANG_ND), -9999.0, 30.0, 30.0, contcheck=False)
+    assert bits_equal(d, d_o), describe_diff(d, d_o, "dsca")
+    # end to end (device angles -> device areas): 1e-6 relative
+    s_o = oracle.areadinf(ang_o, float(ANG_ND), 30.0, 30.0, contcheck=False)
+    s = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0, contcheck=False)
+    ok = (s_o != -1.0)
+    assert np.array_equal(s != -1.0, ok)
+    rel = np.abs(s[ok].astype(np.float64) - s_o[ok]) / np.maximum(np.abs(s_o[ok]), 1e-30)
+    assert rel.max(initial=0.0) <= 1e-6, f"end-to-end sca relative error {rel.max()}"
+
+
+def test_dinf_repeatability(ctx, oracle):
+    dem = oracle.synth_dem((500, 500), 4)
+    fel = oracle.pitremove(dem, -9999.0)
+    ang, _ = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    s0 = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0)
+    for _ in range(3):
+        assert bits_equal(ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0), s0)
