@@ -228,14 +228,10 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
     if (total > 0) {
         // working storage for flat resolution
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
-        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, size_t(total) * 4));
-        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_F, size_t(total) * 4));
-        uint32_t* s2 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(total) * 4));
-        uint32_t* ra = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(total) * 4));
-        if (!qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
+        if (!qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;            // allocated only if a second iteration is needed
         const float* zcur = d_fel;
-        FlatBuffers fbuf{lvl, rq, fa, fb, s2, ra};
+        FlatBuffers fbuf{lvl, rq};
 
         // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
         unsigned long long nq = total;

@@ -268,14 +268,10 @@ extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t
         int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
         uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(total) * 4));
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
-        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, size_t(total) * 4));
-        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_F, size_t(total) * 4));
-        uint32_t* s2 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(total) * 4));
-        uint32_t* ra = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(total) * 4));
-        if (!lvl || !rq || !qlist || !qnext || !fa || !fb || !s2 || !ra) return TDX_ERR_NOMEM;
+        if (!lvl || !rq || !qlist || !qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;
         const float* zcur = d_fel;
-        FlatBuffers fbuf{lvl, rq, fa, fb, s2, ra};
+        FlatBuffers fbuf{lvl, rq};
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(n, 2048)), dim3(256), 0, s, d_ang, n, lvl, rq, qlist, d_cnt);
         unsigned long long nq = total, last = total;

@@ -8,21 +8,19 @@
 // the same bits.  Schedule used here:
 //
 //   * pit_seed_kernel    streaming 3x3 stencil: Z -> W0                 (src/flood.cpp:243-271)
-//   * pit_relax_kernel   one workgroup per ACTIVE 64x64 tile: W tile + 1-cell halo staged in LDS
-//                        (66x66 f32 = 17 KB), Z kept in registers, chaotic in-LDS relaxation until the
-//                        tile stops changing, then write-back; tiles whose rim changed re-activate
-//                        their neighbours for the next round
-//   * pit_compact_kernel active flags -> compact tile list (wave ballot + one atomic per wave)
+//   * tilek::relax_kernel<PitOp>  the tile relaxation engine of tile_relax.hpp: one workgroup per
+//                        ACTIVE 64x64 tile, W tile + halo in LDS, Z in registers, chaotic in-LDS
+//                        relaxation to the tile-local fixed point, write-back of changed cells; tiles
+//                        whose rim changed re-activate their neighbours; rounds are chained on the
+//                        device (no host round trip per round)
 //
-// HBM traffic per round = 3 tile images per active tile; rounds ~ longest fill path / 64.
+// HBM traffic per activation of a tile = 2 tile images in + changed cells out; rounds ~ longest fill
+// path measured in tiles.
 #include "context.hpp"
 #include "device_common.hpp"
+#include "tile_relax.hpp"
 
 namespace {
-
-constexpr int TILE = 64;
-constexpr int LDS_W = TILE + 2;
-constexpr int ROWS_PER_WAVE = 16;   // 4 waves x 16 rows
 
 __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__ Z, const int16_t* __restrict__ mask,
                                                        float* __restrict__ W, int nx, int ny, float nodata, int step) {
@@ -46,116 +44,23 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     W[idx] = w;
 }
 
-// flags_next bit layout: any non-zero = active
-__global__ __launch_bounds__(256) void pit_relax_kernel(const float* __restrict__ Z, float* __restrict__ W, int nx, int ny,
-                                                        int tiles_x, int tiles_y, const uint32_t* __restrict__ list,
-                                                        uint32_t* __restrict__ flags_next, int fourway) {
-    __shared__ float sW[LDS_W * LDS_W];
-    __shared__ int sRim[8];   // N S W E NW NE SW SE rim-changed flags
-    const int tile = int(list[blockIdx.x]);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x0 = tx * TILE, y0 = ty * TILE;
-    const int tid = threadIdx.x;
-    if (tid < 8) sRim[tid] = 0;
-    // stage W tile + halo; off-grid cells read as FLT_MAX (neutral for the min, never updated)
-    for (int e = tid; e < LDS_W * LDS_W; e += 256) {
-        const int ly = e / LDS_W, lx = e - ly * LDS_W;
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
-        float v = FLT_MAX;
-        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) v = W[size_t(gy) * size_t(nx) + size_t(gx)];
-        sW[e] = v;
-    }
-    const int lx = tid & 63;                 // column inside the tile
-    const int ry0 = (tid >> 6) * ROWS_PER_WAVE;
-    const int gx = x0 + lx;
-    float z[ROWS_PER_WAVE], w0[ROWS_PER_WAVE];
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; r++) {
-        const int gy = y0 + ry0 + r;
-        z[r] = (gx < nx && gy < ny) ? Z[size_t(gy) * size_t(nx) + size_t(gx)] : FLT_MAX;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; r++) w0[r] = sW[(ry0 + r + 1) * LDS_W + lx + 1];
+// minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
+struct PitOp {
+    using T = float;
+    const float* Z;
+    float* W;
+    unsigned nbr_mask;   // 0xFF = 8 neighbours, 0x55 = the -4way flag (k = 1,3,5,7)
+    static __device__ __forceinline__ float inf() { return FLT_MAX; }
+    __device__ __forceinline__ float load(size_t idx) const { return W[idx]; }
+    __device__ __forceinline__ void store(size_t idx, float v) const { W[idx] = v; }
+    __device__ __forceinline__ void cell(size_t idx, float& cst, unsigned& mask) const { cst = Z[idx]; mask = nbr_mask; }
+    static __device__ __forceinline__ float apply(float z, float w, float m) { return (w > z) ? fmaxf(z, fminf(w, m)) : w; }
+    static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
+};
 
-    bool any_change = false;
-    for (int iter = 0;; iter++) {
-        int changed = 0;
-        if ((iter & 1) == 0) {
-#pragma unroll
-            for (int r = 0; r < ROWS_PER_WAVE; r++) {
-                const int c = (ry0 + r + 1) * LDS_W + lx + 1;
-                const float w = sW[c];
-                if (w > z[r]) {
-                    float m = fminf(fminf(sW[c + 1], sW[c - 1]), fminf(sW[c - LDS_W], sW[c + LDS_W]));
-                    if (!fourway) m = fminf(m, fminf(fminf(sW[c - LDS_W + 1], sW[c - LDS_W - 1]), fminf(sW[c + LDS_W - 1], sW[c + LDS_W + 1])));
-                    const float wn = fmaxf(z[r], fminf(w, m));
-                    if (wn != w) { sW[c] = wn; changed = 1; }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = ROWS_PER_WAVE - 1; r >= 0; r--) {
-                const int c = (ry0 + r + 1) * LDS_W + lx + 1;
-                const float w = sW[c];
-                if (w > z[r]) {
-                    float m = fminf(fminf(sW[c + 1], sW[c - 1]), fminf(sW[c - LDS_W], sW[c + LDS_W]));
-                    if (!fourway) m = fminf(m, fminf(fminf(sW[c - LDS_W + 1], sW[c - LDS_W - 1]), fminf(sW[c + LDS_W - 1], sW[c + LDS_W + 1])));
-                    const float wn = fmaxf(z[r], fminf(w, m));
-                    if (wn != w) { sW[c] = wn; changed = 1; }
-                }
-            }
-        }
-        const int any = __syncthreads_or(changed);
-        if (!any) break;
-        any_change = true;
-    }
-    if (!any_change) return;   // uniform: __syncthreads_or returned the same value to every thread
-    // write back and detect rim changes
-    int rim = 0;
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; r++) {
-        const int ly = ry0 + r;
-        const float w = sW[(ly + 1) * LDS_W + lx + 1];
-        if (w != w0[r]) {
-            const int gy = y0 + ly;
-            W[size_t(gy) * size_t(nx) + size_t(gx)] = w;   // changed cells are always in-grid
-            const bool top = (ly == 0), bot = (ly == TILE - 1), lef = (lx == 0), rig = (lx == TILE - 1);
-            if (top) rim |= 1;
-            if (bot) rim |= 2;
-            if (lef) rim |= 4;
-            if (rig) rim |= 8;
-            if (top && lef) rim |= 16;
-            if (top && rig) rim |= 32;
-            if (bot && lef) rim |= 64;
-            if (bot && rig) rim |= 128;
-        }
-    }
-    if (rim) {
-#pragma unroll
-        for (int b = 0; b < 8; b++) if (rim & (1 << b)) sRim[b] = 1;
-    }
-    __syncthreads();
-    if (tid < 8 && sRim[tid]) {
-        const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
-        const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
-        const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
-        if (ntx >= 0 && ntx < tiles_x && nty >= 0 && nty < tiles_y) flags_next[nty * tiles_x + ntx] = 1u;
-    }
-}
-
-__global__ __launch_bounds__(256) void pit_compact_kernel(uint32_t* __restrict__ flags, int ntiles, uint32_t* __restrict__ list,
-                                                          unsigned long long* __restrict__ counter) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    bool act = false;
-    if (t < ntiles) { act = flags[t] != 0u; flags[t] = 0u; }
-    tdxk::wave_append(act, uint32_t(t), list, counter);
-}
-
-__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
-    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
+constexpr int TILE = 64;
+constexpr int LDS_W = TILE + 2;
+constexpr int ROWS_PER_WAVE = 16;   // 4 waves x 16 rows
 
 }  // namespace
 
@@ -167,12 +72,12 @@ extern "C" int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t n
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int inx = int(nx), iny = int(ny);
-    const int tiles_x = (inx + TILE - 1) / TILE, tiles_y = (iny + TILE - 1) / TILE;
-    const int ntiles = tiles_x * tiles_y;
+    const tilek::TileGeom geom = tilek::make_geom(inx, iny, 0, iny);
+    const int ntiles = geom.tiles_x * geom.tiles_y;
     uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, size_t(ntiles) * 4));
     uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_B, size_t(ntiles) * 4));
-    if (!flags || !list) return TDX_ERR_NOMEM;
-    unsigned long long* d_count = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+    unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_C, size_t(tilek::COUNT_RING) * 16));
+    if (!flags || !list || !counts) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
     {
@@ -182,21 +87,14 @@ extern "C" int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t n
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     // round 0: every tile is active
-    hipLaunchKernelGGL(fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, 1u, size_t(ntiles));
-    int64_t rounds = 0;
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, 1u, size_t(ntiles));
+    int64_t rounds = 0, launches = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
-        for (;;) {
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(pit_compact_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, ntiles, list, d_count);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            const unsigned long long nact = ctx->h_mail[0];
-            if (nact == 0) break;
-            hipLaunchKernelGGL(pit_relax_kernel, dim3(unsigned(nact)), dim3(256), 0, s, d_dem, d_fel, inx, iny, tiles_x, tiles_y, list, flags, fourway);
-            rounds++;
-            if (stats) stats->launches[TDX_K_RELAX]++;
-        }
+        PitOp op{d_dem, d_fel, fourway ? 0x55u : 0xFFu};
+        int rc = tile_relax_run(ctx, op, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
+        if (rc != TDX_OK) return rc;
+        if (stats) stats->launches[TDX_K_RELAX] += launches;
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
     if (stats) stats->rounds = rounds;
