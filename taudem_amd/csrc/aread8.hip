@@ -18,6 +18,8 @@
 #include "context.hpp"
 #include "device_common.hpp"
 
+#include <cstdlib>
+
 namespace {
 using namespace tdxk;
 
@@ -168,7 +170,395 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
     (void)done; (void)nevaluated;
 }
 
+
+// =====================================================================================================
+// Tile-contraction path for the UNWEIGHTED sweep (no -wg, no outlets).
+//
+// With unit weights every value is an integer cell count, and float32 adds of integers are exact (and
+// therefore order-free) up to 2^24.  The dependency-driven walk above is bound by the LONGEST flow path
+// (one device-scope atomic round trip per cell); here the path is contracted through 64x64 tiles so that
+// the serial chain is only as long as the number of TILE crossings of the longest path:
+//
+//   A  ad8_tile_local_kernel   per tile, in LDS: Kahn sweep of the flows that stay inside the tile
+//                              (lanes walk downstream with ONE returning 64-bit LDS atomic per hop that
+//                              carries count + arrival + the contamination / not-evaluated flags).
+//                              Result S_loc(c) -> global; every cell that leaves the tile towards a
+//                              participating cell becomes a NODE of the crossing forest; for every
+//                              crossing that enters the tile the lane follows the in-tile path to the
+//                              exit cell and records next(node).
+//   B  ad8_forest_walk_kernel  the walk of ad8_walk_kernel on the crossing forest (nodes = perimeter
+//                              cells, ~1/16 of the cells, paths ~64x shorter), integer packed atomics.
+//   C  ad8_tile_apply_kernel   per tile, in LDS: add the flow of every entering crossing along its
+//                              in-tile path, convert to float32, apply contamination, write ad8.
+//   D  big cells (count > 2^24, where float32 adds round and the k order of src/aread8.cpp:239-256
+//                              matters) are re-evaluated with the exact k-ordered pull of ad8_evaluate in
+//                              dependency order (ad8_big_* kernels): a few main-stem cells.
+//
+// "not evaluated" (the reference leaves -1): cells fed by the p == 0 north-west quirk, cells on / below
+// a cycle, and everything downstream of them - carried as a flag next to the contamination flag.
+// =====================================================================================================
+constexpr int TS = 64;
+constexpr int TH = TS + 2;
+constexpr uint32_t NODE_INVALID = 0xFFFFFFFFu;   // perimeter cell that is not a node
+constexpr uint32_t NODE_DEAD = 0xFFFFFFFEu;      // node whose cell never completes (cycle / poisoned): never fires
+constexpr uint32_t NEXT_NONE = 0xFFFFFFFFu;
+constexpr float BIG_MARK = -2.0f;                // provisional ad8 of a cell awaiting the exact float re-evaluation
+
+// LDS word of the local sweep: cnt[0:32) arrivals[32:36) contam[36:40) poison[40:44) indeg[44:48)
+__device__ __forceinline__ unsigned long long lw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi, unsigned indeg) {
+    return (unsigned long long)cnt | ((unsigned long long)arr << 32) | ((unsigned long long)con << 36) | ((unsigned long long)poi << 40) |
+           ((unsigned long long)indeg << 44);
+}
+__device__ __forceinline__ unsigned lw_cnt(unsigned long long w) { return unsigned(w); }
+__device__ __forceinline__ unsigned lw_arr(unsigned long long w) { return unsigned(w >> 32) & 15u; }
+__device__ __forceinline__ unsigned lw_con(unsigned long long w) { return unsigned(w >> 36) & 15u; }
+__device__ __forceinline__ unsigned lw_poi(unsigned long long w) { return unsigned(w >> 40) & 15u; }
+__device__ __forceinline__ unsigned lw_indeg(unsigned long long w) { return unsigned(w >> 44) & 15u; }
+// node word of the forest walk: cnt[0:32) arrivals[32:42) contam[42:52) poison[52:62)
+__device__ __forceinline__ unsigned long long nw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi) {
+    return (unsigned long long)cnt | ((unsigned long long)arr << 32) | ((unsigned long long)con << 42) | ((unsigned long long)poi << 52);
+}
+__device__ __forceinline__ unsigned nw_arr(unsigned long long w) { return unsigned(w >> 32) & 1023u; }
+__device__ __forceinline__ unsigned nw_con(unsigned long long w) { return unsigned(w >> 42) & 1023u; }
+__device__ __forceinline__ unsigned nw_poi(unsigned long long w) { return unsigned(w >> 52) & 1023u; }
+// per-cell word between phases A and C: cnt[0:30) contam[30] poison[31]
+__device__ __forceinline__ uint32_t cw_pack(unsigned cnt, bool con, bool poi) { return cnt | (con ? 1u << 30 : 0u) | (poi ? 1u << 31 : 0u); }
+
+// position of a perimeter cell (lx, ly) of a tile in its 256-entry node block
+__device__ __forceinline__ int perim_pos(int lx, int ly) {
+    if (ly == 0) return lx;
+    if (ly == TS - 1) return 64 + lx;
+    if (lx == 0) return 128 + (ly - 1);
+    return 190 + (ly - 1);
+}
+__device__ __forceinline__ uint32_t node_id(int gx, int gy, int tiles_x) {
+    return uint32_t((gy / TS) * tiles_x + gx / TS) * 256u + uint32_t(perim_pos(gx % TS, gy % TS));
+}
+
+struct TileTopo {   // what both tile kernels derive from the staged P tile
+    int16_t tgt;    // >= 0 in-tile target, -1 terminal, -2 leaves the tile towards a participating cell
+    bool part, con, poison;
+    unsigned indeg;
+};
+
+// stage P (tile + halo, off-grid = nodata) into LDS
+__device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, int ny, int x0, int y0, int16_t nodata, int16_t* sP) {
+    for (int e = threadIdx.x; e < TH * TH; e += 256) {
+        const int ly = e / TH, lx = e - ly * TH;
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+        int16_t v = nodata;
+        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) v = P[size_t(gy) * size_t(nx) + size_t(gx)];
+        sP[e] = v;
+    }
+}
+__device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && p >= 0 && p <= 8; }
+
+// topology of the in-tile cell (lx, ly) from the staged tile (initNeighborD8up, src/commonLib.cpp:251-282,
+// and the contamination test of src/aread8.cpp:241-242)
+__device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly, int16_t nodata) {
+    TileTopo t;
+    const int c = (ly + 1) * TH + lx + 1;
+    const int16_t p = sP[c];
+    t.part = p_part(p, nodata);
+    t.tgt = -1; t.con = false; t.poison = false; t.indeg = 0;
+    if (!t.part) return t;
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        const int nlx = lx + d1(k), nly = ly + d2(k);
+        const int16_t pn = sP[(nly + 1) * TH + nlx + 1];
+        if (pn == nodata) { t.con = true; continue; }
+        if (pn >= 0 && pn <= 8 && (pn - k == 4 || pn - k == -4)) {
+            if (pn == 0) t.poison = true;   // k == 4: counted in the in-degree but never decremented (src/aread8.cpp:262)
+            else if (nlx >= 0 && nlx < TS && nly >= 0 && nly < TS) t.indeg++;
+        }
+    }
+    if (p >= 1) {
+        const int tlx = lx + d1(p), tly = ly + d2(p);
+        if (p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) t.tgt = (tlx >= 0 && tlx < TS && tly >= 0 && tly < TS) ? int16_t(tly * TS + tlx) : int16_t(-2);
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int tiles_x,
+                                                             uint32_t* __restrict__ cellw, unsigned long long* __restrict__ node_acc,
+                                                             uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next) {
+    __shared__ int16_t sP[TH * TH];
+    __shared__ unsigned long long sAcc[TS * TS];
+    __shared__ int16_t sTgt[TS * TS];
+    __shared__ unsigned sIn[256];   // crossings that end at each perimeter cell
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
+    stage_p(P, nx, ny, x0, y0, nodata, sP);
+    sIn[tid] = 0u;
+    __syncthreads();
+    unsigned src = 0;   // rows of this lane that start a walk
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ly = ry0 + r;
+        const TileTopo t = tile_topo(sP, lx, ly, nodata);
+        sTgt[ly * TS + lx] = t.tgt;
+        sAcc[ly * TS + lx] = t.part ? lw_pack(1u, 0u, t.con ? 1u : 0u, t.poison ? 1u : 0u, t.indeg) : lw_pack(0u, 0u, 0u, 0u, 15u);
+        if (t.part && t.indeg == 0) src |= 1u << r;
+    }
+    __syncthreads();
+    // Kahn sweep of the in-tile flows: one returning LDS atomic per hop
+    while (src) {
+        const int r = __ffs(int(src)) - 1;
+        src &= src - 1u;
+        int c = (ry0 + r) * TS + lx;
+        unsigned long long w = sAcc[c];
+        for (;;) {
+            const int t = sTgt[c];
+            if (t < 0) break;
+            const unsigned long long add = lw_pack(lw_cnt(w), 1u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u, 0u);
+            const unsigned long long nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
+            if (lw_arr(nw) != lw_indeg(nw)) break;   // someone else will be the last contributor
+            c = t; w = nw;
+        }
+    }
+    __syncthreads();
+    // crossings that enter the tile: follow the in-tile path of the entry cell to where it leaves
+    for (int j = tid; j < 4 * (TS + 1); j += 256) {
+        int hx, hy;   // halo ring coordinates in [-1, TS]
+        if (j < TS + 1) { hx = j - 1; hy = -1; }
+        else if (j < 2 * (TS + 1)) { hx = TS; hy = j - (TS + 1) - 1; }
+        else if (j < 3 * (TS + 1)) { hx = j - 2 * (TS + 1); hy = TS; }
+        else { hx = -1; hy = j - 3 * (TS + 1); }
+        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
+        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const int vx = hx + d1(ph), vy = hy + d2(ph);
+        if (vx < 0 || vx >= TS || vy < 0 || vy >= TS) continue;
+        if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
+        int cur = vy * TS + vx, hops = 0;
+        while (sTgt[cur] >= 0 && hops < TS * TS) { cur = sTgt[cur]; hops++; }
+        uint32_t nxt = NEXT_NONE;
+        if (sTgt[cur] == -2) {
+            const int pp = perim_pos(cur % TS, cur / TS);
+            atomicAdd(&sIn[pp], 1u);
+            nxt = uint32_t(tile) * 256u + uint32_t(pp);
+        }
+        node_next[node_id(x0 + hx, y0 + hy, tiles_x)] = nxt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ly = ry0 + r, c = ly * TS + lx;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= nx || gy >= ny) continue;
+        const unsigned long long w = sAcc[c];
+        const bool part = lw_indeg(w) != 15u;
+        const bool complete = part && lw_arr(w) == lw_indeg(w);
+        cellw[size_t(gy) * size_t(nx) + size_t(gx)] = part ? cw_pack(lw_cnt(w), lw_con(w) != 0u, lw_poi(w) != 0u || !complete) : 0u;
+        if (part && sTgt[c] == -2) {
+            const int pp = perim_pos(lx, ly);
+            const uint32_t nid = uint32_t(tile) * 256u + uint32_t(pp);
+            node_acc[nid] = nw_pack(lw_cnt(w), 0u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u);
+            node_indeg[nid] = complete ? sIn[pp] : NODE_DEAD;
+        }
+    }
+}
+
+// the crossing forest: nodes without entering crossings start, the last arrival continues
+__global__ __launch_bounds__(256) void ad8_forest_walk_kernel(unsigned long long* __restrict__ node_acc, const uint32_t* __restrict__ node_indeg,
+                                                              const uint32_t* __restrict__ node_next, size_t nnodes) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nnodes || node_indeg[i] != 0u) return;
+    uint32_t u = uint32_t(i);
+    unsigned long long w = node_acc[u];
+    for (;;) {
+        const uint32_t n = node_next[u];
+        if (n == NEXT_NONE) break;
+        const unsigned long long add = nw_pack(unsigned(w), 1u, nw_con(w) ? 1u : 0u, nw_poi(w) ? 1u : 0u);
+        const unsigned long long nw = __hip_atomic_fetch_add(&node_acc[n], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if (nw_arr(nw) != node_indeg[n]) break;
+        u = n; w = nw;
+    }
+}
+
+// LDS word of the apply pass: cnt[0:32) contam[32:44) poison[44:56)
+__global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int tiles_x,
+                                                             const uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
+                                                             const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
+                                                             float* __restrict__ A, uint32_t* __restrict__ biglist,
+                                                             unsigned long long* __restrict__ nbig) {
+    __shared__ int16_t sP[TH * TH];
+    __shared__ unsigned long long sAcc[TS * TS];
+    __shared__ int16_t sTgt[TS * TS];
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
+    stage_p(P, nx, ny, x0, y0, nodata, sP);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ly = ry0 + r;
+        const int gx = x0 + lx, gy = y0 + ly;
+        const int c = (ly + 1) * TH + lx + 1;
+        const int16_t p = sP[c];
+        int16_t tgt = -1;
+        if (p_part(p, nodata) && p >= 1) {
+            const int tlx = lx + d1(p), tly = ly + d2(p);
+            if (tlx >= 0 && tlx < TS && tly >= 0 && tly < TS && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt = int16_t(tly * TS + tlx);
+        }
+        sTgt[ly * TS + lx] = tgt;
+        uint32_t cw = 0u;
+        if (gx < nx && gy < ny) cw = cellw[size_t(gy) * size_t(nx) + size_t(gx)];
+        sAcc[ly * TS + lx] = (unsigned long long)(cw & 0x3FFFFFFFu) | ((unsigned long long)((cw >> 30) & 1u) << 32) | ((unsigned long long)(cw >> 31) << 44);
+    }
+    __syncthreads();
+    for (int j = tid; j < 4 * (TS + 1); j += 256) {
+        int hx, hy;
+        if (j < TS + 1) { hx = j - 1; hy = -1; }
+        else if (j < 2 * (TS + 1)) { hx = TS; hy = j - (TS + 1) - 1; }
+        else if (j < 3 * (TS + 1)) { hx = j - 2 * (TS + 1); hy = TS; }
+        else { hx = -1; hy = j - 3 * (TS + 1); }
+        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
+        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const int vx = hx + d1(ph), vy = hy + d2(ph);
+        if (vx < 0 || vx >= TS || vy < 0 || vy >= TS) continue;
+        if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
+        const uint32_t nid = node_id(x0 + hx, y0 + hy, tiles_x);
+        const uint32_t ind = node_indeg[nid];
+        const unsigned long long w = node_acc[nid];
+        unsigned long long add;
+        if (ind < NODE_DEAD && nw_arr(w) == ind) add = (unsigned long long)unsigned(w) | ((unsigned long long)(nw_con(w) ? 1u : 0u) << 32) | ((unsigned long long)(nw_poi(w) ? 1u : 0u) << 44);
+        else add = 1ull << 44;   // the crossing never delivers: everything below it stays unevaluated
+        int cur = vy * TS + vx, hops = 0;
+        for (;;) {
+            __hip_atomic_fetch_add(&sAcc[cur], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int t = sTgt[cur];
+            if (t < 0 || ++hops >= TS * TS) break;
+            cur = t;
+        }
+    }
+    __syncthreads();
+    unsigned bigmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ly = ry0 + r;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= nx || gy >= ny) continue;
+        const unsigned long long w = sAcc[ly * TS + lx];
+        const bool part = p_part(sP[(ly + 1) * TH + lx + 1], nodata);
+        const unsigned cnt = unsigned(w);
+        const bool con = ((w >> 32) & 0xFFFull) != 0ull, poi = ((w >> 44) & 0xFFFull) != 0ull;
+        float a = TDX_AREA_NODATA;
+        if (part && !poi && !(con && contcheck == 1)) {
+            if (cnt > big_threshold) { a = BIG_MARK; bigmask |= 1u << r; }
+            else a = (float)cnt;   // exact: cnt <= 2^24
+        }
+        A[size_t(gy) * size_t(nx) + size_t(gx)] = a;
+    }
+    const unsigned long long pos0 = block_reserve(unsigned(__popc(bigmask)), nbig);
+    unsigned long long pos = pos0;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        if (bigmask & (1u << r)) biglist[pos++] = uint32_t(size_t(y0 + ry0 + r) * size_t(nx) + size_t(x0 + lx));
+}
+
+// ---- big cells: exact k-ordered float32 re-evaluation in dependency order ----
+__global__ __launch_bounds__(256) void ad8_big_degree_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata,
+                                                             const uint32_t* __restrict__ biglist, unsigned long long nbig,
+                                                             const float* __restrict__ A, int32_t* __restrict__ cnt) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nbig) return;
+    const size_t c = biglist[q];
+    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
+    int deg = 0;
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        const int xn = x + d1(k), yn = y + d2(k);
+        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) continue;
+        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+        const int16_t pn = P[n];
+        if (pn != nodata && pn >= 1 && pn <= 8 && (pn - k == 4 || pn - k == -4) && A[n] == BIG_MARK) deg++;
+    }
+    cnt[c] = deg ? deg : CNT_SOURCE;
+}
+
+__global__ __launch_bounds__(256) void ad8_big_walk_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int contcheck,
+                                                           const uint32_t* __restrict__ biglist, unsigned long long nbig,
+                                                           int32_t* __restrict__ cnt, float* __restrict__ A) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nbig) return;
+    size_t idx = biglist[q];
+    if (cnt[idx] != CNT_SOURCE) return;
+    int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
+    for (;;) {
+        const float a = ad8_evaluate(P, nullptr, 0.f, A, nx, ny, x, y, idx, nodata, contcheck);
+        st_agent(&A[idx], a);
+        const int16_t k = P[idx];
+        if (k < 1 || k > 8) break;
+        const int xn = x + d1(k), yn = y + d2(k);
+        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) break;
+        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+        if (ld_agent(&A[n]) != BIG_MARK) break;   // downstream is not awaiting re-evaluation (contaminated / unevaluated)
+        drain_stores();
+        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != 1) break;
+        x = xn; y = yn; idx = n;
+    }
+}
+
 }  // namespace
+
+
+// unweighted, no outlets: tile contraction (see the block comment above)
+static int aread8_tiled(tdx_context* ctx, const int16_t* d_p, int inx, int iny, int16_t p_nodata, int contcheck, float* d_ad8, tdx_stats* stats) {
+    hipStream_t s = ctx->stream;
+    const size_t n = size_t(inx) * size_t(iny);
+    const int tiles_x = (inx + TS - 1) / TS, tiles_y = (iny + TS - 1) / TS;
+    const size_t ntiles = size_t(tiles_x) * size_t(tiles_y), nnodes = ntiles * 256;
+    uint32_t* cellw = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, n * 4));          // later reused as the big-cell counters
+    unsigned long long* node_acc = static_cast<unsigned long long*>(ctx->scratch(TDX_S_B, nnodes * 8));
+    uint32_t* node_indeg = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, nnodes * 4));
+    uint32_t* node_next = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, nnodes * 4));
+    const unsigned big_threshold = getenv("TDX_AD8_BIG_THRESHOLD") ? unsigned(atol(getenv("TDX_AD8_BIG_THRESHOLD"))) : (1u << 24);   // test hook
+    const size_t bigcap = big_threshold < (1u << 24) ? n : n / 8 + 4096;
+    uint32_t* biglist = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, bigcap * 4));
+    if (!cellw || !node_acc || !node_indeg || !node_next || !biglist) return TDX_ERR_NOMEM;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+    ctx->begin_call(stats);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(node_indeg, 0xFF, nnodes * 4, s));
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(ad8_tile_local_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, inx, iny, p_nodata, tiles_x, cellw, node_acc,
+                           node_indeg, node_next);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    {
+        TdxSpan sp(ctx, TDX_K_ACCUM);
+        hipLaunchKernelGGL(ad8_forest_walk_kernel, dim3(tdx_blocks_for(nnodes, 256)), dim3(256), 0, s, node_acc, node_indeg, node_next, nnodes);
+        if (stats) stats->launches[TDX_K_ACCUM]++;
+    }
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, inx, iny, p_nodata, tiles_x, cellw, node_acc,
+                           node_indeg, contcheck, big_threshold, d_ad8, biglist, d_cnt);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const unsigned long long nbig = ctx->h_mail[0];
+    if (nbig > bigcap) return tdx_fail(ctx, TDX_ERR_NOMEM, "AreaD8: big-cell list exhausted");
+    if (nbig > 0) {
+        TdxSpan sp(ctx, TDX_K_MISC);
+        int32_t* bigcnt = reinterpret_cast<int32_t*>(cellw);
+        hipLaunchKernelGGL(ad8_big_degree_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, iny, p_nodata, biglist, nbig, d_ad8, bigcnt);
+        hipLaunchKernelGGL(ad8_big_walk_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, iny, p_nodata, contcheck, biglist, nbig,
+                           bigcnt, d_ad8);
+        if (stats) stats->launches[TDX_K_MISC] += 2;
+    }
+    TDX_HIP_CHECK(ctx, hipGetLastError());
+    tdx_stats* st = stats;
+    ctx->end_call();
+    if (st) { st->rounds = 1; st->cells_evaluated = int64_t(nbig); }
+    return TDX_OK;
+}
 
 extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
                               const float* d_w, float w_nodata, int contcheck,
@@ -182,6 +572,8 @@ extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, 
     hipStream_t s = ctx->stream;
     const int inx = int(nx), iny = int(ny);
     const size_t n = size_t(nx) * size_t(ny);
+    const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
+    if (!d_w && n_outlets < 0 && n < (size_t(1) << 30) && !force_walk) return aread8_tiled(ctx, d_p, inx, iny, p_nodata, contcheck, d_ad8, stats);
     int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
     if (!cnt) return TDX_ERR_NOMEM;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);

@@ -112,3 +112,69 @@ def test_repeatability(ctx, oracle):
     a0 = ctx.aread8(p, -32768)
     for _ in range(3):
         assert bits_equal(ctx.aread8(p, -32768), a0)
+
+
+# ---- AreaD8 tile-contraction path (unweighted, no outlets) ---------------------------------------
+def _p_field(oracle, shape, seed):
+    dem = oracle.synth_dem(shape, seed)
+    fel = oracle.pitremove(dem, -9999.0)
+    p, _, _ = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    return p
+
+
+@pytest.mark.parametrize("shape,seed", [((64, 64), 1), ((65, 130), 2), ((200, 333), 3), ((777, 1000), 4)])
+def test_aread8_tiles_equal_walk_and_oracle(shape, seed, ctx, oracle, monkeypatch):
+    p = _p_field(oracle, shape, seed)
+    for cc in (True, False):
+        a_o = oracle.aread8(p, -32768, contcheck=cc)
+        monkeypatch.delenv("TDX_AD8_WALK", raising=False)
+        a_t = ctx.aread8(p, -32768, contcheck=cc)
+        monkeypatch.setenv("TDX_AD8_WALK", "1")
+        a_w = ctx.aread8(p, -32768, contcheck=cc)
+        monkeypatch.delenv("TDX_AD8_WALK", raising=False)
+        assert bits_equal(a_t, a_o), describe_diff(a_t, a_o, f"tiles contcheck={cc}")
+        assert bits_equal(a_w, a_o), describe_diff(a_w, a_o, f"walk contcheck={cc}")
+
+
+def test_aread8_tiles_big_cell_reevaluation(ctx, oracle, monkeypatch):
+    """Forces the exact k-ordered re-evaluation (cells above the float-exact limit) onto ordinary cells."""
+    p = _p_field(oracle, (500, 700), 11)
+    for thr in ("0", "5", "1000"):
+        monkeypatch.setenv("TDX_AD8_BIG_THRESHOLD", thr)
+        for cc in (True, False):
+            a_o = oracle.aread8(p, -32768, contcheck=cc)
+            a = ctx.aread8(p, -32768, contcheck=cc)
+            assert bits_equal(a, a_o), describe_diff(a, a_o, f"threshold {thr} contcheck={cc}")
+
+
+def test_aread8_tiles_quirks(ctx, oracle):
+    """p == 0 cells (north-west quirk of initNeighborD8up), nodata holes, a two-cell cycle, flow into nodata."""
+    rng = np.random.default_rng(3)
+    p = _p_field(oracle, (300, 300), 12).copy()
+    idx = rng.integers(5, 295, size=(40, 2))
+    for y, x in idx[:20]:
+        p[y, x] = 0
+    for y, x in idx[20:30]:
+        p[y, x] = -32768
+    y, x = idx[30]
+    p[y, x] = 1; p[y, x + 1] = 5          # 2-cycle: never evaluated, nor anything downstream
+    for cc in (True, False):
+        a_o = oracle.aread8(p, -32768, contcheck=cc)
+        a = ctx.aread8(p, -32768, contcheck=cc)
+        assert bits_equal(a, a_o), describe_diff(a, a_o, f"quirks contcheck={cc}")
+
+
+@pytest.mark.slow
+def test_aread8_above_2_24_rounds_like_the_reference(ctx, oracle):
+    """A comb-shaped direction field on 4200 x 4200 cells: every row drains east into the last interior
+    column, which drains south - counts pass 2^24 on the trunk, where float32 adds round and the k
+    order of src/aread8.cpp:239-256 decides the bits."""
+    n = 4200
+    p = np.full((n, n), 1, dtype=np.int16)
+    p[:, n - 2] = 7
+    p[:, n - 1] = 5
+    p[0, :] = -32768; p[n - 1, :] = -32768; p[:, 0] = -32768
+    a_o = oracle.aread8(p, -32768, contcheck=False)
+    a = ctx.aread8(p, -32768, contcheck=False)
+    assert a_o.max() > 2 ** 24
+    assert bits_equal(a, a_o), describe_diff(a, a_o, "comb")
