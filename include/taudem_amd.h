@@ -150,6 +150,47 @@ int tdx_dinfdecayaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t n
                        const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
                        float* dsca, tdx_stats* stats);
 
+
+/* ---- row strips across GPUs (replaces linearpart<T>, src/linearpart.h:55-565) ---------------------- */
+/* One process per GPU holds one horizontal strip of the raster plus ONE halo row above and below it,
+ * exactly like linearpart (rows r*(Y/P) .. , remainder to the last rank, src/linearpart.h:133-134; halo =
+ * topBorder/bottomBorder, :148-162).  A strip array therefore has (ny_local + 2) rows of nx cells:
+ * row 0 = halo above, rows 1..ny_local = owned, row ny_local+1 = halo below.  The caller fills the
+ * owned rows of the inputs; the library fills halos (with the neighbour's rows, or with nodata beyond the
+ * global raster - the reference's borders start as nodata, :158-162).
+ *
+ * The library never calls a communication library itself.  It asks the host through tdx_comm:
+ *   exchange(user, bytes): send send_up[0..bytes) to rank-1 and send_down[0..bytes) to rank+1; receive
+ *       rank-1's send_down into recv_up and rank+1's send_up into recv_down (ends of the chain skip the
+ *       missing neighbour).  Replaces share()/passBorders() (src/linearpart.h:194-299).  The four buffers
+ *       are DEVICE memory owned by the host (e.g. torch tensors handed to RCCL send/recv); `capacity`
+ *       bytes each, at least 16*nx.
+ *   allreduce(user, values, count, op): in-place reduction of `count` int64 HOST values over all ranks,
+ *       op 0 = sum, 1 = max.  Replaces MPI_Allreduce / ringTerm (src/linearpart.h:301-360).
+ * Both return 0 on success and must have completed (data visible to any stream) when they return; the
+ * library has synchronised its own stream before it calls them. */
+typedef struct tdx_comm {
+    int32_t rank, size;
+    void* user;
+    int (*exchange)(void* user, uint64_t bytes);
+    int (*allreduce)(void* user, int64_t* values, int32_t count, int32_t op);
+    void* send_up; void* send_down; void* recv_up; void* recv_down;
+    uint64_t capacity;
+} tdx_comm;
+#define TDX_OP_SUM 0
+#define TDX_OP_MAX 1
+
+/* Strip variants of the device entry points (comm == NULL or comm->size == 1: a single strip whose halo
+ * rows lie outside the raster).  All raster pointers are DEVICE strip arrays of (ny_local + 2) x nx. */
+int tdx_pitremove_strip(tdx_context* ctx, const tdx_comm* comm, float* d_dem, int64_t nx, int64_t ny_local, float dem_nodata,
+                        const int16_t* d_mask, int fourway, float* d_fel, tdx_stats* stats);
+/* dxc/dyc: per-row cell sizes of the ny_local + 2 strip rows */
+int tdx_d8flowdir_strip(tdx_context* ctx, const tdx_comm* comm, float* d_fel, int64_t nx, int64_t ny_local, float fel_nodata,
+                        const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats);
+/* unweighted, no outlets (the tile-contraction sweep) */
+int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                     int contcheck, float* d_ad8, tdx_stats* stats);
+
 /* ---- synthetic benchmark input (not in the reference) -------------------------------------- */
 /* Fills d_out (nx*ny float32) with the seeded fractal surface of taudem_amd/csrc/synth_dem.h for
  * the window whose top-left global cell is (x0,y0).  Bit-identical to the host generator. */

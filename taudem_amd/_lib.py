@@ -59,6 +59,26 @@ class TdxStats(C.Structure):
         return d
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
+
+
+class TdxComm(C.Structure):
+    """struct tdx_comm of include/taudem_amd.h (row strips across GPUs)."""
+    _fields_ = [
+        ("rank", C.c_int32),
+        ("size", C.c_int32),
+        ("user", C.c_void_p),
+        ("exchange", EXCHANGE_FN),
+        ("allreduce", ALLREDUCE_FN),
+        ("send_up", C.c_void_p),
+        ("send_down", C.c_void_p),
+        ("recv_up", C.c_void_p),
+        ("recv_down", C.c_void_p),
+        ("capacity", C.c_uint64),
+    ]
+
+
 class TdxRasterInfo(C.Structure):
     _fields_ = [
         ("nx", C.c_int64),
@@ -100,6 +120,9 @@ _SIGNATURES = {
     "tdx_areadinf": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_dinfdecayaccum_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_dinfdecayaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_pitremove_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, C.c_int, _P, _P]),
+    "tdx_d8flowdir_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_aread8_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, C.c_int, _P, _P]),
     "tdx_synth_dem_dev": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _I64, _I64, _P]),
     "tdx_raster_info_read": (C.c_int, [C.c_char_p, C.POINTER(TdxRasterInfo)]),
     "tdx_raster_read": (C.c_int, [C.c_char_p, C.c_int, _P, _P, _P]),

@@ -17,6 +17,7 @@
 //   outlets            reverse BFS from the outlet cells marks the upstream closure (frontier sweeps)
 #include "context.hpp"
 #include "device_common.hpp"
+#include "strips.hpp"
 
 #include <cstdlib>
 
@@ -199,10 +200,22 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
 // =====================================================================================================
 constexpr int TS = 64;
 constexpr int TH = TS + 2;
-constexpr uint32_t NODE_INVALID = 0xFFFFFFFFu;   // perimeter cell that is not a node
+constexpr uint32_t NODE_INVALID = 0xFFFFFFFFu;   // perimeter / halo cell that is not (yet) a node
 constexpr uint32_t NODE_DEAD = 0xFFFFFFFEu;      // node whose cell never completes (cycle / poisoned): never fires
 constexpr uint32_t NEXT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t NEXT_REMOTE_UP = 0xFFFFFFFDu;    // the crossing leaves the strip through the halo row above
+constexpr uint32_t NEXT_REMOTE_DOWN = 0xFFFFFFFCu;  //                                           ... below
+constexpr unsigned long long BOX_VALID = 1ull << 63;
 constexpr float BIG_MARK = -2.0f;                // provisional ad8 of a cell awaiting the exact float re-evaluation
+
+// Geometry of one strip: tiles cover the OWNED rows [y0, y1) of an array of ny_arr rows; the rows y0-1
+// and y1 (when inside the array) are halo rows owned by the neighbouring ranks.  Every cell that can
+// carry a crossing has a node id: perimeter cells of the tiles first, then the 2 x nx halo cells.
+struct Ad8Geom {
+    int nx, ny_arr, y0, y1, tiles_x, tiles_y;
+    uint32_t nnodes_local;   // tiles * 256
+};
+__device__ __forceinline__ int rows_valid(const Ad8Geom& g, int ty) { const int r = g.y1 - (g.y0 + ty * TS); return r < TS ? r : TS; }
 
 // LDS word of the local sweep: cnt[0:32) arrivals[32:36) contam[36:40) poison[40:44) indeg[44:48)
 __device__ __forceinline__ unsigned long long lw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi, unsigned indeg) {
@@ -224,15 +237,19 @@ __device__ __forceinline__ unsigned nw_poi(unsigned long long w) { return unsign
 // per-cell word between phases A and C: cnt[0:30) contam[30] poison[31]
 __device__ __forceinline__ uint32_t cw_pack(unsigned cnt, bool con, bool poi) { return cnt | (con ? 1u << 30 : 0u) | (poi ? 1u << 31 : 0u); }
 
-// position of a perimeter cell (lx, ly) of a tile in its 256-entry node block
-__device__ __forceinline__ int perim_pos(int lx, int ly) {
+// position of a perimeter cell (lx, ly) of a tile with rv valid rows in its 256-entry node block
+__device__ __forceinline__ int perim_pos(int lx, int ly, int rv) {
     if (ly == 0) return lx;
-    if (ly == TS - 1) return 64 + lx;
+    if (ly == rv - 1) return 64 + lx;
     if (lx == 0) return 128 + (ly - 1);
     return 190 + (ly - 1);
 }
-__device__ __forceinline__ uint32_t node_id(int gx, int gy, int tiles_x) {
-    return uint32_t((gy / TS) * tiles_x + gx / TS) * 256u + uint32_t(perim_pos(gx % TS, gy % TS));
+// node id of the array cell (gx, gy): a tile perimeter cell or a halo-row cell
+__device__ __forceinline__ uint32_t node_id(const Ad8Geom& g, int gx, int gy) {
+    if (gy < g.y0) return g.nnodes_local + uint32_t(gx);
+    if (gy >= g.y1) return g.nnodes_local + uint32_t(g.nx) + uint32_t(gx);
+    const int ty = (gy - g.y0) / TS, ly = (gy - g.y0) % TS;
+    return uint32_t(ty * g.tiles_x + gx / TS) * 256u + uint32_t(perim_pos(gx % TS, ly, rows_valid(g, ty)));
 }
 
 struct TileTopo {   // what both tile kernels derive from the staged P tile
@@ -241,26 +258,27 @@ struct TileTopo {   // what both tile kernels derive from the staged P tile
     unsigned indeg;
 };
 
-// stage P (tile + halo, off-grid = nodata) into LDS
-__device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, int ny, int x0, int y0, int16_t nodata, int16_t* sP) {
+// stage P (tile + ring, outside the array = nodata) into LDS; ya0 = array row of the tile's first row
+__device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, int ny_arr, int x0, int ya0, int16_t nodata, int16_t* sP) {
     for (int e = threadIdx.x; e < TH * TH; e += 256) {
         const int ly = e / TH, lx = e - ly * TH;
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+        const int gx = x0 + lx - 1, gy = ya0 + ly - 1;
         int16_t v = nodata;
-        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) v = P[size_t(gy) * size_t(nx) + size_t(gx)];
+        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny_arr) v = P[size_t(gy) * size_t(nx) + size_t(gx)];
         sP[e] = v;
     }
 }
 __device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && p >= 0 && p <= 8; }
+__device__ __forceinline__ bool in_tile(int lx, int ly, int rv) { return lx >= 0 && lx < TS && ly >= 0 && ly < rv; }
 
 // topology of the in-tile cell (lx, ly) from the staged tile (initNeighborD8up, src/commonLib.cpp:251-282,
-// and the contamination test of src/aread8.cpp:241-242)
-__device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly, int16_t nodata) {
+// and the contamination test of src/aread8.cpp:241-242); rv = rows of the tile that belong to this strip
+__device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly, int rv, int16_t nodata) {
     TileTopo t;
-    const int c = (ly + 1) * TH + lx + 1;
-    const int16_t p = sP[c];
+    t.part = false; t.tgt = -1; t.con = false; t.poison = false; t.indeg = 0;
+    if (ly >= rv) return t;
+    const int16_t p = sP[(ly + 1) * TH + lx + 1];
     t.part = p_part(p, nodata);
-    t.tgt = -1; t.con = false; t.poison = false; t.indeg = 0;
     if (!t.part) return t;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
@@ -269,17 +287,28 @@ __device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly,
         if (pn == nodata) { t.con = true; continue; }
         if (pn >= 0 && pn <= 8 && (pn - k == 4 || pn - k == -4)) {
             if (pn == 0) t.poison = true;   // k == 4: counted in the in-degree but never decremented (src/aread8.cpp:262)
-            else if (nlx >= 0 && nlx < TS && nly >= 0 && nly < TS) t.indeg++;
+            else if (in_tile(nlx, nly, rv)) t.indeg++;
         }
     }
     if (p >= 1) {
         const int tlx = lx + d1(p), tly = ly + d2(p);
-        if (p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) t.tgt = (tlx >= 0 && tlx < TS && tly >= 0 && tly < TS) ? int16_t(tly * TS + tlx) : int16_t(-2);
+        if (p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) t.tgt = in_tile(tlx, tly, rv) ? int16_t(tly * TS + tlx) : int16_t(-2);
     }
     return t;
 }
 
-__global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int tiles_x,
+// ring cell j of a tile with rv valid rows: top row, bottom row, left column, right column
+__device__ __forceinline__ bool ring_cell(int j, int rv, int& hx, int& hy) {
+    if (j < TH) { hx = j - 1; hy = -1; return true; }
+    if (j < 2 * TH) { hx = j - TH - 1; hy = rv; return true; }
+    j -= 2 * TH;
+    if (j < rv) { hx = -1; hy = j; return true; }
+    j -= rv;
+    if (j < rv) { hx = TS; hy = j; return true; }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, unsigned long long* __restrict__ node_acc,
                                                              uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next) {
     __shared__ int16_t sP[TH * TH];
@@ -287,17 +316,17 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     __shared__ int16_t sTgt[TS * TS];
     __shared__ unsigned sIn[256];   // crossings that end at each perimeter cell
     const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x0 = tx * TS, y0 = ty * TS;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, ya0 = g.y0 + ty * TS, rv = rows_valid(g, ty);
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
-    stage_p(P, nx, ny, x0, y0, nodata, sP);
+    stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
     sIn[tid] = 0u;
     __syncthreads();
     unsigned src = 0;   // rows of this lane that start a walk
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r;
-        const TileTopo t = tile_topo(sP, lx, ly, nodata);
+        const TileTopo t = tile_topo(sP, lx, ly, rv, nodata);
         sTgt[ly * TS + lx] = t.tgt;
         sAcc[ly * TS + lx] = t.part ? lw_pack(1u, 0u, t.con ? 1u : 0u, t.poison ? 1u : 0u, t.indeg) : lw_pack(0u, 0u, 0u, 0u, 15u);
         if (t.part && t.indeg == 0) src |= 1u << r;
@@ -320,65 +349,104 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     }
     __syncthreads();
     // crossings that enter the tile: follow the in-tile path of the entry cell to where it leaves
-    for (int j = tid; j < 4 * (TS + 1); j += 256) {
-        int hx, hy;   // halo ring coordinates in [-1, TS]
-        if (j < TS + 1) { hx = j - 1; hy = -1; }
-        else if (j < 2 * (TS + 1)) { hx = TS; hy = j - (TS + 1) - 1; }
-        else if (j < 3 * (TS + 1)) { hx = j - 2 * (TS + 1); hy = TS; }
-        else { hx = -1; hy = j - 3 * (TS + 1); }
+    for (int j = tid; j < 4 * TH; j += 256) {
+        int hx, hy;
+        if (!ring_cell(j, rv, hx, hy)) continue;
         const int16_t ph = sP[(hy + 1) * TH + hx + 1];
         if (ph == nodata || ph < 1 || ph > 8) continue;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
-        if (vx < 0 || vx >= TS || vy < 0 || vy >= TS) continue;
+        if (!in_tile(vx, vy, rv)) continue;
         if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
         int cur = vy * TS + vx, hops = 0;
         while (sTgt[cur] >= 0 && hops < TS * TS) { cur = sTgt[cur]; hops++; }
         uint32_t nxt = NEXT_NONE;
         if (sTgt[cur] == -2) {
-            const int pp = perim_pos(cur % TS, cur / TS);
+            const int pp = perim_pos(cur % TS, cur / TS, rv);
             atomicAdd(&sIn[pp], 1u);
             nxt = uint32_t(tile) * 256u + uint32_t(pp);
         }
-        node_next[node_id(x0 + hx, y0 + hy, tiles_x)] = nxt;
+        node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r, c = ly * TS + lx;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= nx || gy >= ny) continue;
+        const int gx = x0 + lx, gy = ya0 + ly;
+        if (gx >= g.nx || ly >= rv) continue;
         const unsigned long long w = sAcc[c];
         const bool part = lw_indeg(w) != 15u;
         const bool complete = part && lw_arr(w) == lw_indeg(w);
-        cellw[size_t(gy) * size_t(nx) + size_t(gx)] = part ? cw_pack(lw_cnt(w), lw_con(w) != 0u, lw_poi(w) != 0u || !complete) : 0u;
+        cellw[size_t(gy) * size_t(g.nx) + size_t(gx)] = part ? cw_pack(lw_cnt(w), lw_con(w) != 0u, lw_poi(w) != 0u || !complete) : 0u;
         if (part && sTgt[c] == -2) {
-            const int pp = perim_pos(lx, ly);
+            const int pp = perim_pos(lx, ly, rv);
             const uint32_t nid = uint32_t(tile) * 256u + uint32_t(pp);
             node_acc[nid] = nw_pack(lw_cnt(w), 0u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u);
             node_indeg[nid] = complete ? sIn[pp] : NODE_DEAD;
+            const int tgy = gy + d2(sP[(ly + 1) * TH + lx + 1]);
+            if (tgy < g.y0) node_next[nid] = NEXT_REMOTE_UP;        // the tile that would record next(node) lives on another rank
+            else if (tgy >= g.y1) node_next[nid] = NEXT_REMOTE_DOWN;
         }
     }
 }
 
-// the crossing forest: nodes without entering crossings start, the last arrival continues
-__global__ __launch_bounds__(256) void ad8_forest_walk_kernel(unsigned long long* __restrict__ node_acc, const uint32_t* __restrict__ node_indeg,
-                                                              const uint32_t* __restrict__ node_next, size_t nnodes) {
-    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= nnodes || node_indeg[i] != 0u) return;
-    uint32_t u = uint32_t(i);
-    unsigned long long w = node_acc[u];
+// Walk the crossing forest from the completed node u (word w): the last arrival at a node continues.
+// A node whose crossing leaves the strip drops its word into the out-box of that side.
+__device__ __forceinline__ void forest_walk_from(uint32_t u, unsigned long long w, const Ad8Geom& g, unsigned long long* __restrict__ node_acc,
+                                                 const uint32_t* __restrict__ node_indeg, const uint32_t* __restrict__ node_next,
+                                                 unsigned long long* __restrict__ outbox) {
     for (;;) {
         const uint32_t n = node_next[u];
-        if (n == NEXT_NONE) break;
+        if (n == NEXT_NONE) return;
+        if (n == NEXT_REMOTE_UP || n == NEXT_REMOTE_DOWN) {
+            // u is a perimeter node in the first / last tile row; its column is tile column * 64 + (pos & 63)
+            const uint32_t tile = u >> 8, pos = u & 255u;
+            const uint32_t gx = (tile % uint32_t(g.tiles_x)) * TS + (pos & 63u);
+            outbox[(n == NEXT_REMOTE_UP ? 0u : uint32_t(g.nx)) + gx] = (w & ~BOX_VALID) | BOX_VALID;
+            return;
+        }
         const unsigned long long add = nw_pack(unsigned(w), 1u, nw_con(w) ? 1u : 0u, nw_poi(w) ? 1u : 0u);
         const unsigned long long nw = __hip_atomic_fetch_add(&node_acc[n], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-        if (nw_arr(nw) != node_indeg[n]) break;
+        if (nw_arr(nw) != node_indeg[n]) return;
         u = n; w = nw;
     }
 }
 
+// nodes without entering crossings start
+__global__ __launch_bounds__(256) void ad8_forest_walk_kernel(Ad8Geom g, unsigned long long* __restrict__ node_acc, const uint32_t* __restrict__ node_indeg,
+                                                              const uint32_t* __restrict__ node_next, unsigned long long* __restrict__ outbox) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= g.nnodes_local || node_indeg[i] != 0u) return;
+    forest_walk_from(uint32_t(i), node_acc[i], g, node_acc, node_indeg, node_next, outbox);
+}
+
+// crossings that arrived from the neighbouring ranks: inbox[side * nx + x] = out-box word of the cell in
+// the halo row above (side 0) / below (side 1); each is delivered once and continues the walk here
+__global__ __launch_bounds__(256) void ad8_forest_deliver_kernel(Ad8Geom g, const unsigned long long* __restrict__ inbox, uint8_t* __restrict__ delivered,
+                                                                 unsigned long long* __restrict__ node_acc, uint32_t* __restrict__ node_indeg,
+                                                                 const uint32_t* __restrict__ node_next, unsigned long long* __restrict__ outbox,
+                                                                 unsigned long long* __restrict__ ndelivered) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool did = false;
+    if (i < 2 * g.nx) {
+        const unsigned long long b = inbox[i];
+        if ((b & BOX_VALID) && !delivered[i]) {
+            delivered[i] = 1;
+            did = true;
+            const uint32_t hn = g.nnodes_local + uint32_t(i);
+            const unsigned long long w = b & ~BOX_VALID;
+            // the halo node is complete by construction: arrivals field 0 == in-degree 0
+            const unsigned long long hw = nw_pack(unsigned(w), 0u, nw_con(w) ? 1u : 0u, nw_poi(w) ? 1u : 0u);
+            node_acc[hn] = hw;
+            node_indeg[hn] = 0u;
+            forest_walk_from(hn, hw, g, node_acc, node_indeg, node_next, outbox);
+        }
+    }
+    const unsigned long long m = __ballot(did);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(ndelivered, (unsigned long long)__popcll(m));
+}
+
 // LDS word of the apply pass: cnt[0:32) contam[32:44) poison[44:56)
-__global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int tiles_x,
+__global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              const uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
@@ -387,40 +455,36 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
     __shared__ unsigned long long sAcc[TS * TS];
     __shared__ int16_t sTgt[TS * TS];
     const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x0 = tx * TS, y0 = ty * TS;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, ya0 = g.y0 + ty * TS, rv = rows_valid(g, ty);
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
-    stage_p(P, nx, ny, x0, y0, nodata, sP);
+    stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r;
-        const int gx = x0 + lx, gy = y0 + ly;
-        const int c = (ly + 1) * TH + lx + 1;
-        const int16_t p = sP[c];
+        const int gx = x0 + lx, gy = ya0 + ly;
+        const int16_t p = sP[(ly + 1) * TH + lx + 1];
         int16_t tgt = -1;
-        if (p_part(p, nodata) && p >= 1) {
+        if (ly < rv && p_part(p, nodata) && p >= 1) {
             const int tlx = lx + d1(p), tly = ly + d2(p);
-            if (tlx >= 0 && tlx < TS && tly >= 0 && tly < TS && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt = int16_t(tly * TS + tlx);
+            if (in_tile(tlx, tly, rv) && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt = int16_t(tly * TS + tlx);
         }
         sTgt[ly * TS + lx] = tgt;
         uint32_t cw = 0u;
-        if (gx < nx && gy < ny) cw = cellw[size_t(gy) * size_t(nx) + size_t(gx)];
+        if (gx < g.nx && ly < rv) cw = cellw[size_t(gy) * size_t(g.nx) + size_t(gx)];
         sAcc[ly * TS + lx] = (unsigned long long)(cw & 0x3FFFFFFFu) | ((unsigned long long)((cw >> 30) & 1u) << 32) | ((unsigned long long)(cw >> 31) << 44);
     }
     __syncthreads();
-    for (int j = tid; j < 4 * (TS + 1); j += 256) {
+    for (int j = tid; j < 4 * TH; j += 256) {
         int hx, hy;
-        if (j < TS + 1) { hx = j - 1; hy = -1; }
-        else if (j < 2 * (TS + 1)) { hx = TS; hy = j - (TS + 1) - 1; }
-        else if (j < 3 * (TS + 1)) { hx = j - 2 * (TS + 1); hy = TS; }
-        else { hx = -1; hy = j - 3 * (TS + 1); }
+        if (!ring_cell(j, rv, hx, hy)) continue;
         const int16_t ph = sP[(hy + 1) * TH + hx + 1];
         if (ph == nodata || ph < 1 || ph > 8) continue;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
-        if (vx < 0 || vx >= TS || vy < 0 || vy >= TS) continue;
+        if (!in_tile(vx, vy, rv)) continue;
         if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
-        const uint32_t nid = node_id(x0 + hx, y0 + hy, tiles_x);
+        const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
         const uint32_t ind = node_indeg[nid];
         const unsigned long long w = node_acc[nid];
         unsigned long long add;
@@ -439,8 +503,8 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= nx || gy >= ny) continue;
+        const int gx = x0 + lx, gy = ya0 + ly;
+        if (gx >= g.nx || ly >= rv) continue;
         const unsigned long long w = sAcc[ly * TS + lx];
         const bool part = p_part(sP[(ly + 1) * TH + lx + 1], nodata);
         const unsigned cnt = unsigned(w);
@@ -450,13 +514,13 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
             if (cnt > big_threshold) { a = BIG_MARK; bigmask |= 1u << r; }
             else a = (float)cnt;   // exact: cnt <= 2^24
         }
-        A[size_t(gy) * size_t(nx) + size_t(gx)] = a;
+        A[size_t(gy) * size_t(g.nx) + size_t(gx)] = a;
     }
     const unsigned long long pos0 = block_reserve(unsigned(__popc(bigmask)), nbig);
     unsigned long long pos = pos0;
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        if (bigmask & (1u << r)) biglist[pos++] = uint32_t(size_t(y0 + ry0 + r) * size_t(nx) + size_t(x0 + lx));
+        if (bigmask & (1u << r)) biglist[pos++] = uint32_t(size_t(ya0 + ry0 + r) * size_t(g.nx) + size_t(x0 + lx));
 }
 
 // ---- big cells: exact k-ordered float32 re-evaluation in dependency order ----
@@ -479,39 +543,85 @@ __global__ __launch_bounds__(256) void ad8_big_degree_kernel(const int16_t* __re
     cnt[c] = deg ? deg : CNT_SOURCE;
 }
 
-__global__ __launch_bounds__(256) void ad8_big_walk_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int contcheck,
-                                                           const uint32_t* __restrict__ biglist, unsigned long long nbig,
-                                                           int32_t* __restrict__ cnt, float* __restrict__ A) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
-    size_t idx = biglist[q];
-    if (cnt[idx] != CNT_SOURCE) return;
+// evaluate idx and keep walking downstream through OWNED big cells while this lane is the last contributor
+__device__ __forceinline__ void big_walk_from(size_t idx, const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
+                                              int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A) {
     int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
     for (;;) {
         const float a = ad8_evaluate(P, nullptr, 0.f, A, nx, ny, x, y, idx, nodata, contcheck);
         st_agent(&A[idx], a);
         const int16_t k = P[idx];
-        if (k < 1 || k > 8) break;
+        if (k < 1 || k > 8) return;
         const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) break;
+        if (xn < 0 || xn >= nx || yn < y_own0 || yn >= y_own1) return;   // off the raster, or into a neighbour's row (next round)
         const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-        if (ld_agent(&A[n]) != BIG_MARK) break;   // downstream is not awaiting re-evaluation (contaminated / unevaluated)
+        if (ld_agent(&A[n]) != BIG_MARK) return;   // downstream is not awaiting re-evaluation (contaminated / unevaluated)
         drain_stores();
         const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old != 1) break;
+        if (old != 1) return;
         x = xn; y = yn; idx = n;
     }
+}
+
+__global__ __launch_bounds__(256) void ad8_big_walk_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
+                                                           int contcheck, const uint32_t* __restrict__ biglist, unsigned long long nbig,
+                                                           int32_t* __restrict__ cnt, float* __restrict__ A) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nbig) return;
+    const size_t idx = biglist[q];
+    if (cnt[idx] != CNT_SOURCE) return;
+    big_walk_from(idx, P, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+}
+
+// A halo row after an exchange: cells that turned from "awaiting re-evaluation" into a final value release
+// the owned big cell they drain into
+__global__ __launch_bounds__(256) void ad8_big_halo_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
+                                                           int contcheck, int yh, const float* __restrict__ recv, int32_t* __restrict__ cnt,
+                                                           float* __restrict__ A, unsigned long long* __restrict__ nchanged) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (x < nx) {
+        const size_t h = size_t(yh) * size_t(nx) + size_t(x);
+        const float a = recv[x], old = A[h];
+        if (a != old) {
+            ch = true;
+            st_agent(&A[h], a);
+            const int16_t k = P[h];
+            if (old == BIG_MARK && a != BIG_MARK && k != nodata && k >= 1 && k <= 8) {
+                const int xn = x + d1(k), yn = yh + d2(k);
+                if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
+                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+                    if (ld_agent(&A[n]) == BIG_MARK) {
+                        drain_stores();
+                        const int32_t o = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (o == 1) big_walk_from(n, P, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(ch);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nchanged, (unsigned long long)__popcll(m));
 }
 
 }  // namespace
 
 
-// unweighted, no outlets: tile contraction (see the block comment above)
-static int aread8_tiled(tdx_context* ctx, const int16_t* d_p, int inx, int iny, int16_t p_nodata, int contcheck, float* d_ad8, tdx_stats* stats) {
+// unweighted, no outlets: tile contraction (see the block comment above).  Multi-strip: crossings that
+// leave the strip are handed to the neighbouring rank through per-column out-boxes, and the exact
+// re-evaluation of big cells continues across strips through exchanged boundary rows of ad8 - both in
+// outer rounds that end when no rank received anything new (the role of the outer while loop with
+// share()/addBorders() in src/aread8.cpp:282-303).
+static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_nodata, int contcheck, float* d_ad8, tdx_stats* stats) {
     hipStream_t s = ctx->stream;
-    const size_t n = size_t(inx) * size_t(iny);
-    const int tiles_x = (inx + TS - 1) / TS, tiles_y = (iny + TS - 1) / TS;
-    const size_t ntiles = size_t(tiles_x) * size_t(tiles_y), nnodes = ntiles * 256;
+    const int inx = st.nx;
+    const size_t n = size_t(st.nx) * size_t(st.ny_arr);
+    Ad8Geom g;
+    g.nx = st.nx; g.ny_arr = st.ny_arr; g.y0 = st.y0; g.y1 = st.y1;
+    g.tiles_x = (st.nx + TS - 1) / TS; g.tiles_y = (st.y1 - st.y0 + TS - 1) / TS;
+    const size_t ntiles = size_t(g.tiles_x) * size_t(g.tiles_y);
+    g.nnodes_local = uint32_t(ntiles * 256);
+    const size_t nnodes = size_t(g.nnodes_local) + 2 * size_t(st.nx);   // + the halo-row nodes
     uint32_t* cellw = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, n * 4));          // later reused as the big-cell counters
     unsigned long long* node_acc = static_cast<unsigned long long*>(ctx->scratch(TDX_S_B, nnodes * 8));
     uint32_t* node_indeg = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, nnodes * 4));
@@ -519,45 +629,107 @@ static int aread8_tiled(tdx_context* ctx, const int16_t* d_p, int inx, int iny, 
     const unsigned big_threshold = getenv("TDX_AD8_BIG_THRESHOLD") ? unsigned(atol(getenv("TDX_AD8_BIG_THRESHOLD"))) : (1u << 24);   // test hook
     const size_t bigcap = big_threshold < (1u << 24) ? n : n / 8 + 4096;
     uint32_t* biglist = static_cast<uint32_t*>(ctx->scratch(TDX_S_E, bigcap * 4));
-    if (!cellw || !node_acc || !node_indeg || !node_next || !biglist) return TDX_ERR_NOMEM;
+    unsigned long long* boxes = static_cast<unsigned long long*>(ctx->scratch(TDX_S_F, size_t(st.nx) * 4 * 8));   // out-box[2nx], in-box[2nx]
+    uint8_t* delivered = static_cast<uint8_t*>(ctx->scratch(TDX_S_G, size_t(st.nx) * 2));
+    if (!cellw || !node_acc || !node_indeg || !node_next || !biglist || !boxes || !delivered) return TDX_ERR_NOMEM;
+    unsigned long long *outbox = boxes, *inbox = boxes + 2 * size_t(st.nx);
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     ctx->begin_call(stats);
+    int rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);   // directions of the neighbours' boundary rows
+    if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(node_indeg, 0xFF, nnodes * 4, s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(node_next, 0xFF, nnodes * 4, s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(boxes, 0, size_t(st.nx) * 4 * 8, s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(delivered, 0, size_t(st.nx) * 2, s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_tile_local_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, inx, iny, p_nodata, tiles_x, cellw, node_acc,
-                           node_indeg, node_next);
+        hipLaunchKernelGGL(ad8_tile_local_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
+    int64_t outer = 1;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL(ad8_forest_walk_kernel, dim3(tdx_blocks_for(nnodes, 256)), dim3(256), 0, s, node_acc, node_indeg, node_next, nnodes);
+        hipLaunchKernelGGL(ad8_forest_walk_kernel, dim3(tdx_blocks_for(size_t(g.nnodes_local), 256)), dim3(256), 0, s, g, node_acc, node_indeg, node_next,
+                           outbox);
         if (stats) stats->launches[TDX_K_ACCUM]++;
+        while (st.multi()) {
+            const size_t rowb = size_t(st.nx) * 8;
+            rc = strip_exchange_buffers(ctx, st, outbox, outbox + st.nx, inbox, inbox + st.nx, rowb);
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(ad8_forest_deliver_kernel, dim3(tdx_blocks_for(size_t(2 * st.nx), 256)), dim3(256), 0, s, g, inbox, delivered, node_acc,
+                               node_indeg, node_next, outbox, d_cnt + 1);
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            int64_t got = int64_t(ctx->h_mail[0]);
+            rc = strip_allreduce(ctx, st, &got, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (stats) stats->launches[TDX_K_ACCUM]++;
+            if (got == 0) break;
+            outer++;
+        }
     }
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, inx, iny, p_nodata, tiles_x, cellw, node_acc,
-                           node_indeg, contcheck, big_threshold, d_ad8, biglist, d_cnt);
+        hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
+                           big_threshold, d_ad8, biglist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     const unsigned long long nbig = ctx->h_mail[0];
     if (nbig > bigcap) return tdx_fail(ctx, TDX_ERR_NOMEM, "AreaD8: big-cell list exhausted");
-    if (nbig > 0) {
+    int64_t nbig_all = int64_t(nbig);
+    rc = strip_allreduce(ctx, st, &nbig_all, 1, TDX_OP_SUM);
+    if (rc != TDX_OK) return rc;
+    if (nbig_all > 0) {
         TdxSpan sp(ctx, TDX_K_MISC);
         int32_t* bigcnt = reinterpret_cast<int32_t*>(cellw);
-        hipLaunchKernelGGL(ad8_big_degree_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, iny, p_nodata, biglist, nbig, d_ad8, bigcnt);
-        hipLaunchKernelGGL(ad8_big_walk_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, iny, p_nodata, contcheck, biglist, nbig,
-                           bigcnt, d_ad8);
+        rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);   // which halo cells await re-evaluation
+        if (rc != TDX_OK) return rc;
+        if (nbig) {
+            hipLaunchKernelGGL(ad8_big_degree_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, p_nodata, biglist, nbig, d_ad8,
+                               bigcnt);
+            hipLaunchKernelGGL(ad8_big_walk_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata,
+                               contcheck, biglist, nbig, bigcnt, d_ad8);
+        }
         if (stats) stats->launches[TDX_K_MISC] += 2;
+        while (st.multi()) {
+            const size_t rowb = size_t(st.nx) * 4;
+            rc = strip_exchange_buffers(ctx, st, d_ad8 + size_t(st.y0) * st.nx, d_ad8 + size_t(st.y1 - 1) * st.nx, st.comm->recv_up, st.comm->recv_down, rowb);
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
+            const unsigned gx = tdx_blocks_for(size_t(st.nx), 256);
+            if (st.up)
+                hipLaunchKernelGGL(ad8_big_halo_kernel, dim3(gx), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, st.y0 - 1,
+                                   static_cast<const float*>(st.comm->recv_up), bigcnt, d_ad8, d_cnt + 1);
+            if (st.down)
+                hipLaunchKernelGGL(ad8_big_halo_kernel, dim3(gx), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, st.y1,
+                                   static_cast<const float*>(st.comm->recv_down), bigcnt, d_ad8, d_cnt + 1);
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            int64_t changed = int64_t(ctx->h_mail[0]);
+            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (changed == 0) break;
+            outer++;
+        }
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
-    tdx_stats* st = stats;
+    tdx_stats* stt = stats;
     ctx->end_call();
-    if (st) { st->rounds = 1; st->cells_evaluated = int64_t(nbig); }
+    if (stt) { stt->rounds = outer; stt->cells_evaluated = nbig_all; }
     return TDX_OK;
+}
+
+extern "C" int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                                int contcheck, float* d_ad8, tdx_stats* stats) {
+    if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) >= (uint64_t(1) << 30))
+        return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: at most 2^30 cells per device strip");
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return aread8_tiled(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, contcheck, d_ad8, stats);
 }
 
 extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
@@ -573,7 +745,7 @@ extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, 
     const int inx = int(nx), iny = int(ny);
     const size_t n = size_t(nx) * size_t(ny);
     const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
-    if (!d_w && n_outlets < 0 && n < (size_t(1) << 30) && !force_walk) return aread8_tiled(ctx, d_p, inx, iny, p_nodata, contcheck, d_ad8, stats);
+    if (!d_w && n_outlets < 0 && n < (size_t(1) << 30) && !force_walk) return aread8_tiled(ctx, strip_single(inx, iny), const_cast<int16_t*>(d_p), p_nodata, contcheck, d_ad8, stats);
     int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
     if (!cnt) return TDX_ERR_NOMEM;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);

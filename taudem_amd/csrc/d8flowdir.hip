@@ -32,12 +32,12 @@ constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-t
 // One lane walks down a column segment keeping the 3x3 window in registers (3 loads per new row).
 // Besides p and sd8 it initialises the flat-resolution markers (lvl/rq: 0 flat, -1 otherwise) and
 // appends the flat cells to `qlist` with ONE atomic per block.
-__global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, float nodata,
+__global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
                                                        float* __restrict__ SD8, int32_t* __restrict__ lvl, int32_t* __restrict__ rq,
                                                        uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
+    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
     const bool colok = x < nx;
     const int xm = x > 0 ? x - 1 : x, xp = (x < nx - 1) ? x + 1 : (colok ? x : nx - 1);
     const int xc = colok ? x : nx - 1;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
         ldrow(y + 1, s0, s1, s2);
-        if (colok && y < ny) {
+        if (colok && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
             int16_t p = TDX_P_NODATA;
             float sd = -1.0f;
@@ -193,17 +193,16 @@ int tdx_build_fact_table(tdx_context* ctx, int64_t ny, const double* dxc, const 
     return TDX_OK;
 }
 
-extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
-                                 const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats) {
-    if (!ctx || !d_fel || !d_p || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_d8flowdir_dev: bad argument");
-    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
-        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+// One strip of setdird8() (src/d8.cpp:227-320).  Counts that steer the outer loop (flats left) are summed
+// over the ranks, so every rank takes the same branches (src/d8.cpp:294-316).
+static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, int16_t* d_p,
+                          float* d_sd8, tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
-    const size_t n = size_t(nx) * size_t(ny);
+    const int inx = st.nx;
+    const size_t n = size_t(st.nx) * size_t(st.ny_arr);
     double* d_fact = nullptr;
-    int rc = tdx_build_fact_table(ctx, ny, dxc, dyc, &d_fact);
+    int rc = tdx_build_fact_table(ctx, st.ny_arr, dxc, dyc, &d_fact);
     if (rc != TDX_OK) return rc;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     // flat-resolution markers and the flat queue are produced by the slope pass itself
@@ -213,54 +212,71 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
     if (!lvl || !rq || !qlist) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
+    rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
+    if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (iny + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
-        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_fact, d_p, d_sd8, lvl, rq, qlist, d_cnt);
+        dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, lvl, rq, qlist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    unsigned long long total = ctx->h_mail[0];
-    if (stats) { stats->flats_initial = int64_t(total); stats->flats_left = int64_t(total); }
+    unsigned long long nq = ctx->h_mail[0];        // flats of this strip
+    int64_t total = int64_t(nq);                    // flats of the whole raster
+    rc = strip_allreduce(ctx, st, &total, 1, TDX_OP_SUM);
+    if (rc != TDX_OK) return rc;
+    if (stats) { stats->flats_initial = total; stats->flats_left = total; }
 
     if (total > 0) {
+        rc = strip_exchange<int16_t>(ctx, st, d_p, TDX_P_NODATA);
+        if (rc != TDX_OK) return rc;
+        rc = strip_exchange<int32_t>(ctx, st, lvl, -1);
+        if (rc != TDX_OK) return rc;
+        rc = strip_exchange<int32_t>(ctx, st, rq, -1);
+        if (rc != TDX_OK) return rc;
         // working storage for flat resolution
-        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
+        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(nq) * 4));
         if (!qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;            // allocated only if a second iteration is needed
         const float* zcur = d_fel;
         FlatBuffers fbuf{lvl, rq};
 
         // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
-        unsigned long long nq = total;
-        unsigned long long last = total;
+        int64_t last = total;
         bool first = true;
         for (;;) {
             if (!first) {
                 // later calls: elev2 / dn are re-created (src/d8.cpp:483-486): reset markers of the new Q
-                rc = flats_reset_markers(ctx, n, qlist, nq, lvl, rq);
+                rc = flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
                 if (rc != TDX_OK) return rc;
             }
             first = false;
             FlatLevels fl;
             D8Traits tr{d_p};
-            rc = flats_bfs<D8Traits>(ctx, tr, zcur, inx, iny, qlist, nq, fbuf, &fl, stats);
+            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
-                if (fl.has_pits)
-                    hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
-                hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-                hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
+                if (nq) {
+                    if (fl.has_pits)
+                        hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
+                    hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
+                    hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
+                }
                 TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
             }
-            total = ctx->h_mail[0];
-            if (stats) { stats->flat_iterations++; stats->flats_left = int64_t(total); }
+            const unsigned long long nleft = ctx->h_mail[0];
+            total = int64_t(nleft);
+            rc = strip_allreduce(ctx, st, &total, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange<int16_t>(ctx, st, d_p, TDX_P_NODATA);   // directions of the neighbours' boundary rows
+            if (rc != TDX_OK) return rc;
+            if (stats) { stats->flat_iterations++; stats->flats_left = total; }
             if (!(total > 0 && total < last)) break;     // src/d8.cpp:307
             // another iteration: elevDEM := (float)elev2 for ALL cells (src/d8.cpp:669-675)
             if (!zwork) {
@@ -271,13 +287,29 @@ extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t n
             if (rc != TDX_OK) return rc;
             zcur = zwork;
             std::swap(qlist, qnext);
-            nq = total;
+            nq = nleft;
             last = total;
         }
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
     ctx->end_call();
     return TDX_OK;
+}
+
+extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                                 const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_p || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_d8flowdir_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return d8flowdir_impl(ctx, strip_single(int(nx), int(ny)), const_cast<float*>(d_fel), fel_nodata, dxc, dyc, d_p, d_sd8, stats);
+}
+
+extern "C" int tdx_d8flowdir_strip(tdx_context* ctx, const tdx_comm* comm, float* d_fel, int64_t nx, int64_t ny_local, float fel_nodata,
+                                   const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_p || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_d8flowdir_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return d8flowdir_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_fel, fel_nodata, dxc, dyc, d_p, d_sd8, stats);
 }
 
 extern "C" int tdx_d8flowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,

@@ -278,11 +278,11 @@ extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t
         bool first = true;
         int rc;
         for (;;) {
-            if (!first) { rc = flats_reset_markers(ctx, n, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
+            if (!first) { rc = flats_reset_markers(ctx, strip_single(inx, iny), qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
-            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, inx, iny, qlist, nq, fbuf, &fl, stats);
+            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, strip_single(inx, iny), qlist, nq, fbuf, &fl, stats);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);

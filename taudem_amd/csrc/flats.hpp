@@ -29,6 +29,7 @@
 
 #include "context.hpp"
 #include "device_common.hpp"
+#include "strips.hpp"
 #include "tile_relax.hpp"
 
 struct FlatLevels { int T; int Tr; int has_pits; };
@@ -156,11 +157,14 @@ static inline int flats_read_counters(tdx_context* ctx, int nwords) {
     return TDX_OK;
 }
 
-static inline int flats_reset_markers(tdx_context* ctx, size_t n, const uint32_t* qlist, unsigned long long nq, int32_t* lvl, int32_t* rq) {
+static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const uint32_t* qlist, unsigned long long nq, int32_t* lvl, int32_t* rq) {
+    const size_t n = size_t(st.nx) * size_t(st.ny_arr);
     TDX_HIP_CHECK(ctx, hipMemsetAsync(lvl, 0xFF, n * 4, ctx->stream));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(rq, 0xFF, n * 4, ctx->stream));
-    hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
-    return TDX_OK;
+    if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
+    int rc = strip_exchange<int32_t>(ctx, st, lvl, -1);   // queue membership of the neighbours' boundary rows
+    if (rc != TDX_OK) return rc;
+    return strip_exchange<int32_t>(ctx, st, rq, -1);
 }
 
 static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const int32_t* lvl, const int32_t* rq, FlatLevels fl, float* zout) {
@@ -169,14 +173,34 @@ static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const in
     return TDX_OK;
 }
 
-// Runs classification + both level relaxations for the flat queue `qlist`; on return lvl/rq hold the
-// levels and *out the sweep counts of the reference's loops.
+// One level field to its GLOBAL fixed point: relax the strip with frozen halo rows, exchange boundary
+// rows, re-activate the tiles that see a changed halo cell, until no halo cell changed on any rank
+// (the per-level share() + MPI_Allreduce of src/d8.cpp:549-550,620-630, once per strip crossing instead
+// of once per level).
+static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, int32_t* field, const uint8_t* mask, tilek::Sched sc,
+                                    int64_t* rounds, int64_t* launches) {
+    for (;;) {
+        int rc = tile_relax_run(ctx, flatk::LevelOp{field, mask}, geom, sc, rounds, launches);
+        if (rc != TDX_OK) return rc;
+        if (!st.multi()) return TDX_OK;
+        int64_t changed = 0;
+        rc = strip_exchange<int32_t>(ctx, st, field, -1, sc.flags, geom.tiles_x, &changed);
+        if (rc != TDX_OK) return rc;
+        rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+        if (rc != TDX_OK) return rc;
+        if (changed == 0) return TDX_OK;
+    }
+}
+
+// Runs classification + both level relaxations for the flat queue `qlist` (cells of this strip); on return
+// lvl/rq hold the levels (halo rows included) and *out the sweep counts of the reference's loops.
 template <class Traits>
-static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, int nx, int ny, const uint32_t* qlist, unsigned long long nq,
+static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
                      FlatBuffers b, FlatLevels* out, tdx_stats* stats) {
     hipStream_t s = ctx->stream;
-    const size_t n = size_t(nx) * size_t(ny);
-    const tilek::TileGeom geom = tilek::make_geom(nx, ny, 0, ny);
+    const int nx = st.nx;
+    const size_t n = size_t(nx) * size_t(st.ny_arr);
+    const tilek::TileGeom geom = tilek::make_geom(nx, st.ny_arr, st.y0, st.y1);
     const int ntiles = geom.tiles_x * geom.tiles_y;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     uint8_t* fmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_E, n));
@@ -191,22 +215,32 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, int nx, int ny
     TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(flags0, 0, size_t(ntiles) * 4, s));
-    hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
-                       geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
+    if (nq)
+        hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
+                           geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
+    int rc = strip_exchange<int32_t>(ctx, st, b.lvl, -1);   // the neighbours' seeds
+    if (rc != TDX_OK) return rc;
+    rc = strip_exchange<int32_t>(ctx, st, b.rq, -1);
+    if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
     // ---- incfall ----
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-    int rc = tile_relax_run(ctx, flatk::LevelOp{b.lvl, fmask}, geom, tilek::Sched{flags, list, counts}, &rounds_fall, &launches);
+    rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches);
     if (rc != TDX_OK) return rc;
     // ---- incrise ----
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-    rc = tile_relax_run(ctx, flatk::LevelOp{b.rq, rmask}, geom, tilek::Sched{flags, list, counts}, &rounds_rise, &launches);
+    rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches);
     if (rc != TDX_OK) return rc;
-    hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    if (nq) hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
     rc = flats_read_counters(ctx, 3);
     if (rc != TDX_OK) return rc;
-    const int L = int(ctx->h_mail[0]), Qmax = int(ctx->h_mail[2]);
-    const unsigned long long unvisited = ctx->h_mail[1];
+    int64_t mx[2] = {int64_t(ctx->h_mail[0]), int64_t(ctx->h_mail[2])}, unvisited = int64_t(ctx->h_mail[1]);
+    rc = strip_allreduce(ctx, st, mx, 2, TDX_OP_MAX);
+    if (rc != TDX_OK) return rc;
+    rc = strip_allreduce(ctx, st, &unvisited, 1, TDX_OP_SUM);
+    if (rc != TDX_OK) return rc;
+    const int L = int(mx[0]), Qmax = int(mx[1]);
     if (L >= 32767 || Qmax >= 32767)
         return tdx_fail(ctx, TDX_ERR_ARG, "flat resolution deeper than the reference's int16 level counter allows");
     out->T = (L == 1 && unvisited == 0) ? 1 : ((L > 1 ? L : 1) + 1);

@@ -18,15 +18,16 @@
 // path measured in tiles.
 #include "context.hpp"
 #include "device_common.hpp"
+#include "strips.hpp"
 #include "tile_relax.hpp"
 
 namespace {
 
 __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__ Z, const int16_t* __restrict__ mask,
-                                                       float* __restrict__ W, int nx, int ny, float nodata, int step) {
+                                                       float* __restrict__ W, int nx, int ny, int y_own0, int y_own1, float nodata, int step) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= ny) return;
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= y_own1) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     const float z = Z[idx];
     float w;
@@ -58,21 +59,17 @@ struct PitOp {
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
 };
 
-constexpr int TILE = 64;
-constexpr int LDS_W = TILE + 2;
-constexpr int ROWS_PER_WAVE = 16;   // 4 waves x 16 rows
-
 }  // namespace
 
-extern "C" int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t nx, int64_t ny, float dem_nodata,
-                                 const int16_t* d_mask, int fourway, float* d_fel, tdx_stats* stats) {
-    if (!ctx || !d_dem || !d_fel || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_pitremove_dev: bad argument");
-    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
-        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+// One strip (src/flood.cpp:132-482).  Multi-strip: every rank relaxes its strip to the local fixed point
+// with the neighbours' boundary rows frozen in its halo rows, then boundary rows are exchanged and the
+// tiles that see a changed halo cell are re-activated; repeat until no halo cell changed on any rank
+// (the roles of share() + ringTerm() in src/flood.cpp:344-355,457-468).
+static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const int16_t* d_mask, int fourway, float dem_nodata, float* d_fel,
+                          tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
-    const tilek::TileGeom geom = tilek::make_geom(inx, iny, 0, iny);
+    const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
     const int ntiles = geom.tiles_x * geom.tiles_y;
     uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, size_t(ntiles) * 4));
     uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_B, size_t(ntiles) * 4));
@@ -80,26 +77,56 @@ extern "C" int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t n
     if (!flags || !list || !counts) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
+    int rc = strip_exchange<float>(ctx, st, d_dem, dem_nodata);   // elevation halo rows
+    if (rc != TDX_OK) return rc;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (iny + 3) / 4);
-        hipLaunchKernelGGL(pit_seed_kernel, grid, dim3(256), 0, s, d_dem, d_mask, d_fel, inx, iny, dem_nodata, fourway ? 2 : 1);
+        dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
+        hipLaunchKernelGGL(pit_seed_kernel, grid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, fourway ? 2 : 1);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
+    rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // seed surface halo rows
+    if (rc != TDX_OK) return rc;
     // round 0: every tile is active
     hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, 1u, size_t(ntiles));
-    int64_t rounds = 0, launches = 0;
+    int64_t rounds = 0, launches = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
         PitOp op{d_dem, d_fel, fourway ? 0x55u : 0xFFu};
-        int rc = tile_relax_run(ctx, op, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
-        if (rc != TDX_OK) return rc;
+        for (;;) {
+            rc = tile_relax_run(ctx, op, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
+            if (rc != TDX_OK) return rc;
+            outer++;
+            if (!st.multi()) break;
+            int64_t changed = 0;
+            rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA, flags, geom.tiles_x, &changed);
+            if (rc != TDX_OK) return rc;
+            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (changed == 0) break;
+        }
         if (stats) stats->launches[TDX_K_RELAX] += launches;
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
-    if (stats) stats->rounds = rounds;
+    if (stats) { stats->rounds = rounds; stats->cells_evaluated = outer; }
     ctx->end_call();
     return TDX_OK;
+}
+
+extern "C" int tdx_pitremove_dev(tdx_context* ctx, const float* d_dem, int64_t nx, int64_t ny, float dem_nodata,
+                                 const int16_t* d_mask, int fourway, float* d_fel, tdx_stats* stats) {
+    if (!ctx || !d_dem || !d_fel || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_pitremove_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return pitremove_impl(ctx, strip_single(int(nx), int(ny)), const_cast<float*>(d_dem), d_mask, fourway, dem_nodata, d_fel, stats);
+}
+
+extern "C" int tdx_pitremove_strip(tdx_context* ctx, const tdx_comm* comm, float* d_dem, int64_t nx, int64_t ny_local, float dem_nodata,
+                                   const int16_t* d_mask, int fourway, float* d_fel, tdx_stats* stats) {
+    if (!ctx || !d_dem || !d_fel || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_pitremove_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return pitremove_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_dem, d_mask, fourway, dem_nodata, d_fel, stats);
 }
 
 extern "C" int tdx_pitremove(tdx_context* ctx, const float* dem, int64_t nx, int64_t ny, float dem_nodata,

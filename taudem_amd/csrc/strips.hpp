@@ -1,0 +1,125 @@
+// Row strips: halo rows and the host-provided exchange (tdx_comm, include/taudem_amd.h).
+// Replaces linearpart<T>::share() / passBorders() / ringTerm() (src/linearpart.h:194-360).
+//
+// A Strip describes the rows of a device array that the calling rank may write ("owned") and whether a
+// halo row above / below belongs to a neighbouring rank.  For the single-strip entry points the array
+// has no halo rows at all (own = [0, ny)): kernels read rows outside the array as nodata, which is
+// what a halo row beyond the global raster holds in a strip array.
+#pragma once
+#include "context.hpp"
+#include "device_common.hpp"
+
+struct Strip {
+    int nx = 0;
+    int ny_arr = 0;          // rows of the device arrays
+    int y0 = 0, y1 = 0;      // owned rows [y0, y1)
+    bool up = false, down = false;   // a neighbouring rank owns the halo row above / below
+    const tdx_comm* comm = nullptr;
+    bool multi() const { return comm && comm->size > 1; }
+};
+
+static inline Strip strip_single(int nx, int ny) {
+    Strip s; s.nx = nx; s.ny_arr = ny; s.y0 = 0; s.y1 = ny; return s;
+}
+static inline Strip strip_from_comm(const tdx_comm* comm, int nx, int ny_local) {
+    Strip s; s.nx = nx; s.ny_arr = ny_local + 2; s.y0 = 1; s.y1 = ny_local + 1; s.comm = comm;
+    if (comm && comm->size > 1) { s.up = comm->rank > 0; s.down = comm->rank < comm->size - 1; }
+    return s;
+}
+
+namespace stripk {
+template <class T>
+__global__ void fill_row_kernel(T* row, T v, int nx) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x < nx) row[x] = v;
+}
+// halo <- recv where they differ; counts the differing cells and raises the activation flag of the
+// tiles that see the changed cell (tile rows tr0 / tr1, columns x-1 .. x+1)
+template <class T>
+__global__ void merge_row_kernel(T* halo, const T* recv, int nx, unsigned long long* nchanged, uint32_t* tile_flags, int tiles_x, int tr0, int tr1) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (x < nx) {
+        const T a = recv[x];
+        if (!(a == halo[x])) {
+            halo[x] = a;
+            ch = true;
+            if (tile_flags) {
+                const int t0 = (x > 0 ? x - 1 : 0) / 64, t1 = (x + 1 < nx ? x + 1 : nx - 1) / 64;
+                for (int t = t0; t <= t1; t++) {
+                    tile_flags[tr0 * tiles_x + t] = 1u;
+                    tile_flags[tr1 * tiles_x + t] = 1u;
+                }
+            }
+        }
+    }
+    const unsigned long long b = __ballot(ch);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nchanged, (unsigned long long)__popcll(b));
+}
+}  // namespace stripk
+
+static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v, int count, int op) {
+    if (!st.multi()) return TDX_OK;
+    if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed");
+    return TDX_OK;
+}
+
+// Halo rows of `arr` <- the neighbours' boundary rows (or `outside` beyond the raster).  With
+// tile_flags != nullptr only differing cells are written, the tiles that see them are flagged, and
+// *nchanged (host) receives this rank's number of changed halo cells.
+template <class T>
+static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, uint32_t* tile_flags = nullptr, int tiles_x = 0, int64_t* nchanged = nullptr) {
+    if (nchanged) *nchanged = 0;
+    if (st.ny_arr == st.y1 - st.y0) return TDX_OK;   // single-strip array without halo rows
+    hipStream_t s = ctx->stream;
+    const size_t nx = size_t(st.nx), bytes = nx * sizeof(T);
+    const unsigned g = tdx_blocks_for(nx, 256);
+    if (!st.up) hipLaunchKernelGGL(stripk::fill_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(st.y0 - 1) * nx, outside, st.nx);
+    if (!st.down) hipLaunchKernelGGL(stripk::fill_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(st.y1) * nx, outside, st.nx);
+    if (!st.multi()) return TDX_OK;
+    const tdx_comm* c = st.comm;
+    if (bytes > c->capacity) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm buffers smaller than one raster row");
+    if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, arr + size_t(st.y0) * nx, bytes, hipMemcpyDeviceToDevice, s));
+    if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, arr + size_t(st.y1 - 1) * nx, bytes, hipMemcpyDeviceToDevice, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
+    if (!tile_flags && !nchanged) {
+        if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y0 - 1) * nx, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
+        if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y1) * nx, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
+        return TDX_OK;
+    }
+    unsigned long long* d_n = reinterpret_cast<unsigned long long*>(ctx->d_mail) + 40;
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), s));
+    if (st.up) {
+        const int yh = st.y0 - 1;
+        hipLaunchKernelGGL(stripk::merge_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(yh) * nx, static_cast<const T*>(c->recv_up), st.nx, d_n,
+                           tile_flags, tiles_x, yh / 64, (yh + 1) / 64);
+    }
+    if (st.down) {
+        const int yh = st.y1;
+        hipLaunchKernelGGL(stripk::merge_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(yh) * nx, static_cast<const T*>(c->recv_down), st.nx, d_n,
+                           tile_flags, tiles_x, (yh - 1) / 64, yh / 64);
+    }
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 40, d_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (nchanged) *nchanged = int64_t(ctx->h_mail[40]);
+    return TDX_OK;
+}
+
+// Raw neighbour exchange of two caller-chosen device buffers: `up_src` goes to the rank above, `down_src`
+// to the rank below; what they sent towards this rank lands in up_dst (from above) / down_dst (from
+// below).  Missing neighbours are skipped (their destination is left untouched).
+static inline int strip_exchange_buffers(tdx_context* ctx, const Strip& st, const void* up_src, const void* down_src, void* up_dst, void* down_dst,
+                                         size_t bytes) {
+    if (!st.multi()) return TDX_OK;
+    hipStream_t s = ctx->stream;
+    const tdx_comm* c = st.comm;
+    if (bytes > c->capacity) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm buffers smaller than one exchange row");
+    if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, up_src, bytes, hipMemcpyDeviceToDevice, s));
+    if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, down_src, bytes, hipMemcpyDeviceToDevice, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
+    if (st.up && up_dst != c->recv_up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(up_dst, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
+    if (st.down && down_dst != c->recv_down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(down_dst, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
+    return TDX_OK;
+}

@@ -1,0 +1,182 @@
+"""Row strips across GPUs: one process per GPU, one horizontal strip (+ one halo row above and below)
+per process - the layout of the reference's linearpart<T> (src/linearpart.h:133-162) - with the halo
+exchange and the termination votes carried by torch.distributed (backend "nccl" = RCCL over xGMI on a
+GPU node; "gloo" with host staging for CPU-side tests and for several ranks sharing one GPU).
+
+The library itself never talks to a communication library: it calls back into :class:`StripComm`
+through the ``tdx_comm`` struct of include/taudem_amd.h (exchange one boundary row with each strip
+neighbour; all-reduce a few int64 on the host).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TdxStats, check
+
+
+def partition_rows(ny: int, size: int):
+    """Row ranges [y0, y1) per rank: ny // size rows each, the remainder to the last rank
+    (src/linearpart.h:133-134)."""
+    base = ny // size
+    out = []
+    for r in range(size):
+        y0 = r * base
+        y1 = (r + 1) * base if r < size - 1 else ny
+        out.append((y0, y1))
+    return out
+
+
+class StripComm:
+    """tdx_comm backed by a torch.distributed process group (ranks ordered north to south)."""
+
+    def __init__(self, nx: int, device: int | None = 0, group=None):
+        """device=None keeps the four exchange buffers in host memory (protocol tests without a GPU)."""
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.dev = torch.device(f"cuda:{device}") if device is not None else torch.device("cpu")
+        self.capacity = 16 * int(nx)
+        self._bufs = [torch.zeros(self.capacity, dtype=torch.uint8, device=self.dev) for _ in range(4)]   # send_up send_down recv_up recv_down
+        self._host = None
+        if self.backend != "nccl" and self.dev.type == "cuda":
+            self._host = [torch.zeros(self.capacity, dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self.exchanges = 0
+        self.allreduces = 0
+        self._ex_cb = _lib.EXCHANGE_FN(self._exchange)
+        self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce)
+        self.struct = _lib.TdxComm(self.rank, self.size, None, self._ex_cb, self._ar_cb, *[C.c_void_p(b.data_ptr()) for b in self._bufs], self.capacity)
+
+    def ptr(self):
+        return C.byref(self.struct)
+
+    def _peer(self, delta):
+        r = self.rank + delta
+        if r < 0 or r >= self.size:
+            return None
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _exchange(self, user, nbytes):
+        try:
+            torch, dist = self.torch, self.dist
+            n = int(nbytes)
+            up, down = self._peer(-1), self._peer(+1)
+            self.exchanges += 1
+            if self.backend == "nccl":
+                s_up, s_dn, r_up, r_dn = [b[:n] for b in self._bufs]
+                ops = []
+                if up is not None:
+                    ops += [dist.P2POp(dist.isend, s_up, up, self.group), dist.P2POp(dist.irecv, r_up, up, self.group)]
+                if down is not None:
+                    ops += [dist.P2POp(dist.isend, s_dn, down, self.group), dist.P2POp(dist.irecv, r_dn, down, self.group)]
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                torch.cuda.synchronize(self.dev)
+            else:   # gloo: host staging (or host buffers to begin with)
+                staged = self._host is not None
+                h = [x[:n] for x in (self._host if staged else self._bufs)]
+                if staged:
+                    if up is not None:
+                        h[0].copy_(self._bufs[0][:n])
+                    if down is not None:
+                        h[1].copy_(self._bufs[1][:n])
+                    torch.cuda.synchronize(self.dev)
+                reqs = []
+                if up is not None:
+                    reqs += [dist.isend(h[0], up, self.group, tag=1), dist.irecv(h[2], up, self.group, tag=2)]
+                if down is not None:
+                    reqs += [dist.isend(h[1], down, self.group, tag=2), dist.irecv(h[3], down, self.group, tag=1)]
+                for r in reqs:
+                    r.wait()
+                if staged:
+                    if up is not None:
+                        self._bufs[2][:n].copy_(h[2])
+                    if down is not None:
+                        self._bufs[3][:n].copy_(h[3])
+                    torch.cuda.synchronize(self.dev)
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            import sys
+            print(f"StripComm.exchange failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+    def _allreduce(self, user, values, count, op):
+        try:
+            torch, dist = self.torch, self.dist
+            self.allreduces += 1
+            a = np.ctypeslib.as_array(values, shape=(int(count),))
+            t = torch.from_numpy(a.copy())
+            if self.backend == "nccl":
+                t = t.to(self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=self.group)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception as e:
+            import sys
+            print(f"StripComm.allreduce failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+
+def _tptr(t, dtype, shape, name):
+    import torch
+
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: need a contiguous CUDA tensor {dtype} of shape {tuple(shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+class StripPipeline:
+    """PitRemove -> D8FlowDir -> AreaD8 on one strip of a row-partitioned raster.  All rasters are CUDA
+    tensors of shape (ny_local + 2, nx): row 0 / row -1 are the halo rows the library maintains."""
+
+    def __init__(self, ctx, comm: StripComm | None, nx: int, ny_local: int):
+        import torch
+
+        self.ctx, self.comm, self.nx, self.ny_local = ctx, comm, int(nx), int(ny_local)
+        self.torch = torch
+        self.shape = (self.ny_local + 2, self.nx)
+        self._cp = comm.ptr() if comm is not None else None
+
+    def empty(self, dtype):
+        return self.torch.empty(self.shape, dtype=dtype, device=f"cuda:{self.ctx.device}")
+
+    def pitremove(self, dem, nodata=-9999.0, fourway=False, out=None):
+        torch = self.torch
+        fel = out if out is not None else self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_pitremove_strip(self.ctx._h, self._cp, _tptr(dem, torch.float32, self.shape, "dem"), self.nx, self.ny_local,
+                                                float(nodata), None, int(bool(fourway)), _tptr(fel, torch.float32, self.shape, "fel"), C.byref(st)),
+              self.ctx._h)
+        return fel, st.as_dict()
+
+    def d8flowdir(self, fel, nodata=-3.0e38, dx=1.0, dy=1.0, out=None):
+        torch = self.torch
+        rows = self.ny_local + 2
+        dxc = np.ascontiguousarray(np.broadcast_to(np.asarray(dx, dtype=np.float64), (rows,)))
+        dyc = np.ascontiguousarray(np.broadcast_to(np.asarray(dy, dtype=np.float64), (rows,)))
+        p = out[0] if out is not None else self.empty(torch.int16)
+        sd8 = out[1] if out is not None else self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_d8flowdir_strip(self.ctx._h, self._cp, _tptr(fel, torch.float32, self.shape, "fel"), self.nx, self.ny_local,
+                                                float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                _tptr(p, torch.int16, self.shape, "p"), _tptr(sd8, torch.float32, self.shape, "sd8"), C.byref(st)),
+              self.ctx._h)
+        return p, sd8, st.as_dict()
+
+    def aread8(self, p, nodata=-32768, contcheck=True, out=None):
+        torch = self.torch
+        ad8 = out if out is not None else self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_aread8_strip(self.ctx._h, self._cp, _tptr(p, torch.int16, self.shape, "p"), self.nx, self.ny_local, int(nodata),
+                                             int(bool(contcheck)), _tptr(ad8, torch.float32, self.shape, "ad8"), C.byref(st)), self.ctx._h)
+        return ad8, st.as_dict()
