@@ -6,7 +6,9 @@
 One "step" = one pass of the three-stage pipeline over one synthetic fractal DEM that is already
 resident in HBM (generated on the device by tdx_synth_dem_dev).  Default workload = BASELINE.json
 configs[1]: 16384 x 16384 on one MI355X.  For N > 1 the driver launches one process per GPU
-(torch.distributed, backend nccl = RCCL); see DESIGN.md "Multi-GPU" for what each rank processes.
+(torch.distributed, backend nccl = RCCL) and ONE raster of 16384 columns x 16384*N rows is
+row-partitioned over the ranks (weak scaling: 16384 rows per GPU), halo rows and cross-strip
+dependencies exchanged through taudem_amd.distributed.StripComm; see DESIGN.md "Multi-GPU".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -79,33 +81,60 @@ def main():
     import torch.distributed as dist
 
     import taudem_amd as T
+    from taudem_amd.distributed import StripComm, StripPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("TDX_BENCH_BACKEND", "nccl")   # "gloo": several ranks may share one GPU (functional check only)
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
+        else:
+            dist.init_process_group(backend)
         world = dist.get_world_size()
     else:
+        dev = 0
         torch.cuda.set_device(0)
-    dev = local_rank if world > 1 else 0
     n = args.size
     ctx = T.Context(dev)
+    device = torch.device(f"cuda:{dev}")
 
-    # every rank owns one n x n DEM (weak scaling: per-GPU work fixed); different seeds per rank
-    dem = ctx.synth_dem(n, seed=args.seed + rank)
-    fel = torch.empty_like(dem)
-    p = torch.empty((n, n), dtype=torch.int16, device=dem.device)
-    sd8 = torch.empty_like(dem)
-    ad8 = torch.empty_like(dem)
+    if world == 1:
+        # one n x n raster on one GPU (BASELINE.json configs[1])
+        dem = ctx.synth_dem(n, seed=args.seed)
+        fel = torch.empty_like(dem)
+        p = torch.empty((n, n), dtype=torch.int16, device=device)
+        sd8 = torch.empty_like(dem)
+        ad8 = torch.empty_like(dem)
+        comm = None
 
-    def step():
-        _, s1 = ctx.pitremove(dem, -9999.0, out=fel, stats=True)
-        _, _, s2 = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, out=(p, sd8), stats=True)
-        _, s3 = ctx.aread8(p, -32768, out=ad8, stats=True)
-        return s1, s2, s3
+        def step():
+            _, s1 = ctx.pitremove(dem, -9999.0, out=fel, stats=True)
+            _, _, s2 = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, out=(p, sd8), stats=True)
+            _, s3 = ctx.aread8(p, -32768, out=ad8, stats=True)
+            return s1, s2, s3
+    else:
+        # ONE raster of n columns x (n * world) rows, row-partitioned like linearpart (src/linearpart.h:133-134):
+        # rank r owns rows [r*n, (r+1)*n) plus one halo row on each side; halo rows and cross-strip dependencies
+        # travel through StripComm (RCCL send/recv + all-reduce).  Per-GPU work is fixed: weak scaling.
+        comm = StripComm(n, device=dev)
+        pipe = StripPipeline(ctx, comm, n, n)
+        dem = pipe.empty(torch.float32)
+        ctx.synth_dem((n, n), seed=args.seed, x0=0, y0=rank * n, base_wavelength=T.synth_base_wavelength(n), out=dem[1:n + 1])
+        fel = pipe.empty(torch.float32)
+        p = pipe.empty(torch.int16)
+        sd8 = pipe.empty(torch.float32)
+        ad8 = pipe.empty(torch.float32)
+
+        def step():
+            _, s1 = pipe.pitremove(dem, -9999.0, out=fel)
+            _, _, s2 = pipe.d8flowdir(fel, -3.0e38, 30.0, 30.0, out=(p, sd8))
+            _, s3 = pipe.aread8(p, -32768, out=ad8)
+            return s1, s2, s3
 
     def barrier():
         if world > 1:
@@ -129,27 +158,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dem.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        cells = float(n) * float(n)
+        cells = float(n) * float(n)          # cells per GPU
         ms_per_step = elapsed / args.steps * 1e3
         value = world * cells * args.steps / elapsed / 1e6
-        stage_ms = {"pitremove": acc[0]["ms_total"] / 1.0, "d8flowdir": acc[1]["ms_total"], "aread8": acc[2]["ms_total"]}
-        # dominant kernel class over the timed region (HIP events on the library's stream)
+        stage_ms = {"pitremove": acc[0]["ms_total"], "d8flowdir": acc[1]["ms_total"], "aread8": acc[2]["ms_total"]}
+        # kernel classes over the timed region (HIP events on the library's own stream, rank 0's strip)
         klass = {}
         for a in acc:
             for name in ("stencil", "relax", "bfs", "flatdir", "accum", "misc"):
                 klass[name] = klass.get(name, 0.0) + a["ms_" + name]
                 klass["n_" + name] = klass.get("n_" + name, 0) + a["launches_" + name]
-        dom = max(("relax", "bfs", "flatdir", "accum", "stencil"), key=lambda k: klass[k])
-        stage = KCLASS_STAGE.get(dom, "d8flowdir")
-        launches = max(1, klass["n_" + dom])
-        avg_ms = klass[dom] / launches
+        # per-stage view of the dominant kernel class: the tile-relaxation kernel of pitremove ("relax") and of
+        # flat resolution ("bfs") are the same kernel template (tilek::relax_kernel) with different operators
+        per_stage = {"pitremove/relax_kernel<PitOp>": (acc[0]["ms_relax"], acc[0]["launches_relax"], "pitremove"),
+                     "d8flowdir/relax_kernel<LevelOp>": (acc[1]["ms_bfs"], acc[1]["launches_bfs"], "d8flowdir"),
+                     "aread8/tile kernels": (acc[2]["ms_stencil"], acc[2]["launches_stencil"], "aread8"),
+                     "aread8/big-cell walk": (acc[2]["ms_misc"], acc[2]["launches_misc"], "aread8")}
+        dom = max(per_stage, key=lambda k: per_stage[k][0])
+        dms, dlaunch, stage = per_stage[dom]
+        launches = max(1, dlaunch)
+        avg_ms = dms / launches
         bytes_per_launch = BYTES_PER_CELL[stage] * cells * args.steps / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the streaming 3x3 stencil that the 40 %-of-HBM target of BASELINE.json is about: D8 slope pass
+        slope_ms = acc[1]["ms_stencil"] / max(1, acc[1]["launches_stencil"])
+        slope_gbs = 10.0 * cells / (slope_ms * 1e-3) / 1e9 if slope_ms > 0 else 0.0
         out = {
             "metric": "Mcells/s (PitRemove->D8FlowDir->AreaD8 pipeline)",
             "value": value,
@@ -163,17 +201,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{n}x{n} synthetic fractal DEM per GPU, PitRemove->D8FlowDir->AreaD8 in HBM, bit-exact vs reference",
-                       "cells_per_gpu": int(cells), "multi_gpu": "independent DEM per rank (replicas)" if world > 1 else "single GPU"},
+            "config": {"workload": (f"{n}x{n} synthetic fractal DEM, PitRemove->D8FlowDir->AreaD8 in HBM, bit-exact vs reference" if world == 1 else
+                                    f"{n} columns x {n * world} rows synthetic fractal DEM row-partitioned over {world} GPUs ({n} rows each + halo rows), "
+                                    "PitRemove->D8FlowDir->AreaD8 in HBM"),
+                       "cells_per_gpu": int(cells), "total_cells": int(cells * world),
+                       "multi_gpu": ("row strips, halo rows + cross-strip dependencies over " + ("RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "kernel_class_ms_per_step": {k: klass[k] / args.steps for k in ("stencil", "relax", "bfs", "flatdir", "accum", "misc")},
-            "kernel_class_launches_per_step": {k: klass["n_" + k] / args.steps for k in ("stencil", "relax", "bfs", "flatdir", "accum")},
+            "kernel_class_launches_per_step": {k: klass["n_" + k] / args.steps for k in ("stencil", "relax", "bfs", "flatdir", "accum", "misc")},
             "roofline": {"bound": "hbm", "kernel": dom, "stage": stage, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "dependency-driven sweep: bound by (critical path in tiles) x launch, not by bandwidth (SURVEY.md 8d)"},
+            "roofline_streaming_stencil": {"kernel": "d8_slope_kernel", "algorithmic_bytes_per_cell": 10, "avg_launch_ms": slope_ms,
+                                           "achieved": slope_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": slope_gbs / HBM_PEAK_GBS},
             "flats": {"initial": acc[1]["flats_initial"], "left": acc[1]["flats_left"], "iterations": acc[1]["flat_iterations"],
-                      "levels_fall": acc[1]["levels_fall"], "levels_rise": acc[1]["levels_rise"], "pit_rounds": acc[0]["rounds"]},
+                      "levels_fall": acc[1]["levels_fall"], "levels_rise": acc[1]["levels_rise"], "pit_rounds": acc[0]["rounds"],
+                      "ad8_big_cells": acc[2]["cells_evaluated"], "ad8_outer_rounds": acc[2]["rounds"]},
         }
+        if comm is not None:
+            out["comm"] = {"exchanges_per_step": comm.exchanges / (args.steps + args.warmup), "allreduces_per_step": comm.allreduces / (args.steps + args.warmup)}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.seed)
         print(json.dumps(out))
