@@ -1,6 +1,6 @@
 // File-level tool functions: same argument lists, banners, timing blocks and error codes as the
 // reference's tool functions, with the compute part on the GPU.  One process drives one device here;
-// multi-GPU strips are orchestrated one process per GPU by taudem_amd/dist.py over RCCL.
+// multi-GPU strips are orchestrated one process per GPU by taudem_amd/distributed.py over RCCL.
 //   tdx_tool_pitremove       <- flood()     src/flood.cpp:50-526
 //   tdx_tool_d8flowdir       <- setdird8()  src/d8.cpp:181-355
 //   tdx_tool_aread8          <- aread8()    src/aread8.cpp:56-322
