@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
 // level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move
 struct LevelOp {
     using T = int;
+    static constexpr int kUniform = 0;
     int32_t* G;
     const uint8_t* M;
     static __device__ __forceinline__ int inf() { return 0x3fffffff; }
@@ -128,10 +129,17 @@ static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* 
         mr = b > mr ? b : mr;
         unv += u;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (ml > 0) atomicMax(out + 0, (unsigned long long)ml);
+    // one atomic per block and counter, and none when the running maximum already covers this block
+    __shared__ int s_ml[4], s_mr[4];
+    __shared__ unsigned s_unv[4];
+    const int w = int(threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) { s_ml[w] = ml; s_mr[w] = mr; s_unv[w] = unv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) { ml = s_ml[i] > ml ? s_ml[i] : ml; mr = s_mr[i] > mr ? s_mr[i] : mr; unv += s_unv[i]; }
+        if ((unsigned long long)ml > __hip_atomic_load(out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + 0, (unsigned long long)ml);
         if (unv) atomicAdd(out + 1, (unsigned long long)unv);
-        if (mr > 0) atomicMax(out + 2, (unsigned long long)mr);
+        if ((unsigned long long)mr > __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + 2, (unsigned long long)mr);
     }
 }
 

@@ -46,15 +46,16 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
 }
 
 // minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
+template <int NBR>   // 8, or 4 for the -4way flag (k = 1,3,5,7)
 struct PitOp {
     using T = float;
+    static constexpr int kUniform = NBR;
     const float* Z;
     float* W;
-    unsigned nbr_mask;   // 0xFF = 8 neighbours, 0x55 = the -4way flag (k = 1,3,5,7)
     static __device__ __forceinline__ float inf() { return FLT_MAX; }
     __device__ __forceinline__ float load(size_t idx) const { return W[idx]; }
     __device__ __forceinline__ void store(size_t idx, float v) const { W[idx] = v; }
-    __device__ __forceinline__ void cell(size_t idx, float& cst, unsigned& mask) const { cst = Z[idx]; mask = nbr_mask; }
+    __device__ __forceinline__ void cell(size_t idx, float& cst, unsigned& mask) const { cst = Z[idx]; mask = (NBR == 4) ? 0x55u : 0xFFu; }
     static __device__ __forceinline__ float apply(float z, float w, float m) { return (w > z) ? fmaxf(z, fminf(w, m)) : w; }
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
 };
@@ -92,9 +93,9 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     int64_t rounds = 0, launches = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
-        PitOp op{d_dem, d_fel, fourway ? 0x55u : 0xFFu};
         for (;;) {
-            rc = tile_relax_run(ctx, op, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
+            rc = fourway ? tile_relax_run(ctx, PitOp<4>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches)
+                         : tile_relax_run(ctx, PitOp<8>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
             if (rc != TDX_OK) return rc;
             outer++;
             if (!st.multi()) break;

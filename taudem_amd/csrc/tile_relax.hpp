@@ -70,6 +70,21 @@ __device__ __forceinline__ T masked_min(unsigned mask, T inf, T e, T ne, T n, T 
     return m;
 }
 
+// all 8 (or the 4 cardinal) neighbours, no per-cell mask: 4 / 2 three-input minima
+template <class T>
+__device__ __forceinline__ T uniform_min(bool fourway, T e, T ne, T n, T nw, T w, T sw, T s, T se) {
+    T m = e < n ? e : n;
+    const T m2 = w < s ? w : s;
+    m = m2 < m ? m2 : m;
+    if (!fourway) {
+        T d = ne < nw ? ne : nw;
+        const T d2 = sw < se ? sw : se;
+        d = d2 < d ? d2 : d;
+        m = d < m ? d : m;
+    }
+    return m;
+}
+
 // Op interface:
 //   using T;  (4 bytes)  static T inf();
 //   T load(size_t idx) const;            value of an in-grid cell
@@ -77,6 +92,7 @@ __device__ __forceinline__ T masked_min(unsigned mask, T inf, T e, T ne, T n, T 
 //   void cell(size_t idx, T& cst, unsigned& mask) const;   per-cell constant + neighbour mask (0 = never updated)
 //   static T apply(T cst, T own, T m);   new value (must be <= own)
 //   static bool settled(T cst, T v);     v can never decrease again
+//   static constexpr int kUniform;       0: per-cell masks; 8 / 4: every updatable cell looks at all 8 / the 4 cardinal neighbours
 //
 // In-tile schedule: alternating downward / upward sweeps in which a lane owns a 16-row column segment
 // (lanes of a wave = 64 consecutive columns, so LDS rows are read conflict-free).  The kernel is
@@ -90,32 +106,28 @@ __device__ __forceinline__ T masked_min(unsigned mask, T inf, T e, T ne, T n, T 
 
 __device__ __forceinline__ unsigned mask_at(const unsigned (&pk)[RPW / 4], int r) { return (pk[r >> 2] >> (8 * (r & 3))) & 0xFFu; }
 
+struct TileLds {   // LDS of one workgroup
+    int rim;
+    unsigned long long top[2][NWAVE], bot[2][NWAVE];   // columns whose first / last segment row changed, per wave
+    unsigned any[2][NWAVE];                            // per wave: did any cell move in this sweep
+    unsigned next;
+};
+
+constexpr int RES_CHANGED = 1 << 8;   // some cell of the tile moved (bits 0-7: which rim parts moved: N S W E NW NE SW SE)
+constexpr int RES_CAPPED = 1 << 9;    // stopped at max_sweeps before the tile-local fixed point
+
+// Relaxes tile `tile` to its local fixed point (or max_sweeps) and writes changed cells back.  Returns the
+// RES_* mask, identical in every thread.  All threads of the workgroup must call it.
 template <class Op>
-__global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list,
-                                                    unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_next,
-                                                    unsigned long long* __restrict__ dbg) {
+__device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int tile, typename Op::T* sV, TileLds& L, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
-    static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
-    __shared__ T sV[LH * LP];
-    __shared__ int sRim;
-    __shared__ unsigned long long sTop[2][NWAVE], sBot[2][NWAVE];
-    __shared__ unsigned sAny[2][NWAVE];   // per wave: did any cell move in this sweep   // columns whose first / last segment row changed, per wave
-    __shared__ unsigned sNext;
-    const unsigned nact = unsigned(count[0]);
-    unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
     const int tid = threadIdx.x;
     const int lx = tid & 63;
     const int wv = tid >> 6;
     const int ry0 = wv * RPW;
-    for (;;) {
-        if (tid == 0) sNext = unsigned(atomicAdd(cursor, 1ull));
-        __syncthreads();
-        const unsigned it = sNext;
-        if (it >= nact) break;
-        const int tile = int(list[it]);
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int x0 = tx * TS, y0 = ty * TS;
-        if (tid == 0) sRim = 0;
+        if (tid == 0) L.rim = 0;
         for (int e = tid; e < LH * LH; e += NTHR) {
             const int ly = e / LH, lxx = e - ly * LH;
             const int hx = x0 + lxx - 1, hy = y0 + ly - 1;
@@ -161,8 +173,11 @@ __global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const
                     if (look) {
                         const int c = (ry0 + r + 1) * LP + lx + 1;
                         const T own = sV[c];
-                        const T m = masked_min<T>(mask_at(mk, r), Op::inf(), sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1],
-                                                  sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
+                        T m;
+                        if (Op::kUniform == 4) m = uniform_min<T>(true, sV[c + 1], Op::inf(), sV[c - LP], Op::inf(), sV[c - 1], Op::inf(), sV[c + LP], Op::inf());
+                        else if (Op::kUniform == 8) m = uniform_min<T>(false, sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1], sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
+                        else m = masked_min<T>(mask_at(mk, r), Op::inf(), sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1],
+                                               sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
                         const T wn = Op::apply(cst[r], own, m);
                         if (wn != own) {
                             sV[c] = wn;
@@ -182,8 +197,11 @@ __global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const
                     if (look) {
                         const int c = (ry0 + r + 1) * LP + lx + 1;
                         const T own = sV[c];
-                        const T m = masked_min<T>(mask_at(mk, r), Op::inf(), sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1],
-                                                  sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
+                        T m;
+                        if (Op::kUniform == 4) m = uniform_min<T>(true, sV[c + 1], Op::inf(), sV[c - LP], Op::inf(), sV[c - 1], Op::inf(), sV[c + LP], Op::inf());
+                        else if (Op::kUniform == 8) m = uniform_min<T>(false, sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1], sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
+                        else m = masked_min<T>(mask_at(mk, r), Op::inf(), sV[c + 1], sV[c - LP + 1], sV[c - LP], sV[c - LP - 1], sV[c - 1],
+                                               sV[c + LP - 1], sV[c + LP], sV[c + LP + 1]);
                         const T wn = Op::apply(cst[r], own, m);
                         if (wn != own) {
                             sV[c] = wn;
@@ -202,18 +220,18 @@ __global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const
             unsigned nd = (h | (h << 1) | (h >> 1)) & ((1u << RPW) - 1u);
             const unsigned long long btop = __ballot((chg & 1u) != 0u), bbot = __ballot((chg & (1u << (RPW - 1))) != 0u);
             const unsigned long long bany = __ballot(chg != 0u);
-            if (lx == 0) { sTop[cur][wv] = btop; sBot[cur][wv] = bbot; sAny[cur][wv] = bany != 0ull; }
+            if (lx == 0) { L.top[cur][wv] = btop; L.bot[cur][wv] = bbot; L.any[cur][wv] = bany != 0ull; }
             __syncthreads();   // the only barrier of a sweep: everything a wave needs from the others is read after it
             unsigned any = 0;
 #pragma unroll
-            for (int w = 0; w < NWAVE; w++) any |= sAny[cur][w];
+            for (int w = 0; w < NWAVE; w++) any |= L.any[cur][w];
             if (any) any_change = true;
             if (!any || iter + 1 >= g.max_sweeps) {
                 capped = any != 0;
                 if (dbg && tid == 0) { atomicAdd(dbg, (unsigned long long)(iter + 1)); atomicAdd(dbg + 1, 1ull); }
                 break;
             }
-            const unsigned long long above = wv > 0 ? sBot[cur][wv - 1] : 0ull, below = wv < NWAVE - 1 ? sTop[cur][wv + 1] : 0ull;
+            const unsigned long long above = wv > 0 ? L.bot[cur][wv - 1] : 0ull, below = wv < NWAVE - 1 ? L.top[cur][wv + 1] : 0ull;
             if ((lx ? (above >> (lx - 1)) : (above << 1)) & 7ull) nd |= 1u;
             if ((lx ? (below >> (lx - 1)) : (below << 1)) & 7ull) nd |= 1u << (RPW - 1);
             dirty = nd & live;
@@ -237,18 +255,180 @@ __global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const
                     if (bot && rig) rim |= 128;
                 }
             }
-            if (rim) atomicOr(&sRim, rim);
-            __syncthreads();
-            if (tid < 8 && ((sRim >> tid) & 1)) {
+            if (rim) atomicOr(&L.rim, rim);
+        }
+        __syncthreads();
+        const int res = (any_change ? (L.rim | RES_CHANGED) : 0) | (capped ? RES_CAPPED : 0);
+        __syncthreads();   // L.rim and the value tile are reused by the next tile
+        return res;
+}
+
+__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags) {
+    const int tid = threadIdx.x;
+    if (tid < 8 && ((res >> tid) & 1)) {
+        const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+        const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
+        const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+        const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
+        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) flags[nty * g.tiles_x + ntx] = 1u;
+    }
+    if (tid == 8 && (res & RES_CAPPED)) flags[tile] = 1u;   // not yet at its fixed point: run again
+}
+
+// ---- schedule 1: rounds.  Workgroups pull the tiles of the current round's list from a device cursor.
+template <class Op>
+__global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list,
+                                                    unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_next,
+                                                    unsigned long long* __restrict__ dbg) {
+    using T = typename Op::T;
+    static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
+    __shared__ T sV[LH * LP];
+    __shared__ TileLds L;
+    const unsigned nact = unsigned(count[0]);
+    unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
+    for (;;) {
+        if (threadIdx.x == 0) L.next = unsigned(atomicAdd(cursor, 1ull));
+        __syncthreads();
+        const unsigned it = L.next;
+        if (it >= nact) break;
+        const int tile = int(list[it]);
+        const int res = relax_tile(op, g, tile, sV, L, dbg);
+        if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next);
+    }
+}
+
+// ---- schedule 2: asynchronous worklist.  ONE launch: resident workgroups pop tiles from a device queue, relax
+// them, and push the neighbours whose halo they changed - a dependency front advances at the pace of single
+// tiles instead of one tile per launch.  Hand-off between workgroups follows the agent-scope release / acquire
+// recipe of cdna_hip_programming.md (Guideline 16): every wave drains its stores, barrier, lane 0 release-fences
+// and only then publishes through atomics; the consumer acquires (L1 invalidate) after popping, before loading.
+// Tile state machine (atomic CAS, so that every state change is an RMW on one word):
+//   0 idle -> 1 queued -> 2 running -> 0;   a neighbour that changes a running tile's halo turns 2 into 3
+//   (running, must run again) and the worker re-queues the tile (3 -> 1) when it finishes.
+struct AsyncCtl {
+    uint32_t* ring; uint32_t mask;          // ticket ring of tile+1 (0 = empty slot); size mask+1 > number of tiles
+    unsigned long long* head; unsigned long long* tail;
+    int* pending;                            // tiles queued or running
+    uint32_t* state;
+    unsigned* error;                         // a bounded spin gave up: the host falls back to schedule 1
+    unsigned spin_limit;                     // polls before a spin gives up
+    unsigned long long* trace;               // debug counters (may be null): pops, pushes, activations, cas retries
+};
+
+#define TDX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ void q_push(const AsyncCtl& c, uint32_t tile) {
+    const unsigned long long t = __hip_atomic_fetch_add(c.tail, 1ull, TDX_AGENT);
+    uint32_t* slot = c.ring + (t & c.mask);
+    for (unsigned spins = 0; __hip_atomic_load(slot, TDX_AGENT) != 0u; spins++) {   // previous lap not consumed yet
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > c.spin_limit) { __hip_atomic_store(c.error, 2u, TDX_AGENT); return; }
+    }
+    __hip_atomic_store(slot, tile + 1u, TDX_AGENT);
+    if (c.trace) atomicAdd(c.trace + 1, 1ull);
+}
+__device__ __forceinline__ int q_pop(const AsyncCtl& c) {
+    const unsigned long long h = __hip_atomic_fetch_add(c.head, 1ull, TDX_AGENT);
+    uint32_t* slot = c.ring + (h & c.mask);
+    for (unsigned spins = 0;; spins++) {
+        const uint32_t v = __hip_atomic_load(slot, TDX_AGENT);
+        if (v != 0u) {
+            __hip_atomic_store(slot, 0u, TDX_AGENT);
+            if (c.trace) atomicAdd(c.trace + 0, 1ull);
+            return int(v - 1u);
+        }
+        if (__hip_atomic_load(c.pending, TDX_AGENT) <= 0) return -1;   // nothing queued or running: no push can follow
+        if (__hip_atomic_load(c.error, TDX_AGENT) != 0u) return -1;
+        __builtin_amdgcn_s_sleep(8);
+        if (spins > c.spin_limit) { __hip_atomic_store(c.error, 1u, TDX_AGENT); return -1; }
+    }
+}
+__device__ __forceinline__ void q_activate(const AsyncCtl& c, uint32_t tile) {
+    if (c.trace) atomicAdd(c.trace + 2, 1ull);
+    for (unsigned tries = 0;; tries++) {
+        if (tries > c.spin_limit) { __hip_atomic_store(c.error, 3u, TDX_AGENT); return; }
+        const uint32_t s = __hip_atomic_load(c.state + tile, TDX_AGENT);
+        const uint32_t want = (s == 0u) ? 1u : (s == 2u ? 3u : s);
+        uint32_t expect = s;
+        if (__hip_atomic_compare_exchange_strong(c.state + tile, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (s == 0u) { __hip_atomic_fetch_add(c.pending, 1, TDX_AGENT); q_push(c, tile); }
+            return;
+        }
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(NTHR, 5) void relax_async_kernel(Op op, TileGeom g, AsyncCtl c, unsigned long long* __restrict__ dbg) {
+    using T = typename Op::T;
+    __shared__ T sV[LH * LP];
+    __shared__ TileLds L;
+    __shared__ int sTile;
+    const int tid = threadIdx.x;
+    for (unsigned served = 0;; served++) {
+        if (tid == 0) {
+            int t = q_pop(c);
+            if (served > c.spin_limit) { __hip_atomic_store(c.error, 5u, TDX_AGENT); t = -1; }
+            if (t >= 0) {
+                __hip_atomic_exchange(c.state + t, 2u, TDX_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale L1 lines before the tile is loaded
+            }
+            sTile = t;
+        }
+        __syncthreads();
+        const int tile = sTile;
+        if (tile < 0) break;
+        const int res = relax_tile(op, g, tile, sV, L, dbg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-back ...
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ... then one lane writes the L2 back
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (res & RES_CHANGED) {
                 const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
                 const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
-                const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
-                if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) flags_next[nty * g.tiles_x + ntx] = 1u;
+                const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+                for (int k = 0; k < 8; k++) {
+                    if (!((res >> k) & 1)) continue;
+                    const int ntx = tx + ddx[k], nty = ty + ddy[k];
+                    if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) q_activate(c, uint32_t(nty * g.tiles_x + ntx));
+                }
             }
-            if (tid == 8 && capped) flags_next[tile] = 1u;   // not yet at its fixed point: run again next round
+            for (unsigned tries = 0;; tries++) {   // leave the running state
+                if (tries > c.spin_limit) { __hip_atomic_store(c.error, 4u, TDX_AGENT); break; }
+                const uint32_t s = __hip_atomic_load(c.state + tile, TDX_AGENT);
+                const bool again = (s == 3u) || (res & RES_CAPPED);
+                uint32_t expect = s;
+                if (__hip_atomic_compare_exchange_strong(c.state + tile, &expect, again ? 1u : 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (again) q_push(c, uint32_t(tile));
+                    else __hip_atomic_fetch_sub(c.pending, 1, TDX_AGENT);
+                    break;
+                }
+            }
         }
-        __syncthreads();   // LDS is reused by the next listed tile
     }
+}
+
+// activation flags -> queue: ring[i] = tile + 1, state = queued; clears the flags; count must be zero on entry
+static __global__ __launch_bounds__(256) void async_fill_kernel(uint32_t* __restrict__ flags, int ntiles, AsyncCtl c, unsigned long long* __restrict__ count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bool act = false;
+    if (t < ntiles) {
+        act = flags[t] != 0u;
+        if (act) flags[t] = 0u;
+        c.state[t] = act ? 1u : 0u;
+    }
+    const unsigned long long ballot = __ballot(act);
+    if (ballot == 0) return;
+    const int lane = int(threadIdx.x & 63), leader = __ffsll((long long)ballot) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(ballot));
+    base = __shfl(base, leader, 64);
+    if (act) c.ring[(base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull))) & c.mask] = uint32_t(t) + 1u;
+}
+static __global__ void async_start_kernel(AsyncCtl c, const unsigned long long* __restrict__ count) {
+    *c.head = 0ull;
+    *c.tail = *count;
+    *c.pending = int(*count);
+    *c.error = 0u;
 }
 
 // activation flags -> compact tile list; clears the flags; count must be zero on entry
@@ -276,51 +456,91 @@ struct Sched {
 
 }  // namespace tilek
 
-// Runs rounds until no tile is active.  `flags` must hold the initially active tiles.
+// Runs the relaxation until no tile is active.  `flags` must hold the initially active tiles.
+// Default schedule: rounds.  TDX_RELAX_ASYNC=1 selects the asynchronous worklist (one launch); a worklist that gave
+// up on a bounded spin continues with rounds (values only ever decrease, so restarting from "all tiles active" is safe).
 template <class Op>
 static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sched sc, int64_t* rounds_out, int64_t* launches_out) {
     using namespace tilek;
     hipStream_t s = ctx->stream;
     const int ntiles = g.tiles_x * g.tiles_y;
-    const unsigned grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
     const unsigned cgrid = tdx_blocks_for(size_t(ntiles), 256);
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
-    int r = 0, batch = 4;
-    int64_t rounds = 0, launches = 0;
-    static const bool debug = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
+    static const bool debug = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // schedule statistics on stderr
+    // The worklist schedule is opt-in (TDX_RELAX_ASYNC=1): measured on MI355X it does not beat the round schedule
+    // (the relaxation is bound by VALU work per tile, not by the number of launches) - see DESIGN.md 4.2.
+    static const bool force_rounds = getenv("TDX_RELAX_ASYNC") == nullptr;
     unsigned long long* dbg = nullptr;
     if (debug) {
-        fprintf(stderr, "tile_relax_run(%d tiles):", ntiles);
         dbg = reinterpret_cast<unsigned long long*>(ctx->d_mail) + 32;
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 16, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 64, s));
     }
-    for (;;) {
-        if (r + batch > COUNT_RING) {
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
-            r = 0;
-        }
-        for (int b = 0; b < batch; b++) {
-            hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, sc.list, sc.counts + r + b);
-            hipLaunchKernelGGL((relax_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, sc.list, sc.counts + r + b, sc.flags, dbg);
-        }
-        launches += batch;
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    int64_t rounds = 0, launches = 0;
+    bool need_rounds = force_rounds;
+    if (!force_rounds) {
+        uint32_t cap = 1;
+        while (cap <= uint32_t(ntiles)) cap <<= 1;
+        uint32_t* ring = static_cast<uint32_t*>(ctx->scratch(TDX_S_Q, size_t(cap) * 4));
+        if (!ring) return TDX_ERR_NOMEM;
+        // control words live at the start of the counts area (re-zeroed below if the round schedule is needed)
+        AsyncCtl c;
+        c.ring = ring; c.mask = cap - 1u;
+        c.head = sc.counts + 0; c.tail = sc.counts + 1;
+        c.pending = reinterpret_cast<int*>(sc.counts + 2);
+        c.error = reinterpret_cast<unsigned*>(sc.counts + 3);
+        c.state = sc.list;   // the round schedule's tile list doubles as the per-tile state
+        c.spin_limit = getenv("TDX_ASYNC_SPIN") ? unsigned(atol(getenv("TDX_ASYNC_SPIN"))) : (1u << 21);
+        c.trace = debug ? dbg + 2 : nullptr;
+        unsigned long long* count = sc.counts + 4;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, 8 * sizeof(unsigned long long), s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(ring, 0, size_t(cap) * 4, s));
+        hipLaunchKernelGGL(async_fill_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, c, count);
+        hipLaunchKernelGGL(async_start_kernel, dim3(1), dim3(1), 0, s, c, count);
+        const unsigned grid = unsigned(std::min(ntiles, 5 * ctx->num_cus));
+        hipLaunchKernelGGL((relax_async_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, c, dbg);
+        launches += 1;
+        rounds += 1;
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, sc.counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        bool done = false;
-        for (int b = 0; b < batch; b++) {
-            if (ctx->h_mail[b] == 0) { done = true; break; }
-            if (debug) fprintf(stderr, " %llu", (unsigned long long)ctx->h_mail[b]);
-            rounds++;
+        const unsigned err = unsigned(ctx->h_mail[3] & 0xffffffffull);
+        if (err) {
+            fprintf(stderr, "taudem_amd: asynchronous tile worklist gave up (code %u, head %llu tail %llu pending %d); continuing with the round schedule\n", err,
+                    (unsigned long long)ctx->h_mail[0], (unsigned long long)ctx->h_mail[1], int(ctx->h_mail[2] & 0xffffffffull));
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, 1u, size_t(ntiles));
+            need_rounds = true;
         }
-        if (done) break;
-        r += batch;
-        if (batch < 64) batch *= 2;
+    }
+    if (need_rounds) {
+        const unsigned grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
+        int r = 0, batch = 4;
+        for (;;) {
+            if (r + batch > COUNT_RING) {
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
+                r = 0;
+            }
+            for (int b = 0; b < batch; b++) {
+                hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, sc.list, sc.counts + r + b);
+                hipLaunchKernelGGL((relax_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, sc.list, sc.counts + r + b, sc.flags, dbg);
+            }
+            launches += batch;
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            bool done = false;
+            for (int b = 0; b < batch; b++) {
+                if (ctx->h_mail[b] == 0) { done = true; break; }
+                rounds++;
+            }
+            if (done) break;
+            r += batch;
+            if (batch < 64) batch *= 2;
+        }
     }
     if (debug) {
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, dbg, 16, hipMemcpyDeviceToHost, s));
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, dbg, 48, hipMemcpyDeviceToHost, s));
         TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        fprintf(stderr, "\n   -> %lld rounds, %llu tile activations, %llu sweeps\n", (long long)rounds, (unsigned long long)ctx->h_mail[1],
-                (unsigned long long)ctx->h_mail[0]);
+        fprintf(stderr, "tile_relax_run(%d tiles, %s): %lld rounds, %llu tile activations, %llu sweeps; queue pops %llu pushes %llu activations %llu\n", ntiles,
+                need_rounds ? "rounds" : "worklist", (long long)rounds, (unsigned long long)ctx->h_mail[1], (unsigned long long)ctx->h_mail[0],
+                (unsigned long long)ctx->h_mail[2], (unsigned long long)ctx->h_mail[3], (unsigned long long)ctx->h_mail[4]);
     }
     if (rounds_out) *rounds_out += rounds;
     if (launches_out) *launches_out += launches;

@@ -15,7 +15,7 @@ BIN = os.path.join(ROOT, "taudem_amd", "bin")
 
 
 def run(tool, *args):
-    r = subprocess.run([os.path.join(BIN, tool), *args], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([os.path.join(BIN, tool), *args], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
 
