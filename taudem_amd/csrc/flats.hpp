@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
             fmask[c] = uint8_t(low ? 0u : fm);     // a level-1 cell can never improve
             rmask[c] = uint8_t(higher ? 0u : rm);
             const unsigned y = unsigned(c / size_t(nx)), x = unsigned(c - size_t(y) * size_t(nx));
-            tile_flags[(y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS] = 1u;
+            tile_flags[(y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS] = tilek::FLAG_FULL;
         }
     }
 }
@@ -96,9 +96,13 @@ struct LevelOp {
     int32_t* G;
     const uint8_t* M;
     static __device__ __forceinline__ int inf() { return 0x3fffffff; }
-    __device__ __forceinline__ int load(size_t idx) const { const int g = G[idx]; return g > 0 ? g : inf(); }
+    using Raw = int;
+    using CellRaw = uint8_t;
+    __device__ __forceinline__ int load_raw(size_t idx) const { return G[idx]; }
+    static __device__ __forceinline__ int decode(int g) { return g > 0 ? g : inf(); }
     __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = v; }
-    __device__ __forceinline__ void cell(size_t idx, int& cst, unsigned& mask) const { cst = 0; mask = M[idx]; }
+    __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
+    static __device__ __forceinline__ void cell_decode(uint8_t m, int& cst, unsigned& mask) { cst = 0; mask = m; }
     static __device__ __forceinline__ int apply(int, int own, int m) { return (m + 1 < own) ? m + 1 : own; }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
 };

@@ -53,9 +53,13 @@ struct PitOp {
     const float* Z;
     float* W;
     static __device__ __forceinline__ float inf() { return FLT_MAX; }
-    __device__ __forceinline__ float load(size_t idx) const { return W[idx]; }
+    using Raw = float;
+    using CellRaw = float;
+    __device__ __forceinline__ float load_raw(size_t idx) const { return W[idx]; }
+    static __device__ __forceinline__ float decode(float v) { return v; }
     __device__ __forceinline__ void store(size_t idx, float v) const { W[idx] = v; }
-    __device__ __forceinline__ void cell(size_t idx, float& cst, unsigned& mask) const { cst = Z[idx]; mask = (NBR == 4) ? 0x55u : 0xFFu; }
+    __device__ __forceinline__ float cell_raw(size_t idx) const { return Z[idx]; }
+    static __device__ __forceinline__ void cell_decode(float z, float& cst, unsigned& mask) { cst = z; mask = (NBR == 4) ? 0x55u : 0xFFu; }
     static __device__ __forceinline__ float apply(float z, float w, float m) { return (w > z) ? fmaxf(z, fminf(w, m)) : w; }
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
 };
@@ -89,7 +93,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // seed surface halo rows
     if (rc != TDX_OK) return rc;
     // round 0: every tile is active
-    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, 1u, size_t(ntiles));
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
     int64_t rounds = 0, launches = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);

@@ -47,8 +47,8 @@ __global__ void merge_row_kernel(T* halo, const T* recv, int nx, unsigned long l
             if (tile_flags) {
                 const int t0 = (x > 0 ? x - 1 : 0) / 64, t1 = (x + 1 < nx ? x + 1 : nx - 1) / 64;
                 for (int t = t0; t <= t1; t++) {
-                    tile_flags[tr0 * tiles_x + t] = 1u;
-                    tile_flags[tr1 * tiles_x + t] = 1u;
+                    tile_flags[tr0 * tiles_x + t] = 2u;   // tilek::FLAG_FULL: a row INSIDE the tile's area changed
+                    tile_flags[tr1 * tiles_x + t] = 2u;
                 }
             }
         }

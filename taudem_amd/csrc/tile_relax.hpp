@@ -87,9 +87,11 @@ __device__ __forceinline__ T uniform_min(bool fourway, T e, T ne, T n, T nw, T w
 
 // Op interface:
 //   using T;  (4 bytes)  static T inf();
-//   T load(size_t idx) const;            value of an in-grid cell
+//   Raw load_raw(size_t idx) const; static T decode(Raw);   value of an in-grid cell (load and decode are split so
+//                                        that all loads of a tile can be issued back to back)
 //   void store(size_t idx, T v) const;   changed cell
-//   void cell(size_t idx, T& cst, unsigned& mask) const;   per-cell constant + neighbour mask (0 = never updated)
+//   CellRaw cell_raw(size_t idx) const; static void cell_decode(CellRaw, T& cst, unsigned& mask);
+//                                        per-cell constant + neighbour mask (0 = never updated)
 //   static T apply(T cst, T own, T m);   new value (must be <= own)
 //   static bool settled(T cst, T v);     v can never decrease again
 //   static constexpr int kUniform;       0: per-cell masks; 8 / 4: every updatable cell looks at all 8 / the 4 cardinal neighbours
@@ -113,13 +115,20 @@ struct TileLds {   // LDS of one workgroup
     unsigned next;
 };
 
+// Activation flag of a tile.  FLAG_HALO: only cells of its halo ring moved since the tile last reached its local
+// fixed point, so only its perimeter cells need a first look (interior cells see nothing but cells of the tile
+// itself, which nobody else writes).  FLAG_FULL: look at every cell (first activation, capped activation, or a
+// strip halo ROW inside the tile's area was rewritten by the exchange).
+constexpr uint32_t FLAG_HALO = 1u, FLAG_FULL = 2u;
+constexpr uint32_t LIST_FULL = 0x80000000u;   // top bit of a tile-list entry: FLAG_FULL
+
 constexpr int RES_CHANGED = 1 << 8;   // some cell of the tile moved (bits 0-7: which rim parts moved: N S W E NW NE SW SE)
 constexpr int RES_CAPPED = 1 << 9;    // stopped at max_sweeps before the tile-local fixed point
 
 // Relaxes tile `tile` to its local fixed point (or max_sweeps) and writes changed cells back.  Returns the
 // RES_* mask, identical in every thread.  All threads of the workgroup must call it.
 template <class Op>
-__device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int tile, typename Op::T* sV, TileLds& L, unsigned long long* __restrict__ dbg) {
+__device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int tile, bool full, typename Op::T* sV, TileLds& L, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
     const int tid = threadIdx.x;
     const int lx = tid & 63;
@@ -127,15 +136,52 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
     const int ry0 = wv * RPW;
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int x0 = tx * TS, y0 = ty * TS;
+        const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
         if (tid == 0) L.rim = 0;
-        for (int e = tid; e < LH * LH; e += NTHR) {
-            const int ly = e / LH, lxx = e - ly * LH;
-            const int hx = x0 + lxx - 1, hy = y0 + ly - 1;
-            T v = Op::inf();
-            if (hx >= 0 && hx < g.nx && hy >= 0 && hy < g.ny) v = op.load(size_t(hy) * size_t(g.nx) + size_t(hx));
-            sV[ly * LP + lxx] = v;
-        }
+        // Stage the value tile + halo ring.  All global loads are issued before the first LDS store (ONE memory
+        // latency per tile) and addresses advance by one row per step (the load phase is VALU-issue bound:
+        // 34 loads per lane, so every instruction of address arithmetic counts).  Lane (lx, wv) loads column
+        // x0 + lx of the rows wv, wv + 4, ... of the 66-row window; lanes 0..131 also load one cell of the two
+        // halo columns.
+        // The loads are UNCONDITIONAL (addresses clamped into the raster, validity applied afterwards): a load inside a
+        // divergent branch gets its own basic block and the compiler waits for it before the next one is issued.
+        constexpr int NROWL = (LH + NWAVE - 1) / NWAVE;   // 17 row steps
         const int gx = x0 + lx;
+        const bool col_ok = gx < g.nx;
+        const int gxc = col_ok ? gx : g.nx - 1;
+        const long long row_pitch = (long long)g.nx;
+        typename Op::Raw stage[NROWL], stage_side;
+        unsigned stage_ok = 0;   // bit i: stage[i] is a raster cell
+        bool side_ok = false;
+        {
+            int hy = y0 - 1 + wv;
+#pragma unroll
+            for (int i = 0; i < NROWL; i++) {
+                const bool ok = col_ok && hy >= 0 && hy < g.ny && (wv + i * NWAVE < LH);
+                const int hyc = hy < 0 ? 0 : (hy >= g.ny ? g.ny - 1 : hy);
+                stage[i] = op.load_raw(size_t((long long)hyc * row_pitch + gxc));
+                if (ok) stage_ok |= 1u << i;
+                hy += NWAVE;
+            }
+            {
+                const int row = (tid >> 1) < LH ? (tid >> 1) : LH - 1, right = tid & 1;
+                const int sx = right ? x0 + TS : x0 - 1, sy = y0 - 1 + row;
+                side_ok = tid < 2 * LH && sx >= 0 && sx < g.nx && sy >= 0 && sy < g.ny;
+                const int sxc = sx < 0 ? 0 : (sx >= g.nx ? g.nx - 1 : sx), syc = sy < 0 ? 0 : (sy >= g.ny ? g.ny - 1 : sy);
+                stage_side = op.load_raw(size_t((long long)syc * row_pitch + sxc));
+            }
+        }
+        const unsigned long long tcA = dbg ? __builtin_readcyclecounter() : 0ull;
+        typename Op::CellRaw craw[RPW];
+        {
+            int gy = y0 + ry0;
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const int gyc = gy >= g.ny ? g.ny - 1 : gy;
+                craw[r] = op.cell_raw(size_t((long long)gyc * row_pitch + gxc));
+                gy++;
+            }
+        }
         T cst[RPW];
         unsigned mk[RPW / 4] = {};
         unsigned live = 0;
@@ -144,19 +190,32 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
             const int gy = y0 + ry0 + r;
             T c = Op::inf();
             unsigned m = 0;
-            if (gx < g.nx && gy >= g.y_own0 && gy < g.y_own1) op.cell(size_t(gy) * size_t(g.nx) + size_t(gx), c, m);
+            if (col_ok && gy >= g.y_own0 && gy < g.y_own1) Op::cell_decode(craw[r], c, m);
             cst[r] = c;
             mk[r >> 2] |= (m & 0xFFu) << (8 * (r & 3));
             if (m) live |= 1u << r;
         }
+        const unsigned long long tcB = dbg ? __builtin_readcyclecounter() : 0ull;
+#pragma unroll
+        for (int i = 0; i < NROWL; i++)
+            if (wv + i * NWAVE < LH) sV[(wv + i * NWAVE) * LP + lx + 1] = ((stage_ok >> i) & 1u) ? Op::decode(stage[i]) : Op::inf();
+        if (tid < 2 * LH) sV[(tid >> 1) * LP + ((tid & 1) ? LH - 1 : 0)] = side_ok ? Op::decode(stage_side) : Op::inf();
+        const unsigned long long tcC = dbg ? __builtin_readcyclecounter() : 0ull;
         __syncthreads();
+        const unsigned long long tcD = dbg ? __builtin_readcyclecounter() : 0ull;
+        if (dbg && tid == 0) { atomicAdd(dbg + 9, tcA - tc0); atomicAdd(dbg + 10, tcB - tcA); atomicAdd(dbg + 11, tcC - tcB); atomicAdd(dbg + 12, tcD - tcC); }
 #pragma unroll
         for (int r = 0; r < RPW; r++)
             if (Op::settled(cst[r], sV[(ry0 + r + 1) * LP + lx + 1])) live &= ~(1u << r);
         unsigned moved = 0;   // rows of this lane that changed during this activation
 
+        const unsigned long long tc1 = dbg ? __builtin_readcyclecounter() : 0ull;
         bool any_change = false, capped = false;
-        unsigned dirty = live;   // the halo may have moved since the last activation: evaluate everything once
+        // first look: everything, or (FLAG_HALO) only the cells that touch the halo ring
+        unsigned perim = (lx == 0 || lx == TS - 1) ? 0xFFFFu : 0u;
+        if (wv == 0) perim |= 1u;
+        if (wv == NWAVE - 1) perim |= 1u << (RPW - 1);
+        unsigned dirty = full ? live : (live & perim);
         for (int iter = 0;; iter++) {
             unsigned chg = 0;
             const int cur = iter & 1;
@@ -236,6 +295,7 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
             if ((lx ? (below >> (lx - 1)) : (below << 1)) & 7ull) nd |= 1u << (RPW - 1);
             dirty = nd & live;
         }
+        const unsigned long long tc2 = dbg ? __builtin_readcyclecounter() : 0ull;
         if (any_change) {   // uniform
             int rim = 0;
 #pragma unroll
@@ -258,6 +318,10 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
             if (rim) atomicOr(&L.rim, rim);
         }
         __syncthreads();
+        if (dbg && tid == 0) {   // phase cycles: load, sweeps, write-back
+            const unsigned long long tc3 = __builtin_readcyclecounter();
+            atomicAdd(dbg + 6, tc1 - tc0); atomicAdd(dbg + 7, tc2 - tc1); atomicAdd(dbg + 8, tc3 - tc2);
+        }
         const int res = (any_change ? (L.rim | RES_CHANGED) : 0) | (capped ? RES_CAPPED : 0);
         __syncthreads();   // L.rim and the value tile are reused by the next tile
         return res;
@@ -270,14 +334,14 @@ __device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeo
         const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
-        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) flags[nty * g.tiles_x + ntx] = 1u;
+        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) atomicMax(&flags[nty * g.tiles_x + ntx], FLAG_HALO);
     }
-    if (tid == 8 && (res & RES_CAPPED)) flags[tile] = 1u;   // not yet at its fixed point: run again
+    if (tid == 8 && (res & RES_CAPPED)) atomicMax(&flags[tile], FLAG_FULL);   // not yet at its fixed point: run again, everything dirty
 }
 
 // ---- schedule 1: rounds.  Workgroups pull the tiles of the current round's list from a device cursor.
 template <class Op>
-__global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list,
                                                     unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_next,
                                                     unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
@@ -291,8 +355,9 @@ __global__ __launch_bounds__(NTHR, 5) void relax_kernel(Op op, TileGeom g, const
         __syncthreads();
         const unsigned it = L.next;
         if (it >= nact) break;
-        const int tile = int(list[it]);
-        const int res = relax_tile(op, g, tile, sV, L, dbg);
+        const uint32_t entry = list[it];
+        const int tile = int(entry & ~LIST_FULL);
+        const int res = relax_tile(op, g, tile, (entry & LIST_FULL) != 0u, sV, L, dbg);
         if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next);
     }
 }
@@ -357,7 +422,7 @@ __device__ __forceinline__ void q_activate(const AsyncCtl& c, uint32_t tile) {
 }
 
 template <class Op>
-__global__ __launch_bounds__(NTHR, 5) void relax_async_kernel(Op op, TileGeom g, AsyncCtl c, unsigned long long* __restrict__ dbg) {
+__global__ __launch_bounds__(NTHR, 4) void relax_async_kernel(Op op, TileGeom g, AsyncCtl c, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
     __shared__ T sV[LH * LP];
     __shared__ TileLds L;
@@ -376,7 +441,7 @@ __global__ __launch_bounds__(NTHR, 5) void relax_async_kernel(Op op, TileGeom g,
         __syncthreads();
         const int tile = sTile;
         if (tile < 0) break;
-        const int res = relax_tile(op, g, tile, sV, L, dbg);
+        const int res = relax_tile(op, g, tile, true, sV, L, dbg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-back ...
         __syncthreads();
         if (tid == 0) {
@@ -435,12 +500,12 @@ static __global__ void async_start_kernel(AsyncCtl c, const unsigned long long* 
 static __global__ __launch_bounds__(256) void compact_kernel(uint32_t* __restrict__ flags, int ntiles, uint32_t* __restrict__ list,
                                                              unsigned long long* __restrict__ count) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    bool act = false;
+    uint32_t f = 0u;
     if (t < ntiles) {
-        act = flags[t] != 0u;
-        if (act) flags[t] = 0u;
+        f = flags[t];
+        if (f) flags[t] = 0u;
     }
-    wave_append(act, uint32_t(t), list, count);
+    wave_append(f != 0u, uint32_t(t) | (f >= FLAG_FULL ? LIST_FULL : 0u), list, count);
 }
 
 static __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
@@ -472,7 +537,7 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     unsigned long long* dbg = nullptr;
     if (debug) {
         dbg = reinterpret_cast<unsigned long long*>(ctx->d_mail) + 32;
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 64, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 128, s));
     }
     int64_t rounds = 0, launches = 0;
     bool need_rounds = force_rounds;
@@ -505,7 +570,7 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         if (err) {
             fprintf(stderr, "taudem_amd: asynchronous tile worklist gave up (code %u, head %llu tail %llu pending %d); continuing with the round schedule\n", err,
                     (unsigned long long)ctx->h_mail[0], (unsigned long long)ctx->h_mail[1], int(ctx->h_mail[2] & 0xffffffffull));
-            hipLaunchKernelGGL(fill_u32_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, 1u, size_t(ntiles));
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, FLAG_FULL, size_t(ntiles));
             need_rounds = true;
         }
     }
@@ -536,11 +601,16 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         }
     }
     if (debug) {
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, dbg, 48, hipMemcpyDeviceToHost, s));
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, dbg, 128, hipMemcpyDeviceToHost, s));
         TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
         fprintf(stderr, "tile_relax_run(%d tiles, %s): %lld rounds, %llu tile activations, %llu sweeps; queue pops %llu pushes %llu activations %llu\n", ntiles,
                 need_rounds ? "rounds" : "worklist", (long long)rounds, (unsigned long long)ctx->h_mail[1], (unsigned long long)ctx->h_mail[0],
                 (unsigned long long)ctx->h_mail[2], (unsigned long long)ctx->h_mail[3], (unsigned long long)ctx->h_mail[4]);
+        const double na = double(ctx->h_mail[1] ? ctx->h_mail[1] : 1);
+        fprintf(stderr, "    cycles per activation (s_memtime): load %.0f, sweeps %.0f, write-back %.0f\n", double(ctx->h_mail[6]) / na, double(ctx->h_mail[7]) / na,
+                double(ctx->h_mail[8]) / na);
+        fprintf(stderr, "    load split: issue tile loads %.0f, issue cell loads %.0f, wait+LDS stores %.0f, barrier %.0f\n", double(ctx->h_mail[9]) / na,
+                double(ctx->h_mail[10]) / na, double(ctx->h_mail[11]) / na, double(ctx->h_mail[12]) / na);
     }
     if (rounds_out) *rounds_out += rounds;
     if (launches_out) *launches_out += launches;
