@@ -87,7 +87,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("TDX_BENCH_BACKEND", "nccl")   # "gloo": several ranks may share one GPU (functional check only)
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dev = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(dev)
@@ -103,7 +103,8 @@ def main():
     ctx = T.Context(dev)
     device = torch.device(f"cuda:{dev}")
 
-    if world == 1:
+    force_strips = os.environ.get("TDX_BENCH_FORCE_STRIPS") == "1" and dist.is_initialized()   # exercise StripComm with one rank
+    if world == 1 and not force_strips:
         # one n x n raster on one GPU (BASELINE.json configs[1])
         dem = ctx.synth_dem(n, seed=args.seed)
         fel = torch.empty_like(dem)
@@ -137,7 +138,7 @@ def main():
             return s1, s2, s3
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,7 +158,7 @@ def main():
                         a[k] += v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -224,7 +225,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.seed)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

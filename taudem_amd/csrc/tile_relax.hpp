@@ -112,6 +112,7 @@ struct TileLds {   // LDS of one workgroup
     int rim;
     unsigned long long top[2][NWAVE], bot[2][NWAVE];   // columns whose first / last segment row changed, per wave
     unsigned any[2][NWAVE];                            // per wave: did any cell move in this sweep
+    unsigned rows[NWAVE];                              // per wave: OR of the lanes' dirty masks
     unsigned next;
 };
 
@@ -222,10 +223,16 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
             // Within a sweep the rows of a segment are visited in lockstep by the 64 lanes, so a cell that
             // moves in one row can hand its value to the three cells below (above) it in the SAME sweep:
             // `prev` = columns that moved in the row just visited.
+            // `rows` (wave-uniform, lives in an SGPR): rows in which at least one lane has something to look at; the other
+            // rows of the unrolled loop cost two scalar instructions.  A row in which a cell moved pulls in the next one.
             unsigned long long prev = 0ull;
+            if (lx == 0) L.rows[wv] = 0u;
+            if (dirty) atomicOr(&L.rows[wv], dirty);   // LDS operations of one wave execute in order: no barrier needed
+            unsigned rows = __builtin_amdgcn_readfirstlane(L.rows[wv]);
             if ((iter & 1) == 0) {   // downward
 #pragma unroll
                 for (int r = 0; r < RPW; r++) {
+                    if (!((rows >> r) & 1u)) { prev = 0ull; continue; }
                     const unsigned long long dil = prev | (prev << 1) | (prev >> 1);
                     const bool look = ((((dirty >> r) | unsigned(dil >> lx)) & (live >> r)) & 1u) != 0u;
                     bool ch = false;
@@ -246,10 +253,12 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
                         }
                     }
                     prev = __ballot(ch);
+                    if (prev) rows |= 2u << r;
                 }
             } else {                 // upward
 #pragma unroll
                 for (int r = RPW - 1; r >= 0; r--) {
+                    if (!((rows >> r) & 1u)) { prev = 0ull; continue; }
                     const unsigned long long dil = prev | (prev << 1) | (prev >> 1);
                     const bool look = ((((dirty >> r) | unsigned(dil >> lx)) & (live >> r)) & 1u) != 0u;
                     bool ch = false;
@@ -270,6 +279,7 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
                         }
                     }
                     prev = __ballot(ch);
+                    if (prev) rows |= (1u << r) >> 1;
                 }
             }
             // rows to look at next: 3x3 dilation of everything that moved in this sweep
