@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void ad8_forest_deliver_kernel(Ad8Geom g, cons
 
 // LDS word of the apply pass: cnt[0:32) contam[32:44) poison[44:56)
 __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
-                                                             const uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
+                                                             uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
                                                              unsigned long long* __restrict__ nbig) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         const bool con = ((w >> 32) & 0xFFFull) != 0ull, poi = ((w >> 44) & 0xFFFull) != 0ull;
         float a = TDX_AREA_NODATA;
         if (part && !poi && !(con && contcheck == 1)) {
-            if (cnt > big_threshold) { a = BIG_MARK; bigmask |= 1u << r; }
+            if (cnt > big_threshold) { a = BIG_MARK; bigmask |= 1u << r; cellw[size_t(gy) * size_t(g.nx) + size_t(gx)] = cnt; }
             else a = (float)cnt;   // exact: cnt <= 2^24
         }
         A[size_t(gy) * size_t(g.nx) + size_t(gx)] = a;
@@ -524,84 +524,92 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
 }
 
 // ---- big cells: exact k-ordered float32 re-evaluation in dependency order ----
-__global__ __launch_bounds__(256) void ad8_big_degree_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata,
-                                                             const uint32_t* __restrict__ biglist, unsigned long long nbig,
-                                                             const float* __restrict__ A, int32_t* __restrict__ cnt) {
+// The exact integer count of a cell is larger than the count of every cell that drains into it, so ascending count
+// is a dependency order.  The big cells (a few thousand main-stem cells) are sorted by count and evaluated by ONE
+// wave, 64 consecutive list entries at a time: all operands of the 64 cells are fetched in parallel; a cell whose
+// big contributors were finished in earlier chunks folds its sum at once; the (rare) cells that depend on a cell of
+// the same chunk are folded one after the other, handing values through LDS.  The fold itself is the reference's:
+// a = 1.0f; for k = 1..8: a += ad8[neighbour k] (float32)  (src/aread8.cpp:231-256).
+__global__ __launch_bounds__(256) void ad8_big_keys_kernel(const uint32_t* __restrict__ biglist, unsigned long long nbig, const uint32_t* __restrict__ cellw,
+                                                           uint32_t* __restrict__ keys) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
-    const size_t c = biglist[q];
-    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-    int deg = 0;
+    if (q < nbig) keys[q] = cellw[biglist[q]];
+}
+__global__ __launch_bounds__(256) void ad8_big_pos_kernel(const uint32_t* __restrict__ sorted, unsigned long long nbig, uint32_t* __restrict__ pos) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q < nbig) pos[sorted[q]] = uint32_t(q);
+}
+
+__global__ __launch_bounds__(64) void ad8_big_ordered_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
+                                                             int contcheck, const uint32_t* __restrict__ sorted, unsigned long long nbig,
+                                                             const uint32_t* __restrict__ pos, float* __restrict__ A,
+                                                             unsigned long long* __restrict__ nfinal) {
+    __shared__ float s_val[64];
+    const int lane = threadIdx.x;
+    unsigned long long done = 0;
+    for (unsigned long long chunk0 = 0; chunk0 < nbig; chunk0 += 64) {
+        const unsigned long long q = chunk0 + (unsigned long long)lane;
+        const bool live = q < nbig;
+        const size_t c = live ? size_t(sorted[q]) : 0;
+        const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
+        const float mine = live ? ld_agent(&A[c]) : 0.f;
+        const bool pending = live && mine == BIG_MARK;
+        float ak[8];
+        unsigned contrib = 0, inchunk = 0, jl[2] = {0u, 0u};   // jl: 8 x 6-bit lane numbers of in-chunk contributors
+        bool con = false, blocked = false;
+        if (pending) {
 #pragma unroll
-    for (int k = 1; k <= 8; k++) {
-        const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) continue;
-        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-        const int16_t pn = P[n];
-        if (pn != nodata && pn >= 1 && pn <= 8 && (pn - k == 4 || pn - k == -4) && A[n] == BIG_MARK) deg++;
-    }
-    cnt[c] = deg ? deg : CNT_SOURCE;
-}
-
-// evaluate idx and keep walking downstream through OWNED big cells while this lane is the last contributor
-__device__ __forceinline__ void big_walk_from(size_t idx, const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                              int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A) {
-    int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
-    for (;;) {
-        const float a = ad8_evaluate(P, nullptr, 0.f, A, nx, ny, x, y, idx, nodata, contcheck);
-        st_agent(&A[idx], a);
-        const int16_t k = P[idx];
-        if (k < 1 || k > 8) return;
-        const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < y_own0 || yn >= y_own1) return;   // off the raster, or into a neighbour's row (next round)
-        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-        if (ld_agent(&A[n]) != BIG_MARK) return;   // downstream is not awaiting re-evaluation (contaminated / unevaluated)
-        drain_stores();
-        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old != 1) return;
-        x = xn; y = yn; idx = n;
-    }
-}
-
-__global__ __launch_bounds__(256) void ad8_big_walk_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                           int contcheck, const uint32_t* __restrict__ biglist, unsigned long long nbig,
-                                                           int32_t* __restrict__ cnt, float* __restrict__ A) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
-    const size_t idx = biglist[q];
-    if (cnt[idx] != CNT_SOURCE) return;
-    big_walk_from(idx, P, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
-}
-
-// A halo row after an exchange: cells that turned from "awaiting re-evaluation" into a final value release
-// the owned big cell they drain into
-__global__ __launch_bounds__(256) void ad8_big_halo_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                           int contcheck, int yh, const float* __restrict__ recv, int32_t* __restrict__ cnt,
-                                                           float* __restrict__ A, unsigned long long* __restrict__ nchanged) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    bool ch = false;
-    if (x < nx) {
-        const size_t h = size_t(yh) * size_t(nx) + size_t(x);
-        const float a = recv[x], old = A[h];
-        if (a != old) {
-            ch = true;
-            st_agent(&A[h], a);
-            const int16_t k = P[h];
-            if (old == BIG_MARK && a != BIG_MARK && k != nodata && k >= 1 && k <= 8) {
-                const int xn = x + d1(k), yn = yh + d2(k);
-                if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
-                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-                    if (ld_agent(&A[n]) == BIG_MARK) {
-                        drain_stores();
-                        const int32_t o = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (o == 1) big_walk_from(n, P, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+            for (int k = 1; k <= 8; k++) {
+                ak[k - 1] = 0.f;
+                const int xn = x + d1(k), yn = y + d2(k);
+                if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { con = true; continue; }
+                const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+                const int16_t pn = P[n];
+                if (is_nodata_s(pn, nodata)) { con = true; continue; }
+                if (pn - k == 4 || pn - k == -4) {
+                    const float a = ld_agent(&A[n]);
+                    contrib |= 1u << (k - 1);
+                    ak[k - 1] = a;
+                    if (a == BIG_MARK) {
+                        unsigned long long pq = ~0ull;
+                        if (yn >= y_own0 && yn < y_own1) pq = pos[n];
+                        if (pq >= chunk0 && pq < q) {   // evaluated earlier in THIS chunk: its value comes through LDS
+                            inchunk |= 1u << (k - 1);
+                            const unsigned j = unsigned(pq - chunk0);
+                            jl[(k - 1) >> 2] |= j << (6 * ((k - 1) & 3));
+                        } else blocked = true;          // a neighbour rank's cell, or an own cell that is itself still waiting
                     }
                 }
             }
         }
+        s_val[lane] = mine;   // final value, or BIG_MARK while pending
+        float result = BIG_MARK;
+        auto fold = [&]() {
+            float a = 1.0f;
+            bool c2 = con, blk = false;
+#pragma unroll
+            for (int k = 1; k <= 8; k++) {
+                if (!((contrib >> (k - 1)) & 1u)) continue;
+                float v = ak[k - 1];
+                if ((inchunk >> (k - 1)) & 1u) v = s_val[(jl[(k - 1) >> 2] >> (6 * ((k - 1) & 3))) & 63u];
+                if (v == BIG_MARK) blk = true;
+                else if (is_nodata_f(v, TDX_AREA_NODATA)) c2 = true;
+                else a = a + v;
+            }
+            if (c2 && contcheck == 1) a = TDX_AREA_NODATA;
+            return blk ? BIG_MARK : a;
+        };
+        if (pending && !blocked && inchunk == 0u) { result = fold(); s_val[lane] = result; }
+        unsigned long long serial = __ballot(pending && !blocked && inchunk != 0u);
+        while (serial) {   // ascending list position = dependency order; LDS operations of one wave execute in order
+            const int i = __ffsll((long long)serial) - 1;
+            serial &= serial - 1ull;
+            if (lane == i) { result = fold(); s_val[lane] = result; }
+        }
+        if (pending && result != BIG_MARK) { st_agent(&A[c], result); done++; }
+        drain_stores();   // the next chunk reads these values back through the L2
     }
-    const unsigned long long m = __ballot(ch);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nchanged, (unsigned long long)__popcll(m));
+    if (done) atomicAdd(nfinal, done);
 }
 
 }  // namespace
@@ -612,6 +620,9 @@ __global__ __launch_bounds__(256) void ad8_big_halo_kernel(const int16_t* __rest
 // re-evaluation of big cells continues across strips through exchanged boundary rows of ad8 - both in
 // outer rounds that end when no rank received anything new (the role of the outer while loop with
 // share()/addBorders() in src/aread8.cpp:282-303).
+int tdx_sort_pairs_u32(tdx_context* ctx, int scratch_slot, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                       size_t n);   // sort_pairs.hip
+
 static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_nodata, int contcheck, float* d_ad8, tdx_stats* stats) {
     hipStream_t s = ctx->stream;
     const int inx = st.nx;
@@ -685,31 +696,28 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     if (rc != TDX_OK) return rc;
     if (nbig_all > 0) {
         TdxSpan sp(ctx, TDX_K_MISC);
-        int32_t* bigcnt = reinterpret_cast<int32_t*>(cellw);
+        // dependency order = ascending exact count (left in cellw by the apply pass)
+        uint32_t* keys = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(nbig ? nbig : 1) * 4 * 3));
+        if (!keys) return TDX_ERR_NOMEM;
+        uint32_t *keys_sorted = keys + (nbig ? nbig : 1), *sorted = keys_sorted + (nbig ? nbig : 1);
+        uint32_t* pos = cellw;   // list position of every big cell (the per-cell words are no longer needed once the keys are out)
+        if (nbig) {
+            hipLaunchKernelGGL(ad8_big_keys_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, biglist, nbig, cellw, keys);
+            rc = tdx_sort_pairs_u32(ctx, TDX_S_I, keys, keys_sorted, biglist, sorted, size_t(nbig));
+            if (rc != TDX_OK) return rc;
+            hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, sorted, nbig, pos);
+        }
         rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);   // which halo cells await re-evaluation
         if (rc != TDX_OK) return rc;
-        if (nbig) {
-            hipLaunchKernelGGL(ad8_big_degree_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, p_nodata, biglist, nbig, d_ad8,
-                               bigcnt);
-            hipLaunchKernelGGL(ad8_big_walk_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata,
-                               contcheck, biglist, nbig, bigcnt, d_ad8);
-        }
-        if (stats) stats->launches[TDX_K_MISC] += 2;
-        while (st.multi()) {
-            const size_t rowb = size_t(st.nx) * 4;
-            rc = strip_exchange_buffers(ctx, st, d_ad8 + size_t(st.y0) * st.nx, d_ad8 + size_t(st.y1 - 1) * st.nx, st.comm->recv_up, st.comm->recv_down, rowb);
+        for (;;) {
+            if (nbig)
+                hipLaunchKernelGGL(ad8_big_ordered_kernel, dim3(1), dim3(64), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, sorted, nbig, pos,
+                                   d_ad8, d_cnt + 2);
+            if (stats) stats->launches[TDX_K_MISC]++;
+            if (!st.multi()) break;
+            int64_t changed = 0;   // halo cells that became final on the neighbouring ranks
+            rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA, nullptr, 0, &changed);
             if (rc != TDX_OK) return rc;
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
-            const unsigned gx = tdx_blocks_for(size_t(st.nx), 256);
-            if (st.up)
-                hipLaunchKernelGGL(ad8_big_halo_kernel, dim3(gx), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, st.y0 - 1,
-                                   static_cast<const float*>(st.comm->recv_up), bigcnt, d_ad8, d_cnt + 1);
-            if (st.down)
-                hipLaunchKernelGGL(ad8_big_halo_kernel, dim3(gx), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, st.y1,
-                                   static_cast<const float*>(st.comm->recv_down), bigcnt, d_ad8, d_cnt + 1);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            int64_t changed = int64_t(ctx->h_mail[0]);
             rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
             if (rc != TDX_OK) return rc;
             if (changed == 0) break;

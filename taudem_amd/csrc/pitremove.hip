@@ -23,26 +23,47 @@
 
 namespace {
 
+// Seed surface (src/flood.cpp:243-271).  A 256-thread block covers 64 columns x 64 rows; each lane walks a 16-row
+// column segment with the 3x3 window of nodata flags in registers: 3 coalesced row loads per output row.
+constexpr int SEED_ROWS = 16;
 __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__ Z, const int16_t* __restrict__ mask,
                                                        float* __restrict__ W, int nx, int ny, int y_own0, int y_own1, float nodata, int step) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= y_own1) return;
-    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    const float z = Z[idx];
-    float w;
-    if (tdxk::is_nodata_f(z, nodata)) w = TDX_FEL_NODATA;
-    else if (mask && mask[idx] == 1) w = z;
-    else if (x == 0 || y == 0 || x == nx - 1 || y == ny - 1) w = z;   // !hasAccess(i+-1,j+-1): global edge ring
-    else {
-        bool con = false;
-        for (int k = 1; k <= 8; k += step) {
-            const float zn = Z[size_t(y + tdxk::d2(k)) * size_t(nx) + size_t(x + tdxk::d1(k))];
-            con = con || tdxk::is_nodata_f(zn, nodata);
+    const int ybase = y_own0 + blockIdx.y * (4 * SEED_ROWS) + (threadIdx.x >> 6) * SEED_ROWS;
+    const bool colok = x < nx;
+    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
+    // per row: centre value and the nodata flags of (x-1, x, x+1); rows outside the array count as nodata
+    auto ldrow = [&](int y, float& zc, bool& a, bool& b, bool& c) {
+        if (y >= 0 && y < ny) {
+            const float* r = Z + size_t(y) * size_t(nx);
+            zc = r[xc];
+            a = tdxk::is_nodata_f(r[xm], nodata); b = tdxk::is_nodata_f(zc, nodata); c = tdxk::is_nodata_f(r[xp], nodata);
+        } else { zc = nodata; a = b = c = true; }
+    };
+    float zn, zc, zs;
+    bool n0, n1, n2, c0, c1, c2, s0, s1, s2;
+    ldrow(ybase - 1, zn, n0, n1, n2);
+    ldrow(ybase, zc, c0, c1, c2);
+#pragma unroll
+    for (int r = 0; r < SEED_ROWS; r++) {
+        const int y = ybase + r;
+        ldrow(y + 1, zs, s0, s1, s2);
+        if (colok && y < y_own1) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            float w;
+            if (c1) w = TDX_FEL_NODATA;
+            else if (mask && mask[idx] == 1) w = zc;
+            else if (x == 0 || y == 0 || x == nx - 1 || y == ny - 1) w = zc;   // !hasAccess(i+-1,j+-1): global edge ring
+            else {
+                const bool con = (step == 2) ? (c2 || n1 || c0 || s1) : (c2 || n2 || n1 || n0 || c0 || s0 || s1 || s2);
+                w = con ? zc : FLT_MAX;
+            }
+            W[idx] = w;
         }
-        w = con ? z : FLT_MAX;
+        zn = zc; n0 = c0; n1 = c1; n2 = c2;
+        zc = zs; c0 = s0; c1 = s1; c2 = s2;
     }
-    W[idx] = w;
+    (void)zn;
 }
 
 // minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
@@ -86,7 +107,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     if (rc != TDX_OK) return rc;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
+        dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
         hipLaunchKernelGGL(pit_seed_kernel, grid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, fourway ? 2 : 1);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
