@@ -66,6 +66,46 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     (void)zn;
 }
 
+// ---- coarse-to-fine start surface ------------------------------------------------------------------------------
+// Relaxing from the reference's +inf start lowers every cell many times (each newly found saddle re-lowers a whole
+// lake).  Any start surface W0 >= W* converges to the same fixed point, so the relaxation is started from a TIGHT
+// upper bound obtained on a 8x coarser raster: Zc = max of the valid cells of an 8x8 block; a block is a seed block if
+// it holds a seed cell.  A coarse minimax path maps to a fine path that stays inside those blocks (a block's valid
+// cells are 8-connected to each other or to a seed next to the block's nodata cells), hence W*(c) <= Wc*(block(c)).
+// Used for the 8-neighbour fill of a single strip; recursive.
+constexpr int CF = 8;
+__global__ __launch_bounds__(256) void pit_coarsen_kernel(const float* __restrict__ Z, const float* __restrict__ W0, int nx, int ny, int nxc, int nyc,
+                                                          float* __restrict__ Zc, float* __restrict__ Wc) {
+    const int xc = blockIdx.x * 64 + (threadIdx.x & 63), yc = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xc >= nxc || yc >= nyc) return;
+    float zmax = -FLT_MAX;
+    bool seed = false, any = false;
+    for (int j = 0; j < CF; j++) {
+        const int y = yc * CF + j;
+        if (y >= ny) break;
+        for (int i = 0; i < CF; i++) {
+            const int x = xc * CF + i;
+            if (x >= nx) break;
+            const float w = W0[size_t(y) * size_t(nx) + size_t(x)];
+            if (w == TDX_FEL_NODATA) continue;            // nodata cell of the fine raster
+            any = true;
+            const float z = Z[size_t(y) * size_t(nx) + size_t(x)];
+            zmax = fmaxf(zmax, z);
+            if (w != FLT_MAX) seed = true;                 // fine seed: W0 == Z
+        }
+    }
+    const size_t c = size_t(yc) * size_t(nxc) + size_t(xc);
+    // a block without valid cells behaves like a nodata cell: never updated; its neighbours are seed blocks anyway
+    Zc[c] = any ? zmax : TDX_FEL_NODATA;
+    Wc[c] = any ? (seed ? zmax : FLT_MAX) : TDX_FEL_NODATA;
+}
+__global__ __launch_bounds__(256) void pit_prolong_kernel(float* __restrict__ W, int nx, int ny, const float* __restrict__ Wc, int nxc) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    if (W[idx] == FLT_MAX) W[idx] = Wc[size_t(y / CF) * size_t(nxc) + size_t(x / CF)];
+}
+
 // minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
 template <int NBR>   // 8, or 4 for the -4way flag (k = 1,3,5,7)
 struct PitOp {
@@ -86,6 +126,29 @@ struct PitOp {
 };
 
 }  // namespace
+
+// Tightens the start surface W (seed surface of an nx x ny raster, 8-neighbour fill) through coarser levels.
+static int pit_coarse_start(tdx_context* ctx, const float* Z, float* W, int nx, int ny, tilek::Sched sc, int depth, int64_t* rounds, int64_t* launches) {
+    if (depth >= 3 || size_t(nx) * size_t(ny) < (size_t(1) << 18)) return TDX_OK;
+    hipStream_t s = ctx->stream;
+    const int nxc = (nx + CF - 1) / CF, nyc = (ny + CF - 1) / CF;
+    const size_t nc = size_t(nxc) * size_t(nyc);
+    float* Zc = static_cast<float*>(ctx->scratch(TDX_S_D + 2 * depth, nc * 4));
+    float* Wc = static_cast<float*>(ctx->scratch(TDX_S_E + 2 * depth, nc * 4));
+    if (!Zc || !Wc) return TDX_ERR_NOMEM;
+    const dim3 gc((nxc + 63) / 64, (nyc + 3) / 4);
+    hipLaunchKernelGGL(pit_coarsen_kernel, gc, dim3(256), 0, s, Z, W, nx, ny, nxc, nyc, Zc, Wc);
+    int rc = pit_coarse_start(ctx, Zc, Wc, nxc, nyc, sc, depth + 1, rounds, launches);
+    if (rc != TDX_OK) return rc;
+    const tilek::TileGeom g = tilek::make_geom(nxc, nyc, 0, nyc);
+    const int ntiles = g.tiles_x * g.tiles_y;
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));
+    rc = tile_relax_run(ctx, PitOp<8>{Zc, Wc}, g, sc, rounds, launches);
+    if (rc != TDX_OK) return rc;
+    const dim3 gf((nx + 63) / 64, (ny + 3) / 4);
+    hipLaunchKernelGGL(pit_prolong_kernel, gf, dim3(256), 0, s, W, nx, ny, Wc, nxc);
+    return TDX_OK;
+}
 
 // One strip (src/flood.cpp:132-482).  Multi-strip: every rank relaxes its strip to the local fixed point
 // with the neighbours' boundary rows frozen in its halo rows, then boundary rows are exchanged and the
@@ -113,11 +176,16 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     }
     rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // seed surface halo rows
     if (rc != TDX_OK) return rc;
-    // round 0: every tile is active
-    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
     int64_t rounds = 0, launches = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
+        static const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;
+        if (!fourway && !st.multi() && st.ny_arr == st.y1 - st.y0 && !no_coarse) {
+            rc = pit_coarse_start(ctx, d_dem, d_fel, st.nx, st.ny_arr, tilek::Sched{flags, list, counts}, 0, &rounds, &launches);
+            if (rc != TDX_OK) return rc;
+        }
+        // round 0: every tile is active
+        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
         for (;;) {
             rc = fourway ? tile_relax_run(ctx, PitOp<4>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches)
                          : tile_relax_run(ctx, PitOp<8>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);

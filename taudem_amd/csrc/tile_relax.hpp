@@ -213,7 +213,7 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
         const unsigned long long tc1 = dbg ? __builtin_readcyclecounter() : 0ull;
         bool any_change = false, capped = false;
         // first look: everything, or (FLAG_HALO) only the cells that touch the halo ring
-        unsigned perim = (lx == 0 || lx == TS - 1) ? 0xFFFFu : 0u;
+        unsigned perim = (lx == 0 || lx == TS - 1) ? ((1u << RPW) - 1u) : 0u;
         if (wv == 0) perim |= 1u;
         if (wv == NWAVE - 1) perim |= 1u << (RPW - 1);
         unsigned dirty = full ? live : (live & perim);
