@@ -180,8 +180,10 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
         static const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;
-        if (!fourway && !st.multi() && st.ny_arr == st.y1 - st.y0 && !no_coarse) {
-            rc = pit_coarse_start(ctx, d_dem, d_fel, st.nx, st.ny_arr, tilek::Sched{flags, list, counts}, 0, &rounds, &launches);
+        if (!fourway && !no_coarse) {
+            // on the OWNED rows of the strip: paths that leave the strip are ignored, which only loosens the bound
+            const size_t off = size_t(st.y0) * size_t(st.nx);
+            rc = pit_coarse_start(ctx, d_dem + off, d_fel + off, st.nx, st.y1 - st.y0, tilek::Sched{flags, list, counts}, 0, &rounds, &launches);
             if (rc != TDX_OK) return rc;
         }
         // round 0: every tile is active
