@@ -27,6 +27,25 @@ BYTES_PER_CELL = {"pitremove": 8, "d8flowdir": 10, "aread8": 6}
 KCLASS_STAGE = {"relax": "pitremove", "bfs": "d8flowdir", "flatdir": "d8flowdir", "accum": "aread8"}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries of this same command
+    (profiles/pmc_fetch_summary.json, profiles/pmc_write_summary.json; scripts/gpu_pmc.sh + scripts/pmc_summary.py).
+    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
+    (MI355X_MICROARCH.md, HBM): it is doubled here.  Returns (bytes, note) or (None, reason)."""
+    try:
+        f = json.load(open(os.path.join(ROOT, "profiles", "pmc_fetch_summary.json")))
+        w = json.load(open(os.path.join(ROOT, "profiles", "pmc_write_summary.json")))
+        fk = [k for k in f if kernel_substr in k]
+        wk = [k for k in w if kernel_substr in k]
+        if not fk or not wk:
+            return None, "kernel not in the PMC summaries"
+        fetch = f[fk[0]]["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * 2.0
+        write = w[wk[0]]["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
+        return fetch + write, "profiles/pmc_{fetch,write}_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
+    except Exception as e:  # no summaries committed
+        return None, f"no PMC summary ({e.__class__.__name__})"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +177,13 @@ def main():
                         a[k] += v
     barrier()
     elapsed = time.perf_counter() - t0
+    # One more pass of the same step, outside the timed region, with every launch of the tile-relaxation kernel
+    # bracketed by HIP events on the library's stream (two event records per launch would cost ~5 % inside it):
+    # the dominant kernel's average launch duration for the roofline object.
+    ctx.set_option("kernel_timing", 1)
+    prof = step()
+    ctx.set_option("kernel_timing", 0)
+    barrier()
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,19 +202,20 @@ def main():
                 klass["n_" + name] = klass.get("n_" + name, 0) + a["launches_" + name]
         # per-stage view of the dominant kernel class: the tile-relaxation kernel of pitremove ("relax") and of
         # flat resolution ("bfs") are the same kernel template (tilek::relax_kernel) with different operators
-        per_stage = {"pitremove/relax_kernel<PitOp>": (acc[0]["ms_relax"], acc[0]["launches_relax"], "pitremove"),
-                     "d8flowdir/relax_kernel<LevelOp>": (acc[1]["ms_bfs"], acc[1]["launches_bfs"], "d8flowdir"),
-                     "aread8/tile kernels": (acc[2]["ms_stencil"], acc[2]["launches_stencil"], "aread8"),
-                     "aread8/big-cell walk": (acc[2]["ms_misc"], acc[2]["launches_misc"], "aread8")}
+        per_stage = {"pitremove/relax_kernel<PitOp>": (prof[0]["ms_tilek"], prof[0]["launches_tilek"], "pitremove"),
+                     "d8flowdir/relax_kernel<LevelOp>": (prof[1]["ms_tilek"], prof[1]["launches_tilek"], "d8flowdir"),
+                     "aread8/tile kernels": (prof[2]["ms_stencil"], prof[2]["launches_stencil"], "aread8"),
+                     "aread8/big-cell evaluation": (prof[2]["ms_misc"], prof[2]["launches_misc"], "aread8")}
         dom = max(per_stage, key=lambda k: per_stage[k][0])
         dms, dlaunch, stage = per_stage[dom]
         launches = max(1, dlaunch)
         avg_ms = dms / launches
-        bytes_per_launch = BYTES_PER_CELL[stage] * cells * args.steps / launches
+        bytes_per_launch = BYTES_PER_CELL[stage] * cells / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # the streaming 3x3 stencil that the 40 %-of-HBM target of BASELINE.json is about: D8 slope pass
         slope_ms = acc[1]["ms_stencil"] / max(1, acc[1]["launches_stencil"])
         slope_gbs = 10.0 * cells / (slope_ms * 1e-3) / 1e9 if slope_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic("LevelOp" if "LevelOp" in dom else ("PitOp" if "PitOp" in dom else "ad8_tile"))
         out = {
             "metric": "Mcells/s (PitRemove->D8FlowDir->AreaD8 pipeline)",
             "value": value,
@@ -211,7 +238,7 @@ def main():
             "kernel_class_ms_per_step": {k: klass[k] / args.steps for k in ("stencil", "relax", "bfs", "flatdir", "accum", "misc")},
             "kernel_class_launches_per_step": {k: klass["n_" + k] / args.steps for k in ("stencil", "relax", "bfs", "flatdir", "accum", "misc")},
             "roofline": {"bound": "hbm", "kernel": dom, "stage": stage, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "dependency-driven sweep: bound by (critical path in tiles) x launch, not by bandwidth (SURVEY.md 8d)"},
             "roofline_streaming_stencil": {"kernel": "d8_slope_kernel", "algorithmic_bytes_per_cell": 10, "avg_launch_ms": slope_ms,

@@ -77,6 +77,7 @@ typedef struct tdx_stats {
 #define TDX_K_FLATDIR 3  /* setFlow2 / SET2 on flats + bookkeeping                                     */
 #define TDX_K_ACCUM 4    /* dependency-driven accumulation sweep                                       */
 #define TDX_K_MISC 5     /* fills, compaction, copies                                                  */
+#define TDX_K_TILEK 6    /* the tile-relaxation kernel alone (nested inside RELAX / BFS): per-launch durations */
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* Creates a context bound to HIP device `device` (one context per GPU / per process rank).
@@ -87,6 +88,9 @@ const char* tdx_last_error(const tdx_context* ctx); /* ctx may be NULL: last err
 int tdx_synchronize(tdx_context* ctx);
 void* tdx_stream(tdx_context* ctx);                  /* the hipStream_t all work is enqueued on */
 const char* tdx_version(void);
+/* Context options.  "kernel_timing" (0/1, default 0): additionally bracket every launch of the tile-relaxation kernel
+ * with HIP events (TDX_K_TILEK in tdx_stats) - two event records per launch, so it is off unless asked for. */
+int tdx_context_set_option(tdx_context* ctx, const char* name, int64_t value);
 int tdx_device_count(void);
 
 /* device memory helpers so that callers without a HIP binding (ctypes, cgo ...) can stage data */

@@ -11,7 +11,7 @@ def main():
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 k = row.get("Kernel_Name", "?")
-                k = k.split("(")[0][-70:]
+                k = k.replace("(anonymous namespace)::", "").split("(")[0][-90:]
                 c = row["Counter_Name"]
                 acc[k][c] += float(row["Counter_Value"])
                 calls[k][c].add(row.get("Dispatch_Id", "0"))

@@ -24,8 +24,8 @@ TDX_ERR_NOMEM = -999
 
 TDX_DT_I16, TDX_DT_I32, TDX_DT_F32 = 0, 1, 2
 
-K_STENCIL, K_RELAX, K_BFS, K_FLATDIR, K_ACCUM, K_MISC = 0, 1, 2, 3, 4, 5
-KERNEL_CLASSES = {"stencil": K_STENCIL, "relax": K_RELAX, "bfs": K_BFS, "flatdir": K_FLATDIR, "accum": K_ACCUM, "misc": K_MISC}
+K_STENCIL, K_RELAX, K_BFS, K_FLATDIR, K_ACCUM, K_MISC, K_TILEK = 0, 1, 2, 3, 4, 5, 6
+KERNEL_CLASSES = {"stencil": K_STENCIL, "relax": K_RELAX, "bfs": K_BFS, "flatdir": K_FLATDIR, "accum": K_ACCUM, "misc": K_MISC, "tilek": K_TILEK}
 
 
 class TdxStats(C.Structure):
@@ -103,6 +103,7 @@ _SIGNATURES = {
     "tdx_synchronize": (C.c_int, [_P]),
     "tdx_stream": (_P, [_P]),
     "tdx_version": (C.c_char_p, []),
+    "tdx_context_set_option": (C.c_int, [_P, C.c_char_p, _I64]),
     "tdx_device_count": (C.c_int, []),
     "tdx_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "tdx_device_free": (C.c_int, [_P, _P]),

@@ -44,6 +44,10 @@ class Context:
             self._lib.tdx_context_destroy(self._h)
             self._h = None
 
+    def set_option(self, name: str, value: int):
+        """Context options of include/taudem_amd.h (e.g. "kernel_timing")."""
+        check(self._lib.tdx_context_set_option(self._h, name.encode(), int(value)), self._h)
+
     def __del__(self):
         try:
             self.close()

@@ -43,17 +43,18 @@ void tdx_context::begin_call(tdx_stats* st) {
     }
 }
 
-void tdx_context::span_begin(int kclass) {
-    if (!timing) return;
+int tdx_context::span_begin(int kclass) {
+    if (!timing) return -1;
     Span s;
     s.a = get_event(); s.b = get_event(); s.kclass = kclass;
     (void)hipEventRecord(s.a, stream);
     spans.push_back(s);
+    return int(spans.size()) - 1;
 }
 
-void tdx_context::span_end() {
-    if (!timing || spans.empty()) return;
-    (void)hipEventRecord(spans.back().b, stream);
+void tdx_context::span_end(int index) {
+    if (!timing || index < 0 || size_t(index) >= spans.size()) return;
+    (void)hipEventRecord(spans[size_t(index)].b, stream);
 }
 
 void tdx_context::end_call() {
@@ -78,6 +79,12 @@ void tdx_context::end_call() {
 extern "C" {
 
 const char* tdx_version(void) { return "taudem_amd 0.1.0 (TauDEM 5.4.0 hot path, gfx950)"; }
+
+int tdx_context_set_option(tdx_context* c, const char* name, int64_t value) {
+    if (!c || !name) return TDX_ERR_ARG;
+    if (strcmp(name, "kernel_timing") == 0) { c->kernel_timing = value != 0; return TDX_OK; }
+    return tdx_fail(c, TDX_ERR_ARG, std::string("unknown option ") + name);
+}
 
 int tdx_device_count(void) {
     int n = 0;

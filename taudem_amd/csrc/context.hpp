@@ -34,13 +34,14 @@ struct tdx_context {
     std::vector<Span> spans;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timing = false;
+    bool kernel_timing = false;               // option "kernel_timing"
     tdx_stats* cur_stats = nullptr;
 
     hipEvent_t get_event();
     void begin_call(tdx_stats* st);
     void end_call();                          // synchronises, fills stats
-    void span_begin(int kclass);
-    void span_end();
+    int span_begin(int kclass);              // returns the span's index (-1 when timing is off); spans may nest
+    void span_end(int index);
 };
 
 extern thread_local std::string g_tdx_thread_error;
@@ -58,8 +59,9 @@ extern thread_local std::string g_tdx_thread_error;
 // RAII helper: times everything enqueued in its scope under one kernel class
 struct TdxSpan {
     tdx_context* c;
-    TdxSpan(tdx_context* ctx, int kclass) : c(ctx) { c->span_begin(kclass); }
-    ~TdxSpan() { c->span_end(); }
+    int index;
+    TdxSpan(tdx_context* ctx, int kclass) : c(ctx), index(ctx->span_begin(kclass)) {}
+    ~TdxSpan() { c->span_end(index); }
 };
 
 // scratch slot ids (one namespace for all stages; stages never run concurrently on a context)
