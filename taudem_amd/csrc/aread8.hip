@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
 // =====================================================================================================
 constexpr int TS = 64;
 constexpr int TH = TS + 2;
-constexpr uint32_t NODE_INVALID = 0xFFFFFFFFu;   // perimeter / halo cell that is not (yet) a node
+// node_indeg == 0xFFFFFFFF: perimeter / halo cell that is not (yet) a node
 constexpr uint32_t NODE_DEAD = 0xFFFFFFFEu;      // node whose cell never completes (cycle / poisoned): never fires
 constexpr uint32_t NEXT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t NEXT_REMOTE_UP = 0xFFFFFFFDu;    // the crossing leaves the strip through the halo row above

@@ -30,12 +30,10 @@ using namespace tdxk;
 constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-thread block
 
 // One lane walks down a column segment keeping the 3x3 window in registers (3 loads per new row).
-// Besides p and sd8 it initialises the flat-resolution markers (lvl/rq: 0 flat, -1 otherwise) and
-// appends the flat cells to `qlist` with ONE atomic per block.
+// Besides p and sd8 it appends the flat cells to `qlist` with ONE atomic per block.
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
-                                                       float* __restrict__ SD8, int32_t* __restrict__ lvl, int32_t* __restrict__ rq,
-                                                       uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
+                                                       float* __restrict__ SD8, uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
     const bool colok = x < nx;
@@ -87,9 +85,6 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
             }
             P[idx] = p;
             if (SD8) SD8[idx] = sd;
-            const int32_t mk = (p == 0) ? 0 : -1;
-            lvl[idx] = mk;
-            rq[idx] = mk;
         }
         n0 = c0; n1 = c1; n2 = c2;
         c0 = s0; c1 = s1; c2 = s2;
@@ -109,6 +104,83 @@ __device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, siz
         case 8: return P[c + 1] == 6 || P[c + nx] == 2;
         default: return false;
     }
+}
+
+// Classification for flat resolution as ONE streaming pass (replaces marker reset + list gathers): the flat queue is
+// exactly {p == 0} in every outer iteration (resolved cells leave it, nothing enters it), so queue membership, the
+// level-1/2 seeds of incfall, the seeds of incrise and both eligibility masks are a function of the 3x3 windows of
+// Z and P.  Every owned cell gets its markers (lvl / rq: -1 outside the queue) and masks; lanes walk 16-row column
+// segments with both windows in registers (6 row loads per output row).  Semantics: flatk::classify_kernel.
+__global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
+                                                                 int y_own0, int y_own1, int tiles_x, int32_t* __restrict__ lvl,
+                                                                 int32_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                                 uint32_t* __restrict__ tile_flags) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
+    const bool colok = x < nx;
+    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
+    auto ldrow = [&](int y, float& a, float& b, float& c, int16_t& pa, int16_t& pb, int16_t& pc) {
+        if (y >= 0 && y < ny) {
+            const float* r = Z + size_t(y) * size_t(nx);
+            const int16_t* q = P + size_t(y) * size_t(nx);
+            a = r[xm]; b = r[xc]; c = r[xp];
+            pa = q[xm]; pb = q[xc]; pc = q[xp];
+        } else { a = b = c = 0.f; pa = pb = pc = TDX_P_NODATA; }
+    };
+    float zn0, zn1, zn2, zc0, zc1, zc2, zs0, zs1, zs2;
+    int16_t pn0, pn1, pn2, pc0, pc1, pc2, ps0, ps1, ps2;
+    ldrow(ybase - 1, zn0, zn1, zn2, pn0, pn1, pn2);
+    ldrow(ybase, zc0, zc1, zc2, pc0, pc1, pc2);
+    int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
+#pragma unroll
+    for (int r = 0; r < SLOPE_ROWS; r++) {
+        const int y = ybase + r;
+        ldrow(y + 1, zs0, zs1, zs2, ps0, ps1, ps2);
+        if (colok && y < y_own1) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            int32_t l = -1, q = -1;
+            unsigned fm = 0, rm = 0;
+            if (pc1 == 0) {   // a flat cell: interior, all eight neighbours valid
+                const float z0 = zc1;
+                bool low = false, quirk = false, higher = false;
+                // neighbour k: value, direction code, dontCross(k) from the cardinal neighbours' codes (src/d8.cpp:54-100)
+#define TDX_CLS(K, ZN, PN, CROSS)                                                     \
+    {                                                                                  \
+        const float zd = z0 - (ZN);                                                    \
+        const bool inq = (PN) == 0;                                                    \
+        if (zd < 0) higher = true;                                                     \
+        if (inq) rm |= 1u << ((K) - 1);                                                \
+        if (!(CROSS)) {                                                                \
+            if (zd >= 0 && (PN) > 0 && (PN) < 9) low = true;                           \
+            else if (zd == 0) { if (inq) fm |= 1u << ((K) - 1); else quirk = true; }   \
+        }                                                                              \
+    }
+                TDX_CLS(1, zc2, pc2, false)
+                TDX_CLS(2, zn2, pn2, (pc2 == 4 || pn1 == 8))
+                TDX_CLS(3, zn1, pn1, false)
+                TDX_CLS(4, zn0, pn0, (pn1 == 6 || pc0 == 2))
+                TDX_CLS(5, zc0, pc0, false)
+                TDX_CLS(6, zs0, ps0, (ps1 == 4 || pc0 == 8))
+                TDX_CLS(7, zs1, ps1, false)
+                TDX_CLS(8, zs2, ps2, (pc2 == 6 || ps1 == 2))
+#undef TDX_CLS
+                l = low ? 1 : (quirk ? 2 : 0);
+                q = higher ? 1 : 0;
+                if (low) fm = 0;       // a level-1 cell can never improve
+                if (higher) rm = 0;
+                const int tr = y / tilek::TS;
+                if (flag_row0 < 0) flag_row0 = tr; else if (tr != flag_row0) flag_row1 = tr;
+            }
+            lvl[idx] = l;
+            rq[idx] = q;
+            fmask[idx] = uint8_t(fm);
+            rmask[idx] = uint8_t(rm);
+        }
+        zn0 = zc0; zn1 = zc1; zn2 = zc2; pn0 = pc0; pn1 = pc1; pn2 = pc2;
+        zc0 = zs0; zc1 = zs1; zc2 = zs2; pc0 = ps0; pc1 = ps1; pc2 = ps2;
+    }
+    if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
 }
 
 struct D8Traits {
@@ -218,7 +290,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
-        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, lvl, rq, qlist, d_cnt);
+        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, qlist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -232,10 +304,6 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     if (total > 0) {
         rc = strip_exchange<int16_t>(ctx, st, d_p, TDX_P_NODATA);
         if (rc != TDX_OK) return rc;
-        rc = strip_exchange<int32_t>(ctx, st, lvl, -1);
-        if (rc != TDX_OK) return rc;
-        rc = strip_exchange<int32_t>(ctx, st, rq, -1);
-        if (rc != TDX_OK) return rc;
         // working storage for flat resolution
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(nq) * 4));
         if (!qnext) return TDX_ERR_NOMEM;
@@ -245,17 +313,17 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
 
         // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
         int64_t last = total;
-        bool first = true;
         for (;;) {
-            if (!first) {
-                // later calls: elev2 / dn are re-created (src/d8.cpp:483-486): reset markers of the new Q
-                rc = flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
-                if (rc != TDX_OK) return rc;
-            }
-            first = false;
+            // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
             FlatLevels fl;
             D8Traits tr{d_p};
-            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
+            const float* zc = zcur;
+            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags) {
+                const dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
+                                   rmask, tile_flags);
+            };
+            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, &classify);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);

@@ -25,6 +25,7 @@
 //   incrise loop ends when the marked count stops growing (src/d8.cpp:631): Tr = Qmax + 1
 #pragma once
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "context.hpp"
@@ -206,9 +207,12 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 
 // Runs classification + both level relaxations for the flat queue `qlist` (cells of this strip); on return
 // lvl/rq hold the levels (halo rows included) and *out the sweep counts of the reference's loops.
+// `stream_classify` (optional): replaces the marker reset + list-based classification by one streaming pass over the
+// whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags.
+using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags)>;
 template <class Traits>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
-                     FlatBuffers b, FlatLevels* out, tdx_stats* stats) {
+                     FlatBuffers b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr) {
     hipStream_t s = ctx->stream;
     const int nx = st.nx;
     const size_t n = size_t(nx) * size_t(st.ny_arr);
@@ -224,12 +228,15 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     uint32_t* flags = flags0 + ntiles;
     TdxSpan sp(ctx, TDX_K_BFS);
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(flags0, 0, size_t(ntiles) * 4, s));
-    if (nq)
-        hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
-                           geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
+    if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0);
+    else {
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
+        if (nq)
+            hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
+                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
+    }
     int rc = strip_exchange<int32_t>(ctx, st, b.lvl, -1);   // the neighbours' seeds
     if (rc != TDX_OK) return rc;
     rc = strip_exchange<int32_t>(ctx, st, b.rq, -1);
