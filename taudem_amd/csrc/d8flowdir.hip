@@ -247,6 +247,67 @@ __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __res
     if (lvl[c] == 0) P[c] = TDX_P_NODATA;   // never stopped incrementing: enclosed pit (src/d8.cpp:559-585)
 }
 
+// mark_pits + setFlow2 + re-collection of the cells that are still flat as ONE streaming pass over the strip (used
+// while a large share of the raster is in the queue; the list kernels above are cheaper for a sparse queue).
+// A cell's new direction depends on the elevations and level markers of its neighbours, never on their directions,
+// so P can be rewritten in place.
+__global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
+                                                                 const double* __restrict__ fact, const int32_t* __restrict__ lvl,
+                                                                 const int32_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
+                                                                 uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
+    const bool colok = x < nx;
+    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
+    struct Row { float z0, z1, z2; int l0, l1, l2, r0, r1, r2; };
+    auto ldrow = [&](int y, Row& w) {
+        if (y >= 0 && y < ny) {
+            const size_t o = size_t(y) * size_t(nx);
+            w.z0 = Z[o + xm]; w.z1 = Z[o + xc]; w.z2 = Z[o + xp];
+            w.l0 = lvl[o + xm]; w.l1 = lvl[o + xc]; w.l2 = lvl[o + xp];
+            w.r0 = rq[o + xm]; w.r1 = rq[o + xc]; w.r2 = rq[o + xp];
+        } else { w.z0 = w.z1 = w.z2 = 0.f; w.l0 = w.l1 = w.l2 = -1; w.r0 = w.r1 = w.r2 = -1; }
+    };
+    Row n, c, s;
+    ldrow(ybase - 1, n);
+    ldrow(ybase, c);
+    unsigned keep = 0;
+#pragma unroll
+    for (int r = 0; r < SLOPE_ROWS; r++) {
+        const int y = ybase + r;
+        ldrow(y + 1, s);
+        if (colok && y < y_own1) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            if (P[idx] == 0) {
+                const double* f = fact + size_t(y) * 9;
+                const int e2c = int(flat_elev2(c.l1, c.r1, fl));
+                const float z0 = c.z1;
+                float smax = 0.f;
+                int16_t dir = (fl.has_pits && c.l1 == 0) ? TDX_P_NODATA : int16_t(0);   // enclosed pit (src/d8.cpp:559-585)
+                bool done = false;
+                // candidate order 1,3,5,7,2,4,6,8; the first non-marked neighbour that is not higher ends the search (src/d8.cpp:444-451)
+#define TDX_SF2(K, ZN, LN, RN)                                                              \
+    if (!done) {                                                                             \
+        if ((RN) > 0) {                                                                      \
+            const float slope = (float)(f[K] * (double)(e2c - int(flat_elev2((LN), (RN), fl)))); \
+            if (slope > smax) { dir = int16_t(K); smax = slope; }                            \
+        } else if (z0 - (ZN) >= 0) { dir = int16_t(K); done = true; }                        \
+    }
+                TDX_SF2(1, c.z2, c.l2, c.r2) TDX_SF2(3, n.z1, n.l1, n.r1) TDX_SF2(5, c.z0, c.l0, c.r0) TDX_SF2(7, s.z1, s.l1, s.r1)
+                TDX_SF2(2, n.z2, n.l2, n.r2) TDX_SF2(4, n.z0, n.l0, n.r0) TDX_SF2(6, s.z0, s.l0, s.r0) TDX_SF2(8, s.z2, s.l2, s.r2)
+#undef TDX_SF2
+                P[idx] = dir;
+                if (dir == 0) keep |= 1u << r;
+            }
+        }
+        n = c; c = s;
+    }
+    unsigned long long pos = block_reserve(unsigned(__popc(keep)), counter);
+#pragma unroll
+    for (int r = 0; r < SLOPE_ROWS; r++)
+        if (keep & (1u << r)) qnext[pos++] = uint32_t(size_t(ybase + r) * size_t(nx) + size_t(x));
+}
+
 }  // namespace
 
 int tdx_build_fact_table(tdx_context* ctx, int64_t ny, const double* dxc, const double* dyc, double** d_fact_out) {
@@ -328,7 +389,11 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-                if (nq) {
+                if (nq > n / 32) {   // dense queue: one streaming pass
+                    const dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                    hipLaunchKernelGGL(d8_setflow2_stream_kernel, grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
+                                       d_cnt);
+                } else if (nq) {
                     if (fl.has_pits)
                         hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
                     hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
