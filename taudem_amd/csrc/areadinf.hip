@@ -66,24 +66,31 @@ __device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, con
     return prop_dev(an, (k + 4) % 8, rows[yn].a2);
 }
 
+// Per cell, once: which neighbours drain into it (bit k-1 of the low byte; the test of initNeighborDinfup,
+// src/commonLib.cpp:99-131) and whether any neighbour is missing (bit 8: outside the raster or nodata - the
+// contamination test of src/areadinf.cpp:196-199).  The walk then touches only real contributors: 1-3 proportion
+// evaluations per cell instead of 16.  With `cnt` the in-degree of every cell is initialised too.
 __global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata,
-                                                         const RowProp* __restrict__ rows, int32_t* __restrict__ cnt,
+                                                         const RowProp* __restrict__ rows, uint16_t* __restrict__ info, int32_t* __restrict__ cnt,
                                                          float* __restrict__ OUT, float out_nodata) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= ny) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    int32_t c = CNT_NOT_PART;
-    if (!is_nodata_f(ANG[idx], nodata)) {
-        c = 0;
-        for (int k = 1; k <= 8; k++) {
-            size_t n; bool miss;
-            const float p = (float)inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);   // `float p` in the reference (commonLib.cpp:99)
-            if (!miss && p > 0.0f) c++;
-        }
-        if (c == 0) c = CNT_SOURCE;
+    // the masks are kept for EVERY cell: an outlet may sit on a cell without an angle (e.g. the edge ring) and is then
+    // evaluated from the neighbours that drain into it (src/commonLib.cpp:165-233)
+    int32_t c = 0;
+    unsigned inf = 0;
+    for (int k = 1; k <= 8; k++) {
+        size_t n; bool miss;
+        const float p = (float)inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);   // `float p` in the reference (commonLib.cpp:99)
+        if (miss) inf |= 0x100u;
+        else if (p > 0.0f) { c++; inf |= 1u << (k - 1); }
     }
-    cnt[idx] = c;
+    if (c == 0) c = CNT_SOURCE;
+    if (is_nodata_f(ANG[idx], nodata)) c = CNT_NOT_PART;
+    info[idx] = uint16_t(inf);
+    if (cnt) cnt[idx] = c;
     OUT[idx] = out_nodata;
 }
 
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(256) void dinf_outlet_seed_kernel(const int32_t* __
 }
 
 // upstream closure of the outlets (src/commonLib.cpp:165-233)
-__global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata,
-                                                                 const RowProp* __restrict__ rows, const uint32_t* __restrict__ fin,
+__global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const uint16_t* __restrict__ info, int nx, int ny,
+                                                                 const uint32_t* __restrict__ fin,
                                                                  unsigned long long nin, int32_t* __restrict__ cnt, int32_t* __restrict__ mark,
                                                                  uint32_t* __restrict__ fout, unsigned long long* __restrict__ counter) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
@@ -122,13 +129,14 @@ __global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const float* __
     const size_t c = live ? size_t(fin[q]) : 0;
     const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
     int indeg = 0;
+    const unsigned inm = live ? unsigned(info[c]) & 0xFFu : 0u;
     for (int k = 1; k <= 8; k++) {
         bool push = false;
         size_t n = 0;
-        if (live) {
-            bool miss;
-            const float p = (float)inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
-            if (!miss && p > 0.f) { indeg++; push = (atomicCAS(&mark[n], 0, 1) == 0); }
+        if ((inm >> (k - 1)) & 1u) {
+            n = size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k));
+            indeg++;
+            push = (atomicCAS(&mark[n], 0, 1) == 0);
         }
         wave_append(push, uint32_t(n), fout, counter);
     }
@@ -139,18 +147,18 @@ __global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const float* __
 struct AreaAlg {   // src/areadinf.cpp:187-217
     const float* W;
     __device__ __forceinline__ float evaluate(const float* __restrict__ ANG, const RowProp* __restrict__ rows, float* __restrict__ OUT,
-                                              int nx, int ny, int x, int y, size_t idx, float nodata, int contcheck) const {
+                                              int nx, int x, int y, size_t idx, unsigned inf, int contcheck) const {
         float areares = 0.f;
-        bool con = false;
+        bool con = (inf & 0x100u) != 0u;
+#pragma unroll
         for (int k = 1; k <= 8; k++) {
-            size_t n; bool miss;
-            const double p = inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
-            if (miss) { con = true; continue; }
-            if (p > 0.0) {
-                const float v = ld_agent(&OUT[n]);
-                if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
-                else areares = (float)(areares + p * v);
-            }
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const int yn = y + d2(k);
+            const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
+            const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
+            const float v = ld_agent(&OUT[n]);
+            if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
+            else areares = (float)(areares + p * v);
         }
         if (W) areares = areares + W[idx];
         else areares = (float)(areares + rows[y].dx);
@@ -163,19 +171,19 @@ struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
     const float* DM;
     float dm_nodata;
     __device__ __forceinline__ float evaluate(const float* __restrict__ ANG, const RowProp* __restrict__ rows, float* __restrict__ OUT,
-                                              int nx, int ny, int x, int y, size_t idx, float nodata, int contcheck) const {
+                                              int nx, int x, int y, size_t idx, unsigned inf, int contcheck) const {
         float acc = W ? W[idx] : (float)rows[y].dx;
-        bool con = false;
+        bool con = (inf & 0x100u) != 0u;
+#pragma unroll
         for (int k = 1; k <= 8; k++) {
-            size_t n; bool miss;
-            const double p = inflow_prop(ANG, rows, nx, ny, x, y, k, nodata, &n, &miss);
-            if (miss) { con = true; continue; }
-            if (p > 0.) {
-                const float area = ld_agent(&OUT[n]);
-                const float dm = DM[n];
-                if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
-                else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
-            }
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const int yn = y + d2(k);
+            const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
+            const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
+            const float area = ld_agent(&OUT[n]);
+            const float dm = DM[n];
+            if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
+            else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
         }
         return (con && contcheck == 1) ? TDX_ANG_NODATA : acc;
     }
@@ -184,8 +192,8 @@ struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
 // walk from `start` (a ready cell) downstream while this lane keeps being the last contributor
 template <class Alg>
 __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                        float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
-                                                        uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
+                                                        const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt,
+                                                        float* __restrict__ OUT, uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                         unsigned long long ovf_cap, size_t start) {
     uint32_t stack[WALK_STACK];
     int sp = 0;
@@ -194,28 +202,41 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
     bool go = true;
     while (go) {
         const int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
-        const float v = alg.evaluate(ANG, rows, OUT, nx, ny, x, y, idx, nodata, contcheck);
+        const float ang = ANG[idx];
+        const double a2 = rows[y].a2;
+        const float v = alg.evaluate(ANG, rows, OUT, nx, x, y, idx, unsigned(info[idx]), contcheck);
         st_agent(&OUT[idx], v);
         done++;
         drain_stores();
         go = false;
-        const float ang = ANG[idx];
-        const double a2 = rows[y].a2;
-        for (int k = 1; k <= 8; k++) {
-            const double p = prop_dev(ang, k, a2);
-            if (p > 0.0) {
-                const int xn = x + d1(k), yn = y + d2(k);
-                if (xn >= 0 && xn < nx && yn >= 0 && yn < ny) {
-                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old == 1) {
-                        if (!go) { idx = n; go = true; }
-                        else if (sp < WALK_STACK) stack[sp++] = uint32_t(n);
-                        else {
-                            const unsigned long long slot = atomicAdd(ovf_count, 1ull);
-                            if (slot < ovf_cap) ovf[slot] = uint32_t(n);
-                        }
-                    }
+        // prop(ang, k) can be positive only for the two directions that bracket the angle (src/commonLib.cpp:83-88):
+        // sector i = number of aref[1..8] that are <= ang; candidates k = i and i % 8 + 1
+        int sector = 0;
+#pragma unroll
+        for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
+        const int s1 = sector < 1 ? 1 : sector;
+        size_t tn[2];
+        bool tv[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int k = (t == 0) ? s1 : (s1 % 8 + 1);
+            const int xn = x + d1(k), yn = y + d2(k);
+            tv[t] = prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+            tn[t] = tv[t] ? size_t(yn) * size_t(nx) + size_t(xn) : 0;
+        }
+        // both decrements are in flight together: one atomic round trip per cell, not one per downslope neighbour
+        int32_t old[2] = {0, 0};
+        if (tv[0]) old[0] = __hip_atomic_fetch_sub(&cnt[tn[0]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tv[1]) old[1] = __hip_atomic_fetch_sub(&cnt[tn[1]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (tv[t] && old[t] == 1) {
+                const size_t n = tn[t];
+                if (!go) { idx = n; go = true; }
+                else if (sp < WALK_STACK) stack[sp++] = uint32_t(n);
+                else {
+                    const unsigned long long slot = atomicAdd(ovf_count, 1ull);
+                    if (slot < ovf_cap) ovf[slot] = uint32_t(n);
                 }
             }
         }
@@ -226,7 +247,7 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
 
 template <class Alg>
 __global__ __launch_bounds__(256) void dinf_walk_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                        float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+                                                        const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
                                                         uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                         unsigned long long ovf_cap) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -234,18 +255,18 @@ __global__ __launch_bounds__(256) void dinf_walk_kernel(Alg alg, const float* __
     if (x >= nx || y >= ny) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     if (cnt[idx] != CNT_SOURCE) return;
-    dinf_walk(alg, ANG, rows, nx, ny, nodata, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, idx);
+    dinf_walk(alg, ANG, rows, nx, ny, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, idx);
 }
 
 template <class Alg>
 __global__ __launch_bounds__(256) void dinf_walk_list_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                             float nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+                                                             const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
                                                              const uint32_t* __restrict__ list, unsigned long long nlist,
                                                              uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                              unsigned long long ovf_cap) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nlist) return;
-    dinf_walk(alg, ANG, rows, nx, ny, nodata, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, size_t(list[q]));
+    dinf_walk(alg, ANG, rows, nx, ny, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, size_t(list[q]));
 }
 
 template <class Alg>
@@ -264,10 +285,11 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
     for (int64_t j = 0; j < ny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
     RowProp* d_rows = static_cast<RowProp*>(ctx->scratch(TDX_S_J, rows.size() * sizeof(RowProp)));
     int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+    uint16_t* info = static_cast<uint16_t*>(ctx->scratch(TDX_S_I, n * 2));
     const unsigned long long ovf_cap = n / 4 + 1024;
     uint32_t* ovfa = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ovf_cap) * 4));
     uint32_t* ovfb = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ovf_cap) * 4));
-    if (!d_rows || !cnt || !ovfa || !ovfb) return TDX_ERR_NOMEM;
+    if (!d_rows || !cnt || !info || !ovfa || !ovfb) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowProp), hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
@@ -277,7 +299,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     if (n_outlets < 0) {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, cnt, d_out, out_nodata);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     } else {
         TdxSpan sp(ctx, TDX_K_BFS);
@@ -288,7 +310,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
         int32_t* d_oy = static_cast<int32_t*>(ctx->scratch(TDX_S_F, size_t(n_outlets ? n_outlets : 1) * 4));
         if (!mark || !fa || !fb || !d_ox || !d_oy) return TDX_ERR_NOMEM;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, cnt, CNT_NOT_PART, n);
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_out, out_nodata, n);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, info, static_cast<int32_t*>(nullptr), d_out,
+                           out_nodata);
         TDX_HIP_CHECK(ctx, hipMemsetAsync(mark, 0, n * 4, s));
         unsigned long long ncur = 0;
         if (n_outlets > 0) {
@@ -303,8 +326,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
         uint32_t *cur = fa, *nxt = fb;
         while (ncur > 0) {
             TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(dinf_outlet_expand_kernel, dim3(tdx_blocks_for(ncur, 256)), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows,
-                               cur, ncur, cnt, mark, nxt, d_cnt);
+            hipLaunchKernelGGL(dinf_outlet_expand_kernel, dim3(tdx_blocks_for(ncur, 256)), dim3(256), 0, s, info, inx, iny, cur, ncur, cnt, mark, nxt,
+                               d_cnt);
             TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             ncur = ctx->h_mail[0];
@@ -316,7 +339,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
     int64_t rounds = 0;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, ang_nodata, contcheck, cnt, d_out,
+        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, info, contcheck, cnt, d_out,
                            ovfa, d_cnt, ovf_cap);
         rounds++;
         uint32_t *lst = ovfa, *nxt = ovfb;
@@ -327,7 +350,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
             if (novf == 0) break;
             if (novf > ovf_cap) return tdx_fail(ctx, TDX_ERR_NOMEM, "D-infinity accumulation overflow list exhausted");
             TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, ang_nodata,
+            hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, info,
                                contcheck, cnt, d_out, lst, novf, nxt, d_cnt, ovf_cap);
             std::swap(lst, nxt);
             rounds++;
