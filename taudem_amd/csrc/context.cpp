@@ -107,9 +107,9 @@ int tdx_context_create(int device, tdx_context** out) {
     TDX_HIP_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 64 * sizeof(uint64_t), hipHostMallocDefault));
-    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 64 * sizeof(uint64_t)));
-    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 64 * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 256 * sizeof(uint64_t), hipHostMallocDefault));
+    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 256 * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 256 * sizeof(uint64_t)));
     c->slots.resize(size_t(TDX_S_COUNT));
     *out = c;
     return TDX_OK;
@@ -123,6 +123,8 @@ void tdx_context_destroy(tdx_context* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->d_mail) (void)hipFree(c->d_mail);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

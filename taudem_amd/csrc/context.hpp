@@ -15,6 +15,8 @@
 struct tdx_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // second stream for side-by-side relaxations (created on first use)
+    hipEvent_t ev_fork = nullptr;
     std::string err;
     int num_cus = 256;
 
@@ -24,8 +26,8 @@ struct tdx_context {
     void* scratch(int slot, size_t bytes);   // returns nullptr + sets err on failure
 
     // pinned host mailbox for small device->host readbacks (counters, flags)
-    uint64_t* h_mail = nullptr;              // 64 words, hipHostMalloc
-    uint64_t* d_mail = nullptr;              // 64 words of device memory
+    uint64_t* h_mail = nullptr;              // 256 words, hipHostMalloc
+    uint64_t* d_mail = nullptr;              // 256 words of device memory
 
     // ---- timing ----
     struct Span { hipEvent_t a, b; int kclass; };
@@ -67,7 +69,7 @@ struct TdxSpan {
 // scratch slot ids (one namespace for all stages; stages never run concurrently on a context)
 enum {
     TDX_S_A = 0, TDX_S_B, TDX_S_C, TDX_S_D, TDX_S_E, TDX_S_F, TDX_S_G, TDX_S_H, TDX_S_I, TDX_S_J, TDX_S_K,
-    TDX_S_Q, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_COUNT
+    TDX_S_Q, TDX_S_L, TDX_S_M, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_COUNT
 };
 
 static inline int tdx_fail(tdx_context* ctx, int code, const std::string& msg) {

@@ -242,14 +242,28 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     rc = strip_exchange<int32_t>(ctx, st, b.rq, -1);
     if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
-    // ---- incfall ----
-    TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-    rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches);
-    if (rc != TDX_OK) return rc;
-    // ---- incrise ----
-    TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-    rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches);
-    if (rc != TDX_OK) return rc;
+    static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;
+    if (!st.multi() && !ctx->kernel_timing && !no_pair) {
+        // the two level fields are independent: relax them side by side on two streams (own flags / list / counts each)
+        uint32_t* flagsB = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * 2));
+        unsigned long long* countsB = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+        if (!flagsB || !countsB) return TDX_ERR_NOMEM;
+        uint32_t* listB = flagsB + ntiles;
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flagsB, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+        rc = tile_relax_run_pair(ctx, flatk::LevelOp{b.lvl, fmask}, tilek::Sched{flags, list, counts}, flatk::LevelOp{b.rq, rmask},
+                                 tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
+        if (rc != TDX_OK) return rc;
+    } else {
+        // ---- incfall ----
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+        rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches);
+        if (rc != TDX_OK) return rc;
+        // ---- incrise ----
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+        rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches);
+        if (rc != TDX_OK) return rc;
+    }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     if (nq) hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
     rc = flats_read_counters(ctx, 3);

@@ -531,6 +531,85 @@ struct Sched {
 
 }  // namespace tilek
 
+// The round schedule of ONE relaxation as a resumable object: batches of (compact, relax) launch pairs are enqueued on
+// `s`; after the stream has been synchronised collect() reads the batch's per-round tile counts and notes the first
+// empty round.  Two runners on two streams interleave two independent relaxations (tile_relax_run_pair).
+template <class Op>
+struct RoundRunner {
+    tdx_context* ctx; hipStream_t s; Op op; tilek::TileGeom g; tilek::Sched sc; uint64_t* h; unsigned long long* dbg;
+    int ntiles; unsigned cgrid, grid;
+    int r = 0, batch = 4, last_batch = 0;
+    bool done = false;
+    int64_t rounds = 0, launches = 0;
+    RoundRunner(tdx_context* c, hipStream_t st, Op o, tilek::TileGeom geom, tilek::Sched sched, uint64_t* host_mail, unsigned long long* d)
+        : ctx(c), s(st), op(o), g(geom), sc(sched), h(host_mail), dbg(d) {
+        ntiles = g.tiles_x * g.tiles_y;
+        cgrid = tdx_blocks_for(size_t(ntiles), 256);
+        grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
+    }
+    int start() {
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * tilek::COUNT_RING) * sizeof(unsigned long long), s));
+        return TDX_OK;
+    }
+    int enqueue() {
+        using namespace tilek;
+        if (r + batch > COUNT_RING) {
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
+            r = 0;
+        }
+        const bool timed = ctx->kernel_timing && s == ctx->stream;
+        for (int b = 0; b < batch; b++) {
+            hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, sc.list, sc.counts + r + b);
+            const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
+            hipLaunchKernelGGL((relax_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, sc.list, sc.counts + r + b, sc.flags, dbg);
+            ctx->span_end(sp);
+            if (timed && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
+        }
+        launches += batch;
+        last_batch = batch;
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(h, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        return TDX_OK;
+    }
+    void collect() {   // the stream must have been synchronised
+        for (int b = 0; b < last_batch; b++) {
+            if (h[b] == 0) { done = true; break; }
+            rounds++;
+        }
+        r += last_batch;
+        if (batch < 64) batch *= 2;
+    }
+};
+
+// Two independent relaxations (e.g. the two level fields of flat resolution) side by side on two streams: the rounds of
+// one fill the workgroup slots the other leaves idle.  Work already enqueued on the context's stream is waited for.
+template <class Op>
+static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op opB, tilek::Sched scB, tilek::TileGeom g, int64_t* rounds_out,
+                               int64_t* launches_out) {
+    if (!ctx->stream2) {
+        TDX_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    }
+    TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + 64, nullptr);
+    int rc = A.start();
+    if (rc != TDX_OK) return rc;
+    rc = B.start();
+    if (rc != TDX_OK) return rc;
+    while (!A.done || !B.done) {
+        const bool ra = !A.done, rb = !B.done;
+        if (ra) { rc = A.enqueue(); if (rc != TDX_OK) return rc; }
+        if (rb) { rc = B.enqueue(); if (rc != TDX_OK) return rc; }
+        if (ra) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (rb) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+        if (ra) A.collect();
+        if (rb) B.collect();
+    }
+    if (rounds_out) *rounds_out += A.rounds + B.rounds;
+    if (launches_out) *launches_out += A.launches + B.launches;
+    return TDX_OK;
+}
+
 // Runs the relaxation until no tile is active.  `flags` must hold the initially active tiles.
 // Default schedule: rounds.  TDX_RELAX_ASYNC=1 selects the asynchronous worklist (one launch); a worklist that gave
 // up on a bounded spin continues with rounds (values only ever decrease, so restarting from "all tiles active" is safe).
@@ -585,33 +664,17 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         }
     }
     if (need_rounds) {
-        const unsigned grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
-        int r = 0, batch = 4;
-        for (;;) {
-            if (r + batch > COUNT_RING) {
-                TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
-                r = 0;
-            }
-            for (int b = 0; b < batch; b++) {
-                hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, sc.list, sc.counts + r + b);
-                const int sp = ctx->kernel_timing ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
-                hipLaunchKernelGGL((relax_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, sc.list, sc.counts + r + b, sc.flags, dbg);
-                ctx->span_end(sp);
-                if (ctx->kernel_timing && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
-            }
-            launches += batch;
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
+        int rc = run.start();
+        if (rc != TDX_OK) return rc;
+        while (!run.done) {
+            rc = run.enqueue();
+            if (rc != TDX_OK) return rc;
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            bool done = false;
-            for (int b = 0; b < batch; b++) {
-                if (ctx->h_mail[b] == 0) { done = true; break; }
-                rounds++;
-            }
-            if (done) break;
-            r += batch;
-            if (batch < 64) batch *= 2;
+            run.collect();
         }
+        rounds += run.rounds;
+        launches += run.launches;
     }
     if (debug) {
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, dbg, 128, hipMemcpyDeviceToHost, s));
