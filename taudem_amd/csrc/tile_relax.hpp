@@ -531,6 +531,45 @@ struct Sched {
 
 }  // namespace tilek
 
+// Finishes a relaxation with the asynchronous worklist from the current activation flags (one launch on `s`).
+// Returns TDX_OK and sets *gave_up when a bounded spin gave up (the flags are then reset to "everything active").
+template <class Op>
+static int tile_relax_async_finish(tdx_context* ctx, hipStream_t s, Op op, tilek::TileGeom g, tilek::Sched sc, int ring_slot, uint64_t* host_mail,
+                                   unsigned long long* dbg, bool* gave_up) {
+    using namespace tilek;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const unsigned cgrid = tdx_blocks_for(size_t(ntiles), 256);
+    uint32_t cap = 1;
+    while (cap <= uint32_t(ntiles)) cap <<= 1;
+    uint32_t* ring = static_cast<uint32_t*>(ctx->scratch(ring_slot, size_t(cap) * 4));
+    if (!ring) return TDX_ERR_NOMEM;
+    AsyncCtl c;
+    c.ring = ring; c.mask = cap - 1u;
+    c.head = sc.counts + 0; c.tail = sc.counts + 1;   // control words at the start of the counts area
+    c.pending = reinterpret_cast<int*>(sc.counts + 2);
+    c.error = reinterpret_cast<unsigned*>(sc.counts + 3);
+    c.state = sc.list;   // the round schedule's tile list doubles as the per-tile state
+    c.spin_limit = getenv("TDX_ASYNC_SPIN") ? unsigned(atol(getenv("TDX_ASYNC_SPIN"))) : (1u << 21);
+    c.trace = dbg ? dbg + 2 : nullptr;
+    unsigned long long* count = sc.counts + 4;
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, 8 * sizeof(unsigned long long), s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(ring, 0, size_t(cap) * 4, s));
+    hipLaunchKernelGGL(async_fill_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, c, count);
+    hipLaunchKernelGGL(async_start_kernel, dim3(1), dim3(1), 0, s, c, count);
+    const unsigned grid = unsigned(std::min(ntiles, 4 * ctx->num_cus));
+    hipLaunchKernelGGL((relax_async_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, c, dbg);
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(host_mail, sc.counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const unsigned err = unsigned(host_mail[3] & 0xffffffffull);
+    *gave_up = err != 0;
+    if (err) {
+        fprintf(stderr, "taudem_amd: asynchronous tile worklist gave up (code %u, head %llu tail %llu pending %d); continuing with the round schedule\n", err,
+                (unsigned long long)host_mail[0], (unsigned long long)host_mail[1], int(host_mail[2] & 0xffffffffull));
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, FLAG_FULL, size_t(ntiles));
+    }
+    return TDX_OK;
+}
+
 // The round schedule of ONE relaxation as a resumable object: batches of (compact, relax) launch pairs are enqueued on
 // `s`; after the stream has been synchronised collect() reads the batch's per-round tile counts and notes the first
 // empty round.  Two runners on two streams interleave two independent relaxations (tile_relax_run_pair).
@@ -541,6 +580,7 @@ struct RoundRunner {
     int r = 0, batch = 4, last_batch = 0;
     bool done = false;
     int64_t rounds = 0, launches = 0;
+    unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
     RoundRunner(tdx_context* c, hipStream_t st, Op o, tilek::TileGeom geom, tilek::Sched sched, uint64_t* host_mail, unsigned long long* d)
         : ctx(c), s(st), op(o), g(geom), sc(sched), h(host_mail), dbg(d) {
         ntiles = g.tiles_x * g.tiles_y;
@@ -573,6 +613,7 @@ struct RoundRunner {
     void collect() {   // the stream must have been synchronised
         for (int b = 0; b < last_batch; b++) {
             if (h[b] == 0) { done = true; break; }
+            last_count = h[b];
             rounds++;
         }
         r += last_batch;
@@ -631,47 +672,33 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     int64_t rounds = 0, launches = 0;
     bool need_rounds = force_rounds;
     if (!force_rounds) {
-        uint32_t cap = 1;
-        while (cap <= uint32_t(ntiles)) cap <<= 1;
-        uint32_t* ring = static_cast<uint32_t*>(ctx->scratch(TDX_S_Q, size_t(cap) * 4));
-        if (!ring) return TDX_ERR_NOMEM;
-        // control words live at the start of the counts area (re-zeroed below if the round schedule is needed)
-        AsyncCtl c;
-        c.ring = ring; c.mask = cap - 1u;
-        c.head = sc.counts + 0; c.tail = sc.counts + 1;
-        c.pending = reinterpret_cast<int*>(sc.counts + 2);
-        c.error = reinterpret_cast<unsigned*>(sc.counts + 3);
-        c.state = sc.list;   // the round schedule's tile list doubles as the per-tile state
-        c.spin_limit = getenv("TDX_ASYNC_SPIN") ? unsigned(atol(getenv("TDX_ASYNC_SPIN"))) : (1u << 21);
-        c.trace = debug ? dbg + 2 : nullptr;
-        unsigned long long* count = sc.counts + 4;
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, 8 * sizeof(unsigned long long), s));
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(ring, 0, size_t(cap) * 4, s));
-        hipLaunchKernelGGL(async_fill_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, c, count);
-        hipLaunchKernelGGL(async_start_kernel, dim3(1), dim3(1), 0, s, c, count);
-        const unsigned grid = unsigned(std::min(ntiles, 5 * ctx->num_cus));
-        hipLaunchKernelGGL((relax_async_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, c, dbg);
+        bool gave_up = false;
+        int rc = tile_relax_async_finish(ctx, s, op, g, sc, TDX_S_Q, ctx->h_mail, dbg, &gave_up);
+        if (rc != TDX_OK) return rc;
         launches += 1;
         rounds += 1;
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, sc.counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        const unsigned err = unsigned(ctx->h_mail[3] & 0xffffffffull);
-        if (err) {
-            fprintf(stderr, "taudem_amd: asynchronous tile worklist gave up (code %u, head %llu tail %llu pending %d); continuing with the round schedule\n", err,
-                    (unsigned long long)ctx->h_mail[0], (unsigned long long)ctx->h_mail[1], int(ctx->h_mail[2] & 0xffffffffull));
-            hipLaunchKernelGGL(fill_u32_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, FLAG_FULL, size_t(ntiles));
-            need_rounds = true;
-        }
+        need_rounds = gave_up;
     }
     if (need_rounds) {
         RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
         int rc = run.start();
         if (rc != TDX_OK) return rc;
+        static const long hybrid = getenv("TDX_RELAX_HYBRID") ? atol(getenv("TDX_RELAX_HYBRID")) : 0;   // experiment: finish the tail asynchronously
         while (!run.done) {
             rc = run.enqueue();
             if (rc != TDX_OK) return rc;
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             run.collect();
+            if (hybrid > 0 && !run.done && run.rounds >= 8 && long(run.last_count) < hybrid) {
+                bool gave_up = false;
+                rc = tile_relax_async_finish(ctx, s, op, g, sc, TDX_S_Q, ctx->h_mail, dbg, &gave_up);
+                if (rc != TDX_OK) return rc;
+                launches += 1;
+                if (!gave_up) break;
+                rc = run.start();
+                if (rc != TDX_OK) return rc;
+                run.r = 0;
+            }
         }
         rounds += run.rounds;
         launches += run.launches;
