@@ -12,6 +12,7 @@
 // libm (one value per row); everything else is exactly-rounded +,-,/ on the device.
 #include "context.hpp"
 #include "device_common.hpp"
+#include "strips.hpp"
 
 namespace {
 using namespace tdxk;
@@ -19,6 +20,7 @@ using namespace tdxk;
 #define TDX_PI 3.14159265359   /* src/commonLib.h:76 */
 constexpr int32_t CNT_NOT_PART = 0x40000000;
 constexpr int32_t CNT_SOURCE = -1;
+constexpr int32_t CNT_DONE = -2;       // evaluated: what a strip neighbour looks for in the exchanged boundary rows
 constexpr int WALK_STACK = 8;
 
 struct RowProp { double a2; double dx; };   // a2 = atan2(dyc[j], dxc[j]) from the host libm
@@ -70,12 +72,12 @@ __device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, con
 // src/commonLib.cpp:99-131) and whether any neighbour is missing (bit 8: outside the raster or nodata - the
 // contamination test of src/areadinf.cpp:196-199).  The walk then touches only real contributors: 1-3 proportion
 // evaluations per cell instead of 16.  With `cnt` the in-degree of every cell is initialised too.
-__global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata,
+__global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict__ ANG, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                          const RowProp* __restrict__ rows, uint16_t* __restrict__ info, int32_t* __restrict__ cnt,
                                                          float* __restrict__ OUT, float out_nodata) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= ny) return;
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= y_own1) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     // the masks are kept for EVERY cell: an outlet may sit on a cell without an angle (e.g. the edge ring) and is then
     // evaluated from the neighbours that drain into it (src/commonLib.cpp:165-233)
@@ -191,8 +193,8 @@ struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
 
 // walk from `start` (a ready cell) downstream while this lane keeps being the last contributor
 template <class Alg>
-__device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                        const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt,
+__device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int y_own0,
+                                                        int y_own1, const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt,
                                                         float* __restrict__ OUT, uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                         unsigned long long ovf_cap, size_t start) {
     uint32_t stack[WALK_STACK];
@@ -206,6 +208,7 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
         const double a2 = rows[y].a2;
         const float v = alg.evaluate(ANG, rows, OUT, nx, x, y, idx, unsigned(info[idx]), contcheck);
         st_agent(&OUT[idx], v);
+        cnt[idx] = CNT_DONE;   // nobody decrements an evaluated cell any more
         done++;
         drain_stores();
         go = false;
@@ -221,7 +224,8 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
         for (int t = 0; t < 2; t++) {
             const int k = (t == 0) ? s1 : (s1 % 8 + 1);
             const int xn = x + d1(k), yn = y + d2(k);
-            tv[t] = prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+            // a target in a neighbour rank's row is released there, once this cell shows up as done in its halo row
+            tv[t] = prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1;
             tn[t] = tv[t] ? size_t(yn) * size_t(nx) + size_t(xn) : 0;
         }
         // both decrements are in flight together: one atomic round trip per cell, not one per downslope neighbour
@@ -246,60 +250,102 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
 }
 
 template <class Alg>
-__global__ __launch_bounds__(256) void dinf_walk_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                        const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+__global__ __launch_bounds__(256) void dinf_walk_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int y_own0,
+                                                        int y_own1, const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
                                                         uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                         unsigned long long ovf_cap) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= ny) return;
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= y_own1) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     if (cnt[idx] != CNT_SOURCE) return;
-    dinf_walk(alg, ANG, rows, nx, ny, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, idx);
+    dinf_walk(alg, ANG, rows, nx, y_own0, y_own1, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, idx);
 }
 
 template <class Alg>
-__global__ __launch_bounds__(256) void dinf_walk_list_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny,
-                                                             const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
+__global__ __launch_bounds__(256) void dinf_walk_list_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int y_own0,
+                                                             int y_own1, const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ OUT,
                                                              const uint32_t* __restrict__ list, unsigned long long nlist,
                                                              uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count,
                                                              unsigned long long ovf_cap) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nlist) return;
-    dinf_walk(alg, ANG, rows, nx, ny, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, size_t(list[q]));
+    dinf_walk(alg, ANG, rows, nx, y_own0, y_own1, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, size_t(list[q]));
+}
+
+// A halo row after an exchange: cells that the neighbouring rank has evaluated since the last look release the owned
+// cells they drain into (the role of addBorders() + the queue refill of src/areadinf.cpp:241-262).
+template <class Alg>
+__global__ __launch_bounds__(256) void dinf_halo_kernel(Alg alg, const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int y_own0,
+                                                        int y_own1, const uint16_t* __restrict__ info, int contcheck, int32_t* __restrict__ cnt,
+                                                        float* __restrict__ OUT, int yh, const float* __restrict__ recv_out,
+                                                        const int32_t* __restrict__ recv_cnt, uint32_t* __restrict__ ovf,
+                                                        unsigned long long* __restrict__ ovf_count, unsigned long long ovf_cap,
+                                                        unsigned long long* __restrict__ nchanged) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (x < nx) {
+        const size_t h = size_t(yh) * size_t(nx) + size_t(x);
+        if (recv_cnt[x] == CNT_DONE && cnt[h] != CNT_DONE) {
+            ch = true;
+            cnt[h] = CNT_DONE;
+            st_agent(&OUT[h], recv_out[x]);
+            drain_stores();
+            const float ang = ANG[h];
+            const double a2 = rows[yh].a2;
+            int sector = 0;
+#pragma unroll
+            for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
+            const int s1 = sector < 1 ? 1 : sector;
+            for (int t = 0; t < 2; t++) {
+                const int k = (t == 0) ? s1 : (s1 % 8 + 1);
+                const int xn = x + d1(k), yn = yh + d2(k);
+                if (prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
+                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == 1) dinf_walk(alg, ANG, rows, nx, y_own0, y_own1, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, n);
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(ch);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nchanged, (unsigned long long)__popcll(m));
 }
 
 template <class Alg>
-int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata, const double* dxc, const double* dyc,
-                   int contcheck, const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_out, float out_nodata,
+int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, float ang_nodata, const double* dxc, const double* dyc, int contcheck,
+                   const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_out, float out_nodata, float* d_dm, float dm_nodata,
                    tdx_stats* stats) {
-    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
-        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
     if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "outlets missing");
+    if (n_outlets >= 0 && st.multi()) return tdx_fail(ctx, TDX_ERR_ARG, "outlets are not supported on row strips yet");
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
-    const size_t n = size_t(nx) * size_t(ny);
+    const int inx = st.nx, iny = st.ny_arr;
+    const size_t n = size_t(inx) * size_t(iny);
     std::vector<RowProp> rows;
-    rows.resize(size_t(ny));
-    for (int64_t j = 0; j < ny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
+    rows.resize(size_t(iny));
+    for (int j = 0; j < iny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
     RowProp* d_rows = static_cast<RowProp*>(ctx->scratch(TDX_S_J, rows.size() * sizeof(RowProp)));
     int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
     uint16_t* info = static_cast<uint16_t*>(ctx->scratch(TDX_S_I, n * 2));
     const unsigned long long ovf_cap = n / 4 + 1024;
     uint32_t* ovfa = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ovf_cap) * 4));
     uint32_t* ovfb = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ovf_cap) * 4));
-    if (!d_rows || !cnt || !info || !ovfa || !ovfb) return TDX_ERR_NOMEM;
+    float* recvbuf = static_cast<float*>(ctx->scratch(TDX_S_K, size_t(inx) * 4 * 4));   // received OUT rows (up, down) and counter rows (up, down)
+    if (!d_rows || !cnt || !info || !ovfa || !ovfb || !recvbuf) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowProp), hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
-    const dim3 grid2d((inx + 63) / 64, (iny + 3) / 4);
+    const dim3 grid2d((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
 
     ctx->begin_call(stats);
+    int rc = strip_exchange<float>(ctx, st, d_ang, ang_nodata);   // angles of the neighbours' boundary rows
+    if (rc != TDX_OK) return rc;
+    if (d_dm) { rc = strip_exchange<float>(ctx, st, d_dm, dm_nodata); if (rc != TDX_OK) return rc; }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     if (n_outlets < 0) {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     } else {
         TdxSpan sp(ctx, TDX_K_BFS);
@@ -310,8 +356,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
         int32_t* d_oy = static_cast<int32_t*>(ctx->scratch(TDX_S_F, size_t(n_outlets ? n_outlets : 1) * 4));
         if (!mark || !fa || !fb || !d_ox || !d_oy) return TDX_ERR_NOMEM;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, cnt, CNT_NOT_PART, n);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, info, static_cast<int32_t*>(nullptr), d_out,
-                           out_nodata);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info,
+                           static_cast<int32_t*>(nullptr), d_out, out_nodata);
         TDX_HIP_CHECK(ctx, hipMemsetAsync(mark, 0, n * 4, s));
         unsigned long long ncur = 0;
         if (n_outlets > 0) {
@@ -336,31 +382,68 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const float* d_ang, int64_t nx, in
         }
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
     }
-    int64_t rounds = 0;
+    // halo rows of the result and of the counters start as "not evaluated"
+    rc = strip_exchange<float>(ctx, st, d_out, out_nodata);
+    if (rc != TDX_OK) return rc;
+    rc = strip_exchange<int32_t>(ctx, st, cnt, CNT_NOT_PART);
+    if (rc != TDX_OK) return rc;
+    int64_t rounds = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, info, contcheck, cnt, d_out,
-                           ovfa, d_cnt, ovf_cap);
-        rounds++;
         uint32_t *lst = ovfa, *nxt = ovfb;
-        for (;;) {   // drain cells that did not fit a lane's private stack
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        auto drain_overflow = [&]() -> int {   // cells that did not fit a lane's private stack
+            for (;;) {
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                const unsigned long long novf = ctx->h_mail[0];
+                if (novf == 0) return TDX_OK;
+                if (novf > ovf_cap) return tdx_fail(ctx, TDX_ERR_NOMEM, "D-infinity accumulation overflow list exhausted");
+                std::swap(lst, nxt);   // the list just filled becomes the input
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+                hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1,
+                                   info, contcheck, cnt, d_out, nxt, novf, lst, d_cnt, ovf_cap);
+                rounds++;
+            }
+        };
+        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out, lst,
+                           d_cnt, ovf_cap);
+        rounds++;
+        rc = drain_overflow();
+        if (rc != TDX_OK) return rc;
+        while (st.multi()) {
+            // boundary rows of the result and of the counters (evaluated cells carry CNT_DONE) to both neighbours
+            const size_t rowb = size_t(inx) * 4;
+            float *r_out_up = recvbuf, *r_out_dn = recvbuf + inx;
+            int32_t *r_cnt_up = reinterpret_cast<int32_t*>(recvbuf + 2 * size_t(inx)), *r_cnt_dn = reinterpret_cast<int32_t*>(recvbuf + 3 * size_t(inx));
+            rc = strip_exchange_buffers(ctx, st, d_out + size_t(st.y0) * inx, d_out + size_t(st.y1 - 1) * inx, r_out_up, r_out_dn, rowb);
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange_buffers(ctx, st, cnt + size_t(st.y0) * inx, cnt + size_t(st.y1 - 1) * inx, r_cnt_up, r_cnt_dn, rowb);
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
+            const unsigned gx = tdx_blocks_for(size_t(inx), 256);
+            if (st.up)
+                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
+                                   st.y0 - 1, r_out_up, r_cnt_up, lst, d_cnt, ovf_cap, d_cnt + 1);
+            if (st.down)
+                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
+                                   st.y1, r_out_dn, r_cnt_dn, lst, d_cnt, ovf_cap, d_cnt + 1);
+            rc = drain_overflow();
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            const unsigned long long novf = ctx->h_mail[0];
-            if (novf == 0) break;
-            if (novf > ovf_cap) return tdx_fail(ctx, TDX_ERR_NOMEM, "D-infinity accumulation overflow list exhausted");
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, iny, info,
-                               contcheck, cnt, d_out, lst, novf, nxt, d_cnt, ovf_cap);
-            std::swap(lst, nxt);
+            int64_t changed = int64_t(ctx->h_mail[0]);
+            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (changed == 0) break;
+            outer++;
             rounds++;
         }
         if (stats) stats->launches[TDX_K_ACCUM] += rounds;
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
-    tdx_stats* st = stats;
+    tdx_stats* stt = stats;
     ctx->end_call();
-    if (st) st->rounds = rounds;
+    if (stt) { stt->rounds = rounds; stt->cells_evaluated = outer; }
     return TDX_OK;
 }
 
@@ -370,16 +453,43 @@ extern "C" int tdx_areadinf_dev(tdx_context* ctx, const float* d_ang, int64_t nx
                                 const double* dxc, const double* dyc, const float* d_w, int contcheck,
                                 const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_sca, tdx_stats* stats) {
     if (!ctx || !d_ang || !d_sca || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_areadinf_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
     AreaAlg alg{d_w};
-    return run_dinf_accum(ctx, alg, d_ang, nx, ny, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets, d_sca, TDX_AREA_NODATA, stats);
+    return run_dinf_accum(ctx, alg, strip_single(int(nx), int(ny)), const_cast<float*>(d_ang), ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets,
+                          d_sca, TDX_AREA_NODATA, nullptr, 0.f, stats);
+}
+
+extern "C" int tdx_areadinf_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                                  const double* dxc, const double* dyc, const float* d_w, int contcheck, float* d_sca, tdx_stats* stats) {
+    if (!ctx || !d_ang || !d_sca || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_areadinf_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    AreaAlg alg{d_w};
+    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, nullptr, nullptr, -1, d_sca,
+                          TDX_AREA_NODATA, nullptr, 0.f, stats);
 }
 
 extern "C" int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
                                       const double* dxc, const double* dyc, const float* d_dm, float dm_nodata, const float* d_w, int contcheck,
                                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_dsca, tdx_stats* stats) {
     if (!ctx || !d_ang || !d_dm || !d_dsca || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfdecayaccum_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
     DecayAlg alg{d_w, d_dm, dm_nodata};
-    return run_dinf_accum(ctx, alg, d_ang, nx, ny, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets, d_dsca, TDX_ANG_NODATA, stats);
+    return run_dinf_accum(ctx, alg, strip_single(int(nx), int(ny)), const_cast<float*>(d_ang), ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_y, n_outlets,
+                          d_dsca, TDX_ANG_NODATA, nullptr, dm_nodata, stats);
+}
+
+extern "C" int tdx_dinfdecayaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                                        const double* dxc, const double* dyc, float* d_dm, float dm_nodata, const float* d_w, int contcheck,
+                                        float* d_dsca, tdx_stats* stats) {
+    if (!ctx || !d_ang || !d_dm || !d_dsca || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfdecayaccum_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    DecayAlg alg{d_w, d_dm, dm_nodata};
+    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, nullptr, nullptr, -1, d_dsca,
+                          TDX_ANG_NODATA, d_dm, dm_nodata, stats);
 }
 
 extern "C" int tdx_areadinf(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,

@@ -55,13 +55,13 @@ __device__ __forceinline__ void facet_geom(const RowGeom& g, int K, double& D1, 
     AD = one ? g.ad12 : g.ad21;
 }
 
-__global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict__ Z, int nx, int ny, float nodata,
+__global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                          const RowGeom* __restrict__ geom, float* __restrict__ ANG,
                                                          float* __restrict__ SLP, unsigned long long* __restrict__ nflat) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     bool flat = false;
-    if (x < nx && y < ny) {
+    if (x < nx && y < y_own1) {
         const size_t idx = size_t(y) * size_t(nx) + size_t(x);
         float ang = TDX_ANG_NODATA, slp = -1.0f;
         const float z0 = Z[idx];
@@ -114,10 +114,10 @@ struct DinfTraits {
 __device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, TDX_ANG_NODATA) && a < 0.0f; }
 
 // flat queue + markers (8 cells per lane, one atomic per block)
-__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t n, int32_t* __restrict__ lvl,
+__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, int32_t* __restrict__ lvl,
                                                                  int32_t* __restrict__ rq, uint32_t* __restrict__ list,
                                                                  unsigned long long* __restrict__ counter) {
-    const size_t base = size_t(blockIdx.x) * (256 * 8) + threadIdx.x;
+    const size_t base = first + size_t(blockIdx.x) * (256 * 8) + threadIdx.x;   // cells [first, n): the owned rows
     unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -224,19 +224,17 @@ __global__ __launch_bounds__(256) void dinf_recollect_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
-                                   const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats) {
-    if (!ctx || !d_fel || !d_ang || !d_slp || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir_dev: bad argument");
-    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
-        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+// One strip of setdir() (src/dinf.cpp:156-243); the same strip protocol as d8flowdir_impl (d8flowdir.hip).
+static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, float* d_ang,
+                            float* d_slp, tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
-    const size_t n = size_t(nx) * size_t(ny);
+    const int inx = st.nx, iny = st.ny_arr;
+    const size_t n = size_t(inx) * size_t(iny);
     // per-row geometry on the host (sqrt and atan2 from the host libm, src/dinf.cpp:575-576, 300, 466)
     std::vector<RowGeom> geom;
-    geom.resize(size_t(ny));
-    for (int64_t j = 0; j < ny; j++) {
+    geom.resize(size_t(iny));
+    for (int j = 0; j < iny; j++) {
         RowGeom g;
         g.dx = dxc[j]; g.dy = dyc[j];
         g.dd = sqrt(dxc[j] * dxc[j] + dyc[j] * dyc[j]);
@@ -251,64 +249,99 @@ extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
 
     ctx->begin_call(stats);
+    int rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
+    if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (iny + 3) / 4);
-        hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, fel_nodata, d_geom, d_ang, d_slp, d_cnt);
+        dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
+        hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geom, d_ang, d_slp, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    unsigned long long total = ctx->h_mail[0];
-    if (stats) { stats->flats_initial = int64_t(total); stats->flats_left = int64_t(total); }
+    unsigned long long nq = ctx->h_mail[0];   // flats of this strip
+    int64_t total = int64_t(nq);               // flats of the whole raster
+    rc = strip_allreduce(ctx, st, &total, 1, TDX_OP_SUM);
+    if (rc != TDX_OK) return rc;
+    if (stats) { stats->flats_initial = total; stats->flats_left = total; }
 
     if (total > 0) {
         int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
         int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
-        uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(total) * 4));
-        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(total) * 4));
+        uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(nq) * 4));
+        uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(nq) * 4));
         if (!lvl || !rq || !qlist || !qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;
         const float* zcur = d_fel;
         FlatBuffers fbuf{lvl, rq};
+        rc = strip_exchange<float>(ctx, st, d_ang, TDX_ANG_NODATA);   // angles of the neighbours' boundary rows
+        if (rc != TDX_OK) return rc;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(n, 2048)), dim3(256), 0, s, d_ang, n, lvl, rq, qlist, d_cnt);
-        unsigned long long nq = total, last = total;
+        const size_t own_first = size_t(st.y0) * size_t(inx), own_end = size_t(st.y1) * size_t(inx);
+        hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
+                           qlist, d_cnt);
+        rc = strip_exchange<int32_t>(ctx, st, lvl, -1);   // queue membership of the neighbours' boundary rows
+        if (rc != TDX_OK) return rc;
+        rc = strip_exchange<int32_t>(ctx, st, rq, -1);
+        if (rc != TDX_OK) return rc;
+        int64_t last = total;
         bool first = true;
-        int rc;
         for (;;) {
-            if (!first) { rc = flats_reset_markers(ctx, strip_single(inx, iny), qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
+            if (!first) { rc = flats_reset_markers(ctx, st, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
-            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, strip_single(inx, iny), qlist, nq, fbuf, &fl, stats);
+            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
-                if (fl.has_pits)
-                    hipLaunchKernelGGL(dinf_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
-                hipLaunchKernelGGL(dinf_set2flat_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-                hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_cnt);
+                if (nq) {
+                    if (fl.has_pits)
+                        hipLaunchKernelGGL(dinf_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
+                    hipLaunchKernelGGL(dinf_set2flat_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
+                    hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_cnt);
+                }
                 TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
             }
-            total = ctx->h_mail[0];
-            if (stats) { stats->flat_iterations++; stats->flats_left = int64_t(total); }
+            const unsigned long long nleft = ctx->h_mail[0];
+            total = int64_t(nleft);
+            rc = strip_allreduce(ctx, st, &total, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange<float>(ctx, st, d_ang, TDX_ANG_NODATA);   // the neighbours' new angles
+            if (rc != TDX_OK) return rc;
+            if (stats) { stats->flat_iterations++; stats->flats_left = total; }
             if (!(total > 0 && total < last)) break;     // src/dinf.cpp:230
             if (!zwork) { zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4)); if (!zwork) return TDX_ERR_NOMEM; }
             rc = flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);   // src/dinf.cpp:822-828
             if (rc != TDX_OK) return rc;
             zcur = zwork;
             std::swap(qlist, qnext);
-            nq = total; last = total;
+            nq = nleft; last = total;
         }
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
     ctx->end_call();
     return TDX_OK;
+}
+
+extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
+                                   const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_ang || !d_slp || !dxc || !dyc || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return dinfflowdir_impl(ctx, strip_single(int(nx), int(ny)), const_cast<float*>(d_fel), fel_nodata, dxc, dyc, d_ang, d_slp, stats);
+}
+
+extern "C" int tdx_dinfflowdir_strip(tdx_context* ctx, const tdx_comm* comm, float* d_fel, int64_t nx, int64_t ny_local, float fel_nodata,
+                                     const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats) {
+    if (!ctx || !d_fel || !d_ang || !d_slp || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfflowdir_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    return dinfflowdir_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_fel, fel_nodata, dxc, dyc, d_ang, d_slp, stats);
 }
 
 extern "C" int tdx_dinfflowdir(tdx_context* ctx, const float* fel, int64_t nx, int64_t ny, float fel_nodata,

@@ -180,3 +180,47 @@ class StripPipeline:
         check(self.ctx._lib.tdx_aread8_strip(self.ctx._h, self._cp, _tptr(p, torch.int16, self.shape, "p"), self.nx, self.ny_local, int(nodata),
                                              int(bool(contcheck)), _tptr(ad8, torch.float32, self.shape, "ad8"), C.byref(st)), self.ctx._h)
         return ad8, st.as_dict()
+
+    def _cells(self, dx, dy):
+        rows = self.ny_local + 2
+        dxc = np.ascontiguousarray(np.broadcast_to(np.asarray(dx, dtype=np.float64), (rows,)))
+        dyc = np.ascontiguousarray(np.broadcast_to(np.asarray(dy, dtype=np.float64), (rows,)))
+        return dxc, dyc
+
+    def dinfflowdir(self, fel, nodata=-3.0e38, dx=1.0, dy=1.0, out=None):
+        torch = self.torch
+        dxc, dyc = self._cells(dx, dy)
+        ang = out[0] if out is not None else self.empty(torch.float32)
+        slp = out[1] if out is not None else self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_dinfflowdir_strip(self.ctx._h, self._cp, _tptr(fel, torch.float32, self.shape, "fel"), self.nx, self.ny_local,
+                                                  float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                  _tptr(ang, torch.float32, self.shape, "ang"), _tptr(slp, torch.float32, self.shape, "slp"), C.byref(st)),
+              self.ctx._h)
+        return ang, slp, st.as_dict()
+
+    def areadinf(self, ang, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contcheck=True, out=None):
+        torch = self.torch
+        dxc, dyc = self._cells(dx, dy)
+        sca = out if out is not None else self.empty(torch.float32)
+        pw = _tptr(weights, torch.float32, self.shape, "weights") if weights is not None else None
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_areadinf_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local, float(nodata),
+                                               C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pw, int(bool(contcheck)),
+                                               _tptr(sca, torch.float32, self.shape, "sca"), C.byref(st)), self.ctx._h)
+        return sca, st.as_dict()
+
+    def dinfdecayaccum(self, ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, out=None):
+        torch = self.torch
+        dxc, dyc = self._cells(dx, dy)
+        dsca = out if out is not None else self.empty(torch.float32)
+        pw = _tptr(weights, torch.float32, self.shape, "weights") if weights is not None else None
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_dinfdecayaccum_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local,
+                                                     float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
+                                                     _tptr(dm, torch.float32, self.shape, "dm"), float(dm_nodata), pw, int(bool(contcheck)),
+                                                     _tptr(dsca, torch.float32, self.shape, "dsca"), C.byref(st)), self.ctx._h)
+        return dsca, st.as_dict()

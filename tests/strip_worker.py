@@ -86,7 +86,8 @@ def gpu_test(case):
     ndev = torch.cuda.device_count()
     device = int(os.environ.get("LOCAL_RANK", "0")) % ndev
     torch.cuda.set_device(device)
-    dem, env = make_case(case, O)
+    dinf = case.endswith("+dinf")
+    dem, env = make_case(case.replace("+dinf", ""), O)
     os.environ.update(env)
     ny, nx = dem.shape
     y0, y1 = partition_rows(ny, size)[rank]
@@ -103,6 +104,18 @@ def gpu_test(case):
     for cc in (True, False):
         a, st3 = pipe.aread8(p, -32768, contcheck=cc)
         outs[f"ad8_{int(cc)}"] = a.clone()
+    if dinf:
+        rng = np.random.default_rng(17)
+        wgt = (rng.random(dem.shape, dtype=np.float32) * 3.0).astype(np.float32)
+        dmf = (0.9 + 0.1 * rng.random(dem.shape, dtype=np.float32)).astype(np.float32)
+        d_w = pipe.empty(torch.float32); d_w.zero_(); d_w[1:nyl + 1] = torch.from_numpy(wgt[y0:y1]).to(d_w.device)
+        d_dm = pipe.empty(torch.float32); d_dm.zero_(); d_dm[1:nyl + 1] = torch.from_numpy(dmf[y0:y1]).to(d_dm.device)
+        ang, slp, std = pipe.dinfflowdir(fel, -3.0e38, 30.0, 20.0)
+        outs["ang"], outs["slp"] = ang, slp
+        outs["sca"] = pipe.areadinf(ang, dx=30.0, dy=20.0, contcheck=True)[0].clone()
+        outs["sca_w_nc"], sta = pipe.areadinf(ang, dx=30.0, dy=20.0, weights=d_w, contcheck=False)
+        outs["sca_w_nc"] = outs["sca_w_nc"].clone()
+        outs["dsca_nc"] = pipe.dinfdecayaccum(ang, d_dm, dx=30.0, dy=20.0, contcheck=False)[0].clone()
     gathered = {}
     for k, t in outs.items():
         mine = t[1:nyl + 1].cpu().contiguous()
@@ -131,6 +144,16 @@ def gpu_test(case):
             a_o = O.aread8(p_o, -32768, contcheck=cc)
             g = gathered[f"ad8_{int(cc)}"]
             assert same(g, a_o), f"{case}: ad8 contcheck={cc} differs from the oracle ({(g != a_o).sum()} cells)"
+        if dinf:
+            ang_o, slp_o, _ = O.dinfflowdir(fel_o, -3.0e38, 30.0, 20.0)
+            assert same(gathered["ang"], ang_o), f"{case}: ang differs from the oracle ({(gathered['ang'] != ang_o).sum()} cells)"
+            assert same(gathered["slp"], slp_o), f"{case}: slp differs"
+            def close(a, b, name):   # gate of the north star: 1e-6 relative on D-infinity areas (observed: identical bits)
+                ok = (a == b) | (np.abs(a - b) <= 1e-6 * np.abs(b))
+                assert ok.all(), f"{case}: {name}: {(~ok).sum()} cells beyond 1e-6 relative"
+            close(gathered["sca"], O.areadinf(ang_o, dx=30.0, dy=20.0, contcheck=True), "sca")
+            close(gathered["sca_w_nc"], O.areadinf(ang_o, dx=30.0, dy=20.0, weights=wgt, contcheck=False), "sca_w_nc")
+            close(gathered["dsca_nc"], O.dinfdecayaccum(ang_o, dmf, dx=30.0, dy=20.0, contcheck=False), "dsca_nc")
         print(f"strip_worker {case}: {size} ranks bit-exact vs oracle; pit outer rounds {st1['cells_evaluated']}, "
               f"flat iterations {st2['flat_iterations']}, ad8 outer rounds {st3['rounds']}, exchanges {comm.exchanges}, allreduces {comm.allreduces}",
               flush=True)

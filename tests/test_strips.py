@@ -43,7 +43,7 @@ def test_stripcomm_protocol_gloo(nproc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,case", [(2, "plain"), (3, "short_strips"), (2, "holes"), (4, "big"), (1, "plain"), (4, "wide")])
+@pytest.mark.parametrize("nproc,case", [(2, "plain"), (3, "short_strips"), (2, "holes"), (4, "big"), (1, "plain"), (4, "wide"), (2, "plain+dinf"), (3, "holes+dinf"), (4, "short_strips+dinf")])
 def test_strips_bit_exact_vs_oracle(nproc, case):
     out = _launch(nproc, ["--case", case], timeout=900)
     assert f"{nproc} ranks bit-exact vs oracle" in out
