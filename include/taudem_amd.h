@@ -204,6 +204,12 @@ int tdx_dinfdecayaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_an
 int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                      int contcheck, float* d_ad8, tdx_stats* stats);
 
+/* weights and/or outlets on a strip.  outlet_x / outlet_row: HOST arrays in STRIP-ARRAY coordinates (row 1 = first owned
+ * row; outlets outside the owned rows are ignored, like isInPartition, src/commonLib.cpp:289-291); n_outlets < 0 = none */
+int tdx_aread8_strip_ex(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                        const float* d_w, float w_nodata, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
+                        int64_t n_outlets, float* d_ad8, tdx_stats* stats);
+
 /* ---- synthetic benchmark input (not in the reference) -------------------------------------- */
 /* Fills d_out (nx*ny float32) with the seeded fractal surface of taudem_amd/csrc/synth_dem.h for
  * the window whose top-left global cell is (x0,y0).  Bit-identical to the host generator. */

@@ -17,6 +17,7 @@
 //   outlets            reverse BFS from the outlet cells marks the upstream closure (frontier sweeps)
 #include "context.hpp"
 #include "device_common.hpp"
+#include "flats.hpp"
 #include "strips.hpp"
 
 #include <cstdlib>
@@ -29,6 +30,14 @@ constexpr int32_t CNT_NOT_PART = 0x40000000;   // never reaches 0: the reference
 // driven to 0 by its contributors (that cell is evaluated by its last contributor's lane, and its own
 // lane may start later and must not evaluate it again), so sources carry a value no decrement produces.
 constexpr int32_t CNT_SOURCE = -1;
+constexpr int32_t CNT_DONE = -2;        // evaluated: what a strip neighbour looks for in the exchanged boundary rows
+
+// Outlets mode runs the ordinary sweep on a re-coded direction grid P' (d8_apply_reach_kernel): cells outside the
+// upstream closure of the outlets keep "a valid direction" for the contamination test but neither participate nor
+// contribute (codes 16..24 = 16 + p); an outlet placed on a cell without direction participates as a pure sink
+// (code 32) - the reference evaluates such a cell from the neighbours that drain into it (src/commonLib.cpp:285-359).
+constexpr int16_t P_OUTSIDE = 16, P_SINK = 32;
+__device__ __forceinline__ bool d8_participates(int16_t p, int16_t nodata) { return !is_nodata_s(p, nodata) && ((p >= 0 && p <= 8) || p == P_SINK); }
 
 // in-degree as in initNeighborD8up (src/commonLib.cpp:251-282)
 __device__ __forceinline__ int d8_indegree(const int16_t* __restrict__ P, int nx, int ny, int x, int y, int16_t nodata) {
@@ -44,15 +53,15 @@ __device__ __forceinline__ int d8_indegree(const int16_t* __restrict__ P, int nx
     return cnt;
 }
 
-__global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata,
+__global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
                                                         int32_t* __restrict__ cnt, float* __restrict__ A) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= ny) return;
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= y_own1) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     const int16_t p = P[idx];
     int32_t c = CNT_NOT_PART;
-    if (!is_nodata_s(p, nodata) && p >= 0 && p <= 8) {
+    if (d8_participates(p, nodata)) {
         c = d8_indegree(P, nx, ny, x, y, nodata);
         if (c == 0) c = CNT_SOURCE;
     }
@@ -60,51 +69,40 @@ __global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restric
     A[idx] = TDX_AREA_NODATA;
 }
 
-// outlets mode: cnt pre-filled with CNT_NOT_PART, A with -1; frontier cells get their in-degree and
-// push their contributing neighbours (src/commonLib.cpp:312-359)
-__global__ __launch_bounds__(256) void ad8_outlet_expand_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata,
-                                                                const uint32_t* __restrict__ fin, unsigned long long nin,
-                                                                int32_t* __restrict__ cnt, int32_t* __restrict__ mark,
-                                                                uint32_t* __restrict__ fout, unsigned long long* __restrict__ counter) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = q < nin;
-    const size_t c = live ? size_t(fin[q]) : 0;
-    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-    int indeg = 0;
-#pragma unroll
-    for (int k = 1; k <= 8; k++) {
-        bool push = false;
-        size_t n = 0;
-        if (live) {
-            const int xn = x + d1(k), yn = y + d2(k);
-            if (xn >= 0 && xn < nx && yn >= 0 && yn < ny) {
-                n = size_t(yn) * size_t(nx) + size_t(xn);
-                const int16_t pn = P[n];
-                if (!is_nodata_s(pn, nodata) && pn >= 0 && pn <= 8 && (pn - k == 4 || pn - k == -4)) {
-                    indeg++;
-                    push = (atomicCAS(&mark[n], 0, 1) == 0);
-                }
-            }
-        }
-        wave_append(push, uint32_t(n), fout, counter);
+// ---- outlets: upstream closure through the tile relaxation engine (flats.hpp: reach_closure) ----
+// mask of the reachability relaxation: the neighbour a cell drains to; a p == 0 cell counts as draining to its
+// south-east neighbour, because initNeighborD8up counts it in that neighbour's in-degree (src/commonLib.cpp:257-266)
+__global__ __launch_bounds__(256) void d8_reach_mask_kernel(const int16_t* __restrict__ P, size_t n, int16_t nodata, uint8_t* __restrict__ mask) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int16_t p = P[i];
+    unsigned m = 0;
+    if (!is_nodata_s(p, nodata)) {
+        if (p >= 1 && p <= 8) m = 1u << (p - 1);
+        else if (p == 0) m = 1u << 7;
     }
-    if (live) cnt[c] = indeg ? indeg : CNT_SOURCE;
+    mask[i] = uint8_t(m);
 }
-
-__global__ __launch_bounds__(256) void ad8_outlet_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout,
-                                                              int nx, int ny, int32_t* __restrict__ mark, uint32_t* __restrict__ fout,
-                                                              unsigned long long* __restrict__ counter) {
+// outlet cells (array coordinates; only those in the owned rows): reach = 1 and their tile is activated
+__global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int y_own0,
+                                                         int y_own1, int tiles_x, int32_t* __restrict__ reach, uint32_t* __restrict__ tile_flags) {
     const int o = blockIdx.x * 256 + threadIdx.x;
-    bool push = false;
-    uint32_t c = 0;
-    if (o < nout) {
-        const int x = ox[o], y = oy[o];
-        if (x >= 0 && x < nx && y >= 0 && y < ny) {   // globalToLocal + isInPartition (src/commonLib.cpp:289-291)
-            c = uint32_t(size_t(y) * size_t(nx) + size_t(x));
-            push = (atomicCAS(&mark[c], 0, 1) == 0);
-        }
-    }
-    wave_append(push, c, fout, counter);
+    if (o >= nout) return;
+    const int x = ox[o], y = oy[o];
+    if (x < 0 || x >= nx || y < y_own0 || y >= y_own1) return;   // globalToLocal + isInPartition (src/commonLib.cpp:289-291)
+    reach[size_t(y) * size_t(nx) + size_t(x)] = 1;
+    tile_flags[(y / tilek::TS) * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+}
+__global__ __launch_bounds__(256) void d8_apply_reach_kernel(const int16_t* __restrict__ P, const int32_t* __restrict__ reach, size_t n, int16_t nodata,
+                                                             int16_t* __restrict__ Pout) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int16_t p = P[i];
+    const bool valid = !is_nodata_s(p, nodata) && p >= 0 && p <= 8;
+    int16_t q;
+    if (reach[i] == 1) q = valid ? p : P_SINK;
+    else q = valid ? int16_t(p + P_OUTSIDE) : p;
+    Pout[i] = q;
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
@@ -140,35 +138,65 @@ __device__ __forceinline__ float ad8_evaluate(const int16_t* __restrict__ P, con
     return a;
 }
 
-__global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata,
-                                                       int nx, int ny, int16_t nodata, int contcheck, int32_t* __restrict__ cnt,
-                                                       float* __restrict__ A, unsigned long long* __restrict__ nevaluated) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    unsigned long long done = 0;
-    bool go = false;
-    size_t idx = 0;
-    if (x < nx && y < ny) {
-        idx = size_t(y) * size_t(nx) + size_t(x);
-        go = (cnt[idx] == CNT_SOURCE);          // participates and has no contributor
-    }
-    while (go) {
+// evaluate idx and keep walking downstream through OWNED cells while this lane is the last contributor
+__device__ __forceinline__ void ad8_walk_from(size_t idx, const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata, int nx, int ny,
+                                              int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A) {
+    int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
+    for (;;) {
         const float a = ad8_evaluate(P, Wt, w_nodata, A, nx, ny, x, y, idx, nodata, contcheck);
         st_agent(&A[idx], a);
-        done++;
-        go = false;
+        cnt[idx] = CNT_DONE;   // nobody decrements an evaluated cell any more
         const int16_t k = P[idx];
-        if (k >= 1 && k <= 8) {
-            const int xn = x + d1(k), yn = y + d2(k);
-            if (xn >= 0 && xn < nx && yn >= 0 && yn < ny) {
-                const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-                drain_stores();                 // value must be at the coherence point before the counter moves
-                const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == 1) { x = xn; y = yn; idx = n; go = true; }   // I was the last contributor
+        if (k < 1 || k > 8) return;
+        const int xn = x + d1(k), yn = y + d2(k);
+        if (xn < 0 || xn >= nx || yn < y_own0 || yn >= y_own1) return;   // off the raster, or a neighbour rank's row (released there)
+        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+        drain_stores();                 // value must be at the coherence point before the counter moves
+        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != 1) return;           // somebody else is the last contributor
+        x = xn; y = yn; idx = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata,
+                                                       int nx, int ny, int y_own0, int y_own1, int16_t nodata, int contcheck,
+                                                       int32_t* __restrict__ cnt, float* __restrict__ A) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= y_own1) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    if (cnt[idx] != CNT_SOURCE) return;          // participates and has no contributor
+    ad8_walk_from(idx, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+}
+
+// A halo row after an exchange: cells the neighbouring rank has evaluated since the last look release the owned cell
+// they drain into (addBorders + queue refill of src/aread8.cpp:282-303)
+__global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata, int nx, int ny,
+                                                       int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt,
+                                                       float* __restrict__ A, int yh, const float* __restrict__ recv_a, const int32_t* __restrict__ recv_cnt,
+                                                       unsigned long long* __restrict__ nchanged) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (x < nx) {
+        const size_t h = size_t(yh) * size_t(nx) + size_t(x);
+        if (recv_cnt[x] == CNT_DONE && cnt[h] != CNT_DONE) {
+            ch = true;
+            cnt[h] = CNT_DONE;
+            st_agent(&A[h], recv_a[x]);
+            const int16_t k = P[h];
+            if (!is_nodata_s(k, nodata) && k >= 1 && k <= 8) {
+                const int xn = x + d1(k), yn = yh + d2(k);
+                if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
+                    const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+                    drain_stores();
+                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == 1) ad8_walk_from(n, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+                }
             }
         }
     }
-    (void)done; (void)nevaluated;
+    const unsigned long long m = __ballot(ch);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nchanged, (unsigned long long)__popcll(m));
 }
 
 
@@ -268,7 +296,7 @@ __device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, i
         sP[e] = v;
     }
 }
-__device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && p >= 0 && p <= 8; }
+__device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && ((p >= 0 && p <= 8) || p == P_SINK); }
 __device__ __forceinline__ bool in_tile(int lx, int ly, int rv) { return lx >= 0 && lx < TS && ly >= 0 && ly < rv; }
 
 // topology of the in-tile cell (lx, ly) from the staged tile (initNeighborD8up, src/commonLib.cpp:251-282,
@@ -290,7 +318,7 @@ __device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly,
             else if (in_tile(nlx, nly, rv)) t.indeg++;
         }
     }
-    if (p >= 1) {
+    if (p >= 1 && p <= 8) {
         const int tlx = lx + d1(p), tly = ly + d2(p);
         if (p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) t.tgt = in_tile(tlx, tly, rv) ? int16_t(tly * TS + tlx) : int16_t(-2);
     }
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         const int gx = x0 + lx, gy = ya0 + ly;
         const int16_t p = sP[(ly + 1) * TH + lx + 1];
         int16_t tgt = -1;
-        if (ly < rv && p_part(p, nodata) && p >= 1) {
+        if (ly < rv && p_part(p, nodata) && p >= 1 && p <= 8) {
             const int tlx = lx + d1(p), tly = ly + d2(p);
             if (in_tile(tlx, tly, rv) && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt = int16_t(tly * TS + tlx);
         }
@@ -731,13 +759,122 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     return TDX_OK;
 }
 
+// One strip of aread8() (src/aread8.cpp:175-307).  Outlets (array coordinates) restrict the sweep to their upstream
+// closure; unit weights without TDX_AD8_WALK take the tile-contraction path, everything else the exact pull walk.
+static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_nodata, const float* d_w, float w_nodata, int contcheck,
+                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_ad8, tdx_stats* stats) {
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int inx = st.nx, iny = st.ny_arr;
+    const size_t n = size_t(inx) * size_t(iny);
+    const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
+    const bool tiled = !d_w && n < (size_t(1) << 30) && !force_walk;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
+    int16_t* p_use = d_p;
+    int rc;
+    if (n_outlets >= 0) {
+        // upstream closure of the outlets, then the ordinary sweep on the re-coded directions
+        rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);
+        if (rc != TDX_OK) return rc;
+        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+        int32_t* reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
+        uint8_t* mask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
+        int16_t* pprime = static_cast<int16_t*>(ctx->scratch(TDX_S_P, n * 2));
+        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * 2));
+        unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+        int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
+        if (!reach || !mask || !pprime || !flags || !counts || !d_oxy) return TDX_ERR_NOMEM;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(reach, 0, n * 4, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+        hipLaunchKernelGGL(d8_reach_mask_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, n, p_nodata, mask);
+        if (n_outlets > 0) {
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets), inx,
+                               st.y0, st.y1, geom.tiles_x, reach, flags);
+        }
+        int64_t rr = 0, ll = 0;
+        rc = reach_closure(ctx, st, reach, mask, flags, flags + ntiles, counts, &rr, &ll);
+        if (rc != TDX_OK) return rc;
+        hipLaunchKernelGGL(d8_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, reach, n, p_nodata, pprime);
+        p_use = pprime;
+    }
+    if (tiled) return aread8_tiled(ctx, st, p_use, p_nodata, contcheck, d_ad8, stats);
+
+    // ---- exact pull walk (weights / TDX_AD8_WALK) ----
+    int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+    float* recvbuf = static_cast<float*>(ctx->scratch(TDX_S_K, size_t(inx) * 4 * 4));
+    if (!cnt || !recvbuf) return TDX_ERR_NOMEM;
+    const dim3 grid2d((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
+    ctx->begin_call(stats);
+    rc = strip_exchange<int16_t>(ctx, st, p_use, p_nodata);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(ad8_setup_kernel, grid2d, dim3(256), 0, s, p_use, inx, iny, st.y0, st.y1, p_nodata, cnt, d_ad8);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);
+    if (rc != TDX_OK) return rc;
+    rc = strip_exchange<int32_t>(ctx, st, cnt, CNT_NOT_PART);
+    if (rc != TDX_OK) return rc;
+    int64_t outer = 1;
+    {
+        TdxSpan sp(ctx, TDX_K_ACCUM);
+        hipLaunchKernelGGL(ad8_walk_kernel, grid2d, dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8);
+        if (stats) stats->launches[TDX_K_ACCUM]++;
+        while (st.multi()) {
+            const size_t rowb = size_t(inx) * 4;
+            float *r_a_up = recvbuf, *r_a_dn = recvbuf + inx;
+            int32_t *r_c_up = reinterpret_cast<int32_t*>(recvbuf + 2 * size_t(inx)), *r_c_dn = reinterpret_cast<int32_t*>(recvbuf + 3 * size_t(inx));
+            rc = strip_exchange_buffers(ctx, st, d_ad8 + size_t(st.y0) * inx, d_ad8 + size_t(st.y1 - 1) * inx, r_a_up, r_a_dn, rowb);
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange_buffers(ctx, st, cnt + size_t(st.y0) * inx, cnt + size_t(st.y1 - 1) * inx, r_c_up, r_c_dn, rowb);
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
+            const unsigned gx = tdx_blocks_for(size_t(inx), 256);
+            if (st.up)
+                hipLaunchKernelGGL(ad8_halo_kernel, dim3(gx), dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8,
+                                   st.y0 - 1, r_a_up, r_c_up, d_cnt + 1);
+            if (st.down)
+                hipLaunchKernelGGL(ad8_halo_kernel, dim3(gx), dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8,
+                                   st.y1, r_a_dn, r_c_dn, d_cnt + 1);
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            int64_t changed = int64_t(ctx->h_mail[0]);
+            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (stats) stats->launches[TDX_K_ACCUM]++;
+            if (changed == 0) break;
+            outer++;
+        }
+    }
+    TDX_HIP_CHECK(ctx, hipGetLastError());
+    tdx_stats* stt = stats;
+    ctx->end_call();
+    if (stt) stt->rounds = outer;
+    return TDX_OK;
+}
+
 extern "C" int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                                 int contcheck, float* d_ad8, tdx_stats* stats) {
     if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: bad argument");
     if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) >= (uint64_t(1) << 30))
         return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: at most 2^30 cells per device strip");
-    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return aread8_tiled(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, contcheck, d_ad8, stats);
+    return aread8_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, nullptr, 0.f, contcheck, nullptr, nullptr, -1, d_ad8, stats);
+}
+
+extern "C" int tdx_aread8_strip_ex(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                                   const float* d_w, float w_nodata, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
+                                   int64_t n_outlets, float* d_ad8, tdx_stats* stats) {
+    if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip_ex: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    if (n_outlets > 0 && (!outlet_x || !outlet_row)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip_ex: outlets missing");
+    return aread8_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, d_w, w_nodata, contcheck, outlet_x, outlet_row, n_outlets, d_ad8,
+                       stats);
 }
 
 extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
@@ -747,71 +884,9 @@ extern "C" int tdx_aread8_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, 
     if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_dev: bad argument");
     if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
         return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
-    if (n_outlets >= 0 && n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_dev: outlets missing");
-    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
-    const size_t n = size_t(nx) * size_t(ny);
-    const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
-    if (!d_w && n_outlets < 0 && n < (size_t(1) << 30) && !force_walk) return aread8_tiled(ctx, strip_single(inx, iny), const_cast<int16_t*>(d_p), p_nodata, contcheck, d_ad8, stats);
-    int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-    if (!cnt) return TDX_ERR_NOMEM;
-    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
-    const dim3 grid2d((inx + 63) / 64, (iny + 3) / 4);
-
-    ctx->begin_call(stats);
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    if (n_outlets < 0) {
-        TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_setup_kernel, grid2d, dim3(256), 0, s, d_p, inx, iny, p_nodata, cnt, d_ad8);
-        if (stats) stats->launches[TDX_K_STENCIL]++;
-    } else {
-        // upstream closure of the outlets
-        TdxSpan sp(ctx, TDX_K_BFS);
-        int32_t* mark = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
-        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
-        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, n * 4));
-        int32_t* d_ox = static_cast<int32_t*>(ctx->scratch(TDX_S_E, size_t(n_outlets ? n_outlets : 1) * 4));
-        int32_t* d_oy = static_cast<int32_t*>(ctx->scratch(TDX_S_F, size_t(n_outlets ? n_outlets : 1) * 4));
-        if (!mark || !fa || !fb || !d_ox || !d_oy) return TDX_ERR_NOMEM;
-        hipLaunchKernelGGL(fill_i32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, cnt, CNT_NOT_PART, n);
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_ad8, TDX_AREA_NODATA, n);
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(mark, 0, n * 4, s));
-        unsigned long long ncur = 0;
-        if (n_outlets > 0) {
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_ox, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oy, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(ad8_outlet_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_ox, d_oy, int(n_outlets),
-                               inx, iny, mark, fa, d_cnt);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            ncur = ctx->h_mail[0];
-        }
-        uint32_t *cur = fa, *nxt = fb;
-        while (ncur > 0) {
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(ad8_outlet_expand_kernel, dim3(tdx_blocks_for(ncur, 256)), dim3(256), 0, s, d_p, inx, iny, p_nodata, cur, ncur,
-                               cnt, mark, nxt, d_cnt);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            ncur = ctx->h_mail[0];
-            std::swap(cur, nxt);
-            if (stats) stats->launches[TDX_K_BFS]++;
-        }
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-    }
-    {
-        TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL(ad8_walk_kernel, grid2d, dim3(256), 0, s, d_p, d_w, w_nodata, inx, iny, p_nodata, contcheck, cnt, d_ad8,
-                           stats ? d_cnt + 4 : nullptr);
-        if (stats) stats->launches[TDX_K_ACCUM]++;
-    }
-    if (stats) TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    TDX_HIP_CHECK(ctx, hipGetLastError());
-    tdx_stats* st = stats;
-    ctx->end_call();
-    if (st) { st->cells_evaluated = int64_t(ctx->h_mail[4]); st->rounds = 1; }
-    return TDX_OK;
+    if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_dev: outlets missing");
+    return aread8_impl(ctx, strip_single(int(nx), int(ny)), const_cast<int16_t*>(d_p), p_nodata, d_w, w_nodata, contcheck, outlet_x, outlet_y, n_outlets,
+                       d_ad8, stats);
 }
 
 extern "C" int tdx_aread8(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata,

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
 }
 
 // level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move
-struct LevelOp {
+template <int INC>   // 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
+struct LevelOpT {
     using T = int;
     static constexpr int kUniform = 0;
     int32_t* G;
@@ -104,9 +105,11 @@ struct LevelOp {
     __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = v; }
     __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
     static __device__ __forceinline__ void cell_decode(uint8_t m, int& cst, unsigned& mask) { cst = 0; mask = m; }
-    static __device__ __forceinline__ int apply(int, int own, int m) { return (m + 1 < own) ? m + 1 : own; }
+    static __device__ __forceinline__ int apply(int, int own, int m) { return (m + INC < own) ? m + INC : own; }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
 };
+using LevelOp = LevelOpT<1>;
+using ReachOp = LevelOpT<0>;
 
 // out[0] = max level, out[1] = #cells never reached by incfall, out[2] = max incrise level
 static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
@@ -190,10 +193,11 @@ static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const in
 // rows, re-activate the tiles that see a changed halo cell, until no halo cell changed on any rank
 // (the per-level share() + MPI_Allreduce of src/d8.cpp:549-550,620-630, once per strip crossing instead
 // of once per level).
+template <class Op = flatk::LevelOp>
 static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, int32_t* field, const uint8_t* mask, tilek::Sched sc,
                                     int64_t* rounds, int64_t* launches) {
     for (;;) {
-        int rc = tile_relax_run(ctx, flatk::LevelOp{field, mask}, geom, sc, rounds, launches);
+        int rc = tile_relax_run(ctx, Op{field, mask}, geom, sc, rounds, launches);
         if (rc != TDX_OK) return rc;
         if (!st.multi()) return TDX_OK;
         int64_t changed = 0;
@@ -286,4 +290,16 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         stats->rounds += rounds_fall + rounds_rise;
     }
     return TDX_OK;
+}
+
+// ---- upstream closure (outlets) ---------------------------------------------------------------------------------
+// reach[c] = 1 for the seed cells on entry (0 elsewhere); mask[c] selects the neighbours c drains to.  On return
+// reach == 1 exactly on the cells from which a seed is reachable downstream (src/commonLib.cpp:285-385 computes the
+// same set by a level-synchronous upstream search, one MPI round per level).  `flags` must hold FLAG_FULL for the
+// tiles that contain seeds.  Works across strips (boundary rows of reach are exchanged between outer rounds).
+static inline int reach_closure(tdx_context* ctx, const Strip& st, int32_t* reach, const uint8_t* mask, uint32_t* flags, uint32_t* list,
+                                unsigned long long* counts, int64_t* rounds, int64_t* launches) {
+    // halo rows start at 0: the first exchange after the local pass brings in the neighbours' marks and flags the tiles
+    const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
+    return flats_relax_field<flatk::ReachOp>(ctx, st, geom, reach, mask, tilek::Sched{flags, list, counts}, rounds, launches);
 }
