@@ -191,22 +191,19 @@ int tdx_pitremove_strip(tdx_context* ctx, const tdx_comm* comm, float* d_dem, in
 /* dxc/dyc: per-row cell sizes of the ny_local + 2 strip rows */
 int tdx_d8flowdir_strip(tdx_context* ctx, const tdx_comm* comm, float* d_fel, int64_t nx, int64_t ny_local, float fel_nodata,
                         const double* dxc, const double* dyc, int16_t* d_p, float* d_sd8, tdx_stats* stats);
-/* D-infinity on strips: angles / slopes, then contributing area and decayed accumulation (no outlets); d_w optional
- * weight strip; dxc/dyc: per-row cell sizes of the ny_local + 2 strip rows */
+/* D-infinity on strips: angles / slopes, then contributing area and decayed accumulation; d_w optional weight strip;
+ * outlets as for tdx_aread8_strip; dxc/dyc: per-row cell sizes of the ny_local + 2 strip rows */
 int tdx_dinfflowdir_strip(tdx_context* ctx, const tdx_comm* comm, float* d_fel, int64_t nx, int64_t ny_local, float fel_nodata,
                           const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats);
 int tdx_areadinf_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
-                       const double* dxc, const double* dyc, const float* d_w, int contcheck, float* d_sca, tdx_stats* stats);
+                       const double* dxc, const double* dyc, const float* d_w, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
+                       int64_t n_outlets, float* d_sca, tdx_stats* stats);
 int tdx_dinfdecayaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
                              const double* dxc, const double* dyc, float* d_dm, float dm_nodata, const float* d_w, int contcheck,
-                             float* d_dsca, tdx_stats* stats);
-/* unweighted, no outlets (the tile-contraction sweep) */
-int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
-                     int contcheck, float* d_ad8, tdx_stats* stats);
-
-/* weights and/or outlets on a strip.  outlet_x / outlet_row: HOST arrays in STRIP-ARRAY coordinates (row 1 = first owned
+                             const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets, float* d_dsca, tdx_stats* stats);
+/* AreaD8 on a strip, optionally with weights and/or outlets (unit weights take the tile-contraction sweep).  outlet_x / outlet_row: HOST arrays in STRIP-ARRAY coordinates (row 1 = first owned
  * row; outlets outside the owned rows are ignored, like isInPartition, src/commonLib.cpp:289-291); n_outlets < 0 = none */
-int tdx_aread8_strip_ex(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                         const float* d_w, float w_nodata, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
                         int64_t n_outlets, float* d_ad8, tdx_stats* stats);
 

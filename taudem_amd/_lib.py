@@ -123,11 +123,10 @@ _SIGNATURES = {
     "tdx_dinfdecayaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_pitremove_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, C.c_int, _P, _P]),
     "tdx_d8flowdir_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
-    "tdx_aread8_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, C.c_int, _P, _P]),
-    "tdx_aread8_strip_ex": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_aread8_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_dinfflowdir_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
-    "tdx_areadinf_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P]),
-    "tdx_dinfdecayaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P]),
+    "tdx_areadinf_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfdecayaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_synth_dem_dev": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _I64, _I64, _P]),
     "tdx_raster_info_read": (C.c_int, [C.c_char_p, C.POINTER(TdxRasterInfo)]),
     "tdx_raster_read": (C.c_int, [C.c_char_p, C.c_int, _P, _P, _P]),

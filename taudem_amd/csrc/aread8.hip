@@ -859,20 +859,12 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
 }
 
 extern "C" int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
-                                int contcheck, float* d_ad8, tdx_stats* stats) {
-    if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: bad argument");
-    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) >= (uint64_t(1) << 30))
-        return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: at most 2^30 cells per device strip");
-    return aread8_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, nullptr, 0.f, contcheck, nullptr, nullptr, -1, d_ad8, stats);
-}
-
-extern "C" int tdx_aread8_strip_ex(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                                    const float* d_w, float w_nodata, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
                                    int64_t n_outlets, float* d_ad8, tdx_stats* stats) {
-    if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip_ex: bad argument");
+    if (!ctx || !d_p || !d_ad8 || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: bad argument");
     if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
         return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
-    if (n_outlets > 0 && (!outlet_x || !outlet_row)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip_ex: outlets missing");
+    if (n_outlets > 0 && (!outlet_x || !outlet_row)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_aread8_strip: outlets missing");
     return aread8_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, d_w, w_nodata, contcheck, outlet_x, outlet_row, n_outlets, d_ad8,
                        stats);
 }

@@ -12,6 +12,7 @@
 // libm (one value per row); everything else is exactly-rounded +,-,/ on the device.
 #include "context.hpp"
 #include "device_common.hpp"
+#include "flats.hpp"
 #include "strips.hpp"
 
 namespace {
@@ -22,6 +23,7 @@ constexpr int32_t CNT_NOT_PART = 0x40000000;
 constexpr int32_t CNT_SOURCE = -1;
 constexpr int32_t CNT_DONE = -2;       // evaluated: what a strip neighbour looks for in the exchanged boundary rows
 constexpr int WALK_STACK = 8;
+constexpr float ANG_OUTSIDE = 100.0f, ANG_SINK = 200.0f;   // re-coded angles of outlets mode, see dinf_apply_reach_kernel
 
 struct RowProp { double a2; double dx; };   // a2 = atan2(dyc[j], dxc[j]) from the host libm
 
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict
         else if (p > 0.0f) { c++; inf |= 1u << (k - 1); }
     }
     if (c == 0) c = CNT_SOURCE;
-    if (is_nodata_f(ANG[idx], nodata)) c = CNT_NOT_PART;
+    if (is_nodata_f(ANG[idx], nodata) || ANG[idx] == ANG_OUTSIDE) c = CNT_NOT_PART;
     info[idx] = uint16_t(inf);
     if (cnt) cnt[idx] = c;
     OUT[idx] = out_nodata;
@@ -105,44 +107,52 @@ __global__ void fill_f32_kernel(float* p, float v, size_t n) {
     if (i < n) p[i] = v;
 }
 
-__global__ __launch_bounds__(256) void dinf_outlet_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout,
-                                                               int nx, int ny, int32_t* __restrict__ mark, uint32_t* __restrict__ fout,
-                                                               unsigned long long* __restrict__ counter) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    bool push = false;
-    uint32_t c = 0;
-    if (o < nout) {
-        const int x = ox[o], y = oy[o];
-        if (x >= 0 && x < nx && y >= 0 && y < ny) {
-            c = uint32_t(size_t(y) * size_t(nx) + size_t(x));
-            push = (atomicCAS(&mark[c], 0, 1) == 0);
-        }
-    }
-    wave_append(push, c, fout, counter);
+// ---- outlets: upstream closure through the tile relaxation engine (flats.hpp: reach_closure) ----
+// Outlets mode runs the ordinary sweep on re-coded angles: cells outside the closure keep "a valid angle" for the
+// contamination test but neither participate nor contribute (ANG_OUTSIDE, for which prop() is 0 in every direction);
+// an outlet on a cell without angle participates as a pure sink (ANG_SINK) - src/commonLib.cpp:165-233.
+
+__device__ __forceinline__ int dinf_sector(float ang, double a2) {   // number of aref[1..8] that are <= ang, at least 1
+    int sector = 0;
+#pragma unroll
+    for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
+    return sector < 1 ? 1 : sector;
 }
 
-// upstream closure of the outlets (src/commonLib.cpp:165-233)
-__global__ __launch_bounds__(256) void dinf_outlet_expand_kernel(const uint16_t* __restrict__ info, int nx, int ny,
-                                                                 const uint32_t* __restrict__ fin,
-                                                                 unsigned long long nin, int32_t* __restrict__ cnt, int32_t* __restrict__ mark,
-                                                                 uint32_t* __restrict__ fout, unsigned long long* __restrict__ counter) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = q < nin;
-    const size_t c = live ? size_t(fin[q]) : 0;
-    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-    int indeg = 0;
-    const unsigned inm = live ? unsigned(info[c]) & 0xFFu : 0u;
-    for (int k = 1; k <= 8; k++) {
-        bool push = false;
-        size_t n = 0;
-        if ((inm >> (k - 1)) & 1u) {
-            n = size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k));
-            indeg++;
-            push = (atomicCAS(&mark[n], 0, 1) == 0);
-        }
-        wave_append(push, uint32_t(n), fout, counter);
+// mask of the reachability relaxation: the (at most two) neighbours a cell sends flow to
+__global__ __launch_bounds__(256) void dinf_reach_mask_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata, const RowProp* __restrict__ rows,
+                                                              uint8_t* __restrict__ mask) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    const float ang = ANG[idx];
+    unsigned m = 0;
+    if (!is_nodata_f(ang, nodata)) {
+        const double a2 = rows[y].a2;
+        const int s1 = dinf_sector(ang, a2);
+        if (prop_dev(ang, s1, a2) > 0.0) m |= 1u << (s1 - 1);
+        const int s2 = s1 % 8 + 1;
+        if (prop_dev(ang, s2, a2) > 0.0) m |= 1u << (s2 - 1);
     }
-    if (live) cnt[c] = indeg ? indeg : CNT_SOURCE;
+    mask[idx] = uint8_t(m);
+}
+__global__ __launch_bounds__(256) void dinf_reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int y_own0,
+                                                              int y_own1, int tiles_x, int32_t* __restrict__ reach, uint32_t* __restrict__ tile_flags) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    const int x = ox[o], y = oy[o];
+    if (x < 0 || x >= nx || y < y_own0 || y >= y_own1) return;
+    reach[size_t(y) * size_t(nx) + size_t(x)] = 1;
+    tile_flags[(y / tilek::TS) * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+}
+__global__ __launch_bounds__(256) void dinf_apply_reach_kernel(const float* __restrict__ ANG, const int32_t* __restrict__ reach, size_t n, float nodata,
+                                                               float* __restrict__ out) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = ANG[i];
+    const bool nd = is_nodata_f(a, nodata);
+    out[i] = (reach[i] == 1) ? (nd ? ANG_SINK : a) : (nd ? a : ANG_OUTSIDE);
 }
 
 // ---- flow algebra ---------------------------------------------------------------------------------
@@ -214,10 +224,7 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
         go = false;
         // prop(ang, k) can be positive only for the two directions that bracket the angle (src/commonLib.cpp:83-88):
         // sector i = number of aref[1..8] that are <= ang; candidates k = i and i % 8 + 1
-        int sector = 0;
-#pragma unroll
-        for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
-        const int s1 = sector < 1 ? 1 : sector;
+        const int s1 = dinf_sector(ang, a2);
         size_t tn[2];
         bool tv[2];
 #pragma unroll
@@ -293,10 +300,7 @@ __global__ __launch_bounds__(256) void dinf_halo_kernel(Alg alg, const float* __
             drain_stores();
             const float ang = ANG[h];
             const double a2 = rows[yh].a2;
-            int sector = 0;
-#pragma unroll
-            for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
-            const int s1 = sector < 1 ? 1 : sector;
+            const int s1 = dinf_sector(ang, a2);
             for (int t = 0; t < 2; t++) {
                 const int k = (t == 0) ? s1 : (s1 % 8 + 1);
                 const int xn = x + d1(k), yn = yh + d2(k);
@@ -317,7 +321,6 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                    const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_out, float out_nodata, float* d_dm, float dm_nodata,
                    tdx_stats* stats) {
     if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "outlets missing");
-    if (n_outlets >= 0 && st.multi()) return tdx_fail(ctx, TDX_ERR_ARG, "outlets are not supported on row strips yet");
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int inx = st.nx, iny = st.ny_arr;
@@ -343,44 +346,40 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     if (rc != TDX_OK) return rc;
     if (d_dm) { rc = strip_exchange<float>(ctx, st, d_dm, dm_nodata); if (rc != TDX_OK) return rc; }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    if (n_outlets < 0) {
-        TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
-        if (stats) stats->launches[TDX_K_STENCIL]++;
-    } else {
+    float* ang_use = d_ang;
+    if (n_outlets >= 0) {
+        // upstream closure of the outlets, then the ordinary sweep on the re-coded angles
         TdxSpan sp(ctx, TDX_K_BFS);
-        int32_t* mark = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
-        uint32_t* fa = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
-        uint32_t* fb = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, n * 4));
-        int32_t* d_ox = static_cast<int32_t*>(ctx->scratch(TDX_S_E, size_t(n_outlets ? n_outlets : 1) * 4));
-        int32_t* d_oy = static_cast<int32_t*>(ctx->scratch(TDX_S_F, size_t(n_outlets ? n_outlets : 1) * 4));
-        if (!mark || !fa || !fb || !d_ox || !d_oy) return TDX_ERR_NOMEM;
-        hipLaunchKernelGGL(fill_i32_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, cnt, CNT_NOT_PART, n);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, d_ang, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info,
-                           static_cast<int32_t*>(nullptr), d_out, out_nodata);
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(mark, 0, n * 4, s));
-        unsigned long long ncur = 0;
+        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+        int32_t* reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
+        uint8_t* mask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
+        float* aprime = static_cast<float*>(ctx->scratch(TDX_S_P, n * 4));
+        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * 2));
+        unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+        int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
+        if (!reach || !mask || !aprime || !flags || !counts || !d_oxy) return TDX_ERR_NOMEM;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(reach, 0, n * 4, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+        hipLaunchKernelGGL(dinf_reach_mask_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, mask);
         if (n_outlets > 0) {
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_ox, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oy, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(dinf_outlet_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_ox, d_oy, int(n_outlets),
-                               inx, iny, mark, fa, d_cnt);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            ncur = ctx->h_mail[0];
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(dinf_reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets),
+                               inx, st.y0, st.y1, geom.tiles_x, reach, flags);
         }
-        uint32_t *cur = fa, *nxt = fb;
-        while (ncur > 0) {
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(dinf_outlet_expand_kernel, dim3(tdx_blocks_for(ncur, 256)), dim3(256), 0, s, info, inx, iny, cur, ncur, cnt, mark, nxt,
-                               d_cnt);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            ncur = ctx->h_mail[0];
-            std::swap(cur, nxt);
-            if (stats) stats->launches[TDX_K_BFS]++;
-        }
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+        int64_t rr = 0, ll = 0;
+        rc = reach_closure(ctx, st, reach, mask, flags, flags + ntiles, counts, &rr, &ll);
+        if (rc != TDX_OK) return rc;
+        hipLaunchKernelGGL(dinf_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_ang, reach, n, ang_nodata, aprime);
+        ang_use = aprime;
+        if (stats) stats->launches[TDX_K_BFS] += ll;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    }
+    {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     // halo rows of the result and of the counters start as "not evaluated"
     rc = strip_exchange<float>(ctx, st, d_out, out_nodata);
@@ -400,12 +399,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 if (novf > ovf_cap) return tdx_fail(ctx, TDX_ERR_NOMEM, "D-infinity accumulation overflow list exhausted");
                 std::swap(lst, nxt);   // the list just filled becomes the input
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
-                hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1,
+                hipLaunchKernelGGL((dinf_walk_list_kernel<Alg>), dim3(tdx_blocks_for(novf, 256)), dim3(256), 0, s, alg, ang_use, d_rows, inx, st.y0, st.y1,
                                    info, contcheck, cnt, d_out, nxt, novf, lst, d_cnt, ovf_cap);
                 rounds++;
             }
         };
-        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out, lst,
+        hipLaunchKernelGGL((dinf_walk_kernel<Alg>), grid2d, dim3(256), 0, s, alg, ang_use, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out, lst,
                            d_cnt, ovf_cap);
         rounds++;
         rc = drain_overflow();
@@ -422,10 +421,10 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
             const unsigned gx = tdx_blocks_for(size_t(inx), 256);
             if (st.up)
-                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
+                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, ang_use, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
                                    st.y0 - 1, r_out_up, r_cnt_up, lst, d_cnt, ovf_cap, d_cnt + 1);
             if (st.down)
-                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, d_ang, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
+                hipLaunchKernelGGL((dinf_halo_kernel<Alg>), dim3(gx), dim3(256), 0, s, alg, ang_use, d_rows, inx, st.y0, st.y1, info, contcheck, cnt, d_out,
                                    st.y1, r_out_dn, r_cnt_dn, lst, d_cnt, ovf_cap, d_cnt + 1);
             rc = drain_overflow();
             if (rc != TDX_OK) return rc;
@@ -461,13 +460,14 @@ extern "C" int tdx_areadinf_dev(tdx_context* ctx, const float* d_ang, int64_t nx
 }
 
 extern "C" int tdx_areadinf_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
-                                  const double* dxc, const double* dyc, const float* d_w, int contcheck, float* d_sca, tdx_stats* stats) {
+                                  const double* dxc, const double* dyc, const float* d_w, int contcheck, const int32_t* outlet_x,
+                                  const int32_t* outlet_row, int64_t n_outlets, float* d_sca, tdx_stats* stats) {
     if (!ctx || !d_ang || !d_sca || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_areadinf_strip: bad argument");
     if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
         return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
     AreaAlg alg{d_w};
-    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, nullptr, nullptr, -1, d_sca,
-                          TDX_AREA_NODATA, nullptr, 0.f, stats);
+    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_row, n_outlets,
+                          d_sca, TDX_AREA_NODATA, nullptr, 0.f, stats);
 }
 
 extern "C" int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
@@ -483,13 +483,13 @@ extern "C" int tdx_dinfdecayaccum_dev(tdx_context* ctx, const float* d_ang, int6
 
 extern "C" int tdx_dinfdecayaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
                                         const double* dxc, const double* dyc, float* d_dm, float dm_nodata, const float* d_w, int contcheck,
-                                        float* d_dsca, tdx_stats* stats) {
+                                        const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets, float* d_dsca, tdx_stats* stats) {
     if (!ctx || !d_ang || !d_dm || !d_dsca || !dxc || !dyc || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_dinfdecayaccum_strip: bad argument");
     if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
         return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
     DecayAlg alg{d_w, d_dm, dm_nodata};
-    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, nullptr, nullptr, -1, d_dsca,
-                          TDX_ANG_NODATA, d_dm, dm_nodata, stats);
+    return run_dinf_accum(ctx, alg, strip_from_comm(comm, int(nx), int(ny_local)), d_ang, ang_nodata, dxc, dyc, contcheck, outlet_x, outlet_row, n_outlets,
+                          d_dsca, TDX_ANG_NODATA, d_dm, dm_nodata, stats);
 }
 
 extern "C" int tdx_areadinf(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,

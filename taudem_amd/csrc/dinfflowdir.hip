@@ -25,7 +25,6 @@ using namespace tdxk;
 
 // facet tables (src/dinf.cpp:328-335)
 __device__ __constant__ const int kID1[9] = {0, 1, 2, 2, 1, 1, 2, 2, 1};
-__device__ __constant__ const int kID2[9] = {0, 2, 1, 1, 2, 2, 1, 1, 2};
 __device__ __constant__ const int kI1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0};
 __device__ __constant__ const int kI2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1};
 __device__ __constant__ const int kJ1[9] = {0, 1, 0, 0, -1, -1, 0, 0, 1};

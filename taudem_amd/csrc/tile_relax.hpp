@@ -659,7 +659,6 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     using namespace tilek;
     hipStream_t s = ctx->stream;
     const int ntiles = g.tiles_x * g.tiles_y;
-    const unsigned cgrid = tdx_blocks_for(size_t(ntiles), 256);
     static const bool debug = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // schedule statistics on stderr
     // The worklist schedule is opt-in (TDX_RELAX_ASYNC=1): measured on MI355X it does not beat the round schedule
     // (the relaxation is bound by VALU work per tile, not by the number of launches) - see DESIGN.md 4.2.

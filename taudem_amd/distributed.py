@@ -172,13 +172,30 @@ class StripPipeline:
               self.ctx._h)
         return p, sd8, st.as_dict()
 
-    def aread8(self, p, nodata=-32768, contcheck=True, out=None):
+    @staticmethod
+    def _outlets(outlets):
+        """(columns, STRIP-ARRAY rows) -> ctypes pointers; None = no outlets."""
+        if outlets is None:
+            return None, None, -1, ()
+        ox = np.ascontiguousarray(np.asarray(outlets[0], dtype=np.int32))
+        oy = np.ascontiguousarray(np.asarray(outlets[1], dtype=np.int32))
+        return C.c_void_p(ox.ctypes.data), C.c_void_p(oy.ctypes.data), int(ox.size), (ox, oy)
+
+    def local_outlets(self, cols, global_rows, y0):
+        """Global (column, row) outlet indices -> strip-array coordinates of the strip that starts at global row y0."""
+        return np.asarray(cols, dtype=np.int32), (np.asarray(global_rows, dtype=np.int64) - int(y0) + 1).astype(np.int32)
+
+    def aread8(self, p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=True, outlets=None, out=None):
         torch = self.torch
         ad8 = out if out is not None else self.empty(torch.float32)
+        pw = _tptr(weights, torch.float32, self.shape, "weights") if weights is not None else None
+        ox, oy, no, keep = self._outlets(outlets)
         st = TdxStats()
         torch.cuda.synchronize(self.ctx.device)
-        check(self.ctx._lib.tdx_aread8_strip(self.ctx._h, self._cp, _tptr(p, torch.int16, self.shape, "p"), self.nx, self.ny_local, int(nodata),
-                                             int(bool(contcheck)), _tptr(ad8, torch.float32, self.shape, "ad8"), C.byref(st)), self.ctx._h)
+        check(self.ctx._lib.tdx_aread8_strip(self.ctx._h, self._cp, _tptr(p, torch.int16, self.shape, "p"), self.nx, self.ny_local, int(nodata), pw,
+                                             float(weights_nodata), int(bool(contcheck)), ox, oy, no, _tptr(ad8, torch.float32, self.shape, "ad8"),
+                                             C.byref(st)), self.ctx._h)
+        del keep
         return ad8, st.as_dict()
 
     def _cells(self, dx, dy):
@@ -200,27 +217,31 @@ class StripPipeline:
               self.ctx._h)
         return ang, slp, st.as_dict()
 
-    def areadinf(self, ang, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contcheck=True, out=None):
+    def areadinf(self, ang, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None, out=None):
         torch = self.torch
         dxc, dyc = self._cells(dx, dy)
         sca = out if out is not None else self.empty(torch.float32)
         pw = _tptr(weights, torch.float32, self.shape, "weights") if weights is not None else None
+        ox, oy, no, keep = self._outlets(outlets)
         st = TdxStats()
         torch.cuda.synchronize(self.ctx.device)
         check(self.ctx._lib.tdx_areadinf_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local, float(nodata),
-                                               C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pw, int(bool(contcheck)),
+                                               C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pw, int(bool(contcheck)), ox, oy, no,
                                                _tptr(sca, torch.float32, self.shape, "sca"), C.byref(st)), self.ctx._h)
+        del keep
         return sca, st.as_dict()
 
-    def dinfdecayaccum(self, ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, out=None):
+    def dinfdecayaccum(self, ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None, out=None):
         torch = self.torch
         dxc, dyc = self._cells(dx, dy)
         dsca = out if out is not None else self.empty(torch.float32)
         pw = _tptr(weights, torch.float32, self.shape, "weights") if weights is not None else None
+        ox, oy, no, keep = self._outlets(outlets)
         st = TdxStats()
         torch.cuda.synchronize(self.ctx.device)
         check(self.ctx._lib.tdx_dinfdecayaccum_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local,
                                                      float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data),
-                                                     _tptr(dm, torch.float32, self.shape, "dm"), float(dm_nodata), pw, int(bool(contcheck)),
+                                                     _tptr(dm, torch.float32, self.shape, "dm"), float(dm_nodata), pw, int(bool(contcheck)), ox, oy, no,
                                                      _tptr(dsca, torch.float32, self.shape, "dsca"), C.byref(st)), self.ctx._h)
+        del keep
         return dsca, st.as_dict()

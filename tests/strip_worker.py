@@ -104,6 +104,16 @@ def gpu_test(case):
     for cc in (True, False):
         a, st3 = pipe.aread8(p, -32768, contcheck=cc)
         outs[f"ad8_{int(cc)}"] = a.clone()
+    # weights (exact pull walk across strips) and outlets (upstream closure across strips)
+    rng0 = np.random.default_rng(23)
+    wd8 = (rng0.random(dem.shape, dtype=np.float32) * 1.0e4).astype(np.float32)
+    o_rows = rng0.integers(2, ny - 2, size=6)
+    o_cols = rng0.integers(2, nx - 2, size=6)
+    d_wd8 = pipe.empty(torch.float32); d_wd8.zero_(); d_wd8[1:nyl + 1] = torch.from_numpy(wd8[y0:y1]).to(d_wd8.device)
+    lo = pipe.local_outlets(o_cols, o_rows, y0)
+    outs["ad8_w_nc"] = pipe.aread8(p, -32768, weights=d_wd8, contcheck=False)[0].clone()
+    outs["ad8_o"] = pipe.aread8(p, -32768, contcheck=True, outlets=lo)[0].clone()
+    outs["ad8_w_o_nc"] = pipe.aread8(p, -32768, weights=d_wd8, contcheck=False, outlets=lo)[0].clone()
     if dinf:
         rng = np.random.default_rng(17)
         wgt = (rng.random(dem.shape, dtype=np.float32) * 3.0).astype(np.float32)
@@ -116,6 +126,8 @@ def gpu_test(case):
         outs["sca_w_nc"], sta = pipe.areadinf(ang, dx=30.0, dy=20.0, weights=d_w, contcheck=False)
         outs["sca_w_nc"] = outs["sca_w_nc"].clone()
         outs["dsca_nc"] = pipe.dinfdecayaccum(ang, d_dm, dx=30.0, dy=20.0, contcheck=False)[0].clone()
+        outs["sca_o_nc"] = pipe.areadinf(ang, dx=30.0, dy=20.0, contcheck=False, outlets=lo)[0].clone()
+        outs["dsca_w_o_nc"] = pipe.dinfdecayaccum(ang, d_dm, dx=30.0, dy=20.0, weights=d_w, contcheck=False, outlets=lo)[0].clone()
     gathered = {}
     for k, t in outs.items():
         mine = t[1:nyl + 1].cpu().contiguous()
@@ -144,6 +156,11 @@ def gpu_test(case):
             a_o = O.aread8(p_o, -32768, contcheck=cc)
             g = gathered[f"ad8_{int(cc)}"]
             assert same(g, a_o), f"{case}: ad8 contcheck={cc} differs from the oracle ({(g != a_o).sum()} cells)"
+        og = (o_cols.astype(np.int32), o_rows.astype(np.int32))
+        for key, kw in (("ad8_w_nc", dict(weights=wd8, contcheck=False)), ("ad8_o", dict(contcheck=True, outlets=og)),
+                        ("ad8_w_o_nc", dict(weights=wd8, contcheck=False, outlets=og))):
+            a_o = O.aread8(p_o, -32768, weights_nodata=-9999.0, **kw)
+            assert same(gathered[key], a_o), f"{case}: {key} differs from the oracle ({(gathered[key] != a_o).sum()} cells)"
         if dinf:
             ang_o, slp_o, _ = O.dinfflowdir(fel_o, -3.0e38, 30.0, 20.0)
             assert same(gathered["ang"], ang_o), f"{case}: ang differs from the oracle ({(gathered['ang'] != ang_o).sum()} cells)"
@@ -154,6 +171,8 @@ def gpu_test(case):
             close(gathered["sca"], O.areadinf(ang_o, dx=30.0, dy=20.0, contcheck=True), "sca")
             close(gathered["sca_w_nc"], O.areadinf(ang_o, dx=30.0, dy=20.0, weights=wgt, contcheck=False), "sca_w_nc")
             close(gathered["dsca_nc"], O.dinfdecayaccum(ang_o, dmf, dx=30.0, dy=20.0, contcheck=False), "dsca_nc")
+            close(gathered["sca_o_nc"], O.areadinf(ang_o, dx=30.0, dy=20.0, contcheck=False, outlets=og), "sca_o_nc")
+            close(gathered["dsca_w_o_nc"], O.dinfdecayaccum(ang_o, dmf, dx=30.0, dy=20.0, weights=wgt, contcheck=False, outlets=og), "dsca_w_o_nc")
         print(f"strip_worker {case}: {size} ranks bit-exact vs oracle; pit outer rounds {st1['cells_evaluated']}, "
               f"flat iterations {st2['flat_iterations']}, ad8 outer rounds {st3['rounds']}, exchanges {comm.exchanges}, allreduces {comm.allreduces}",
               flush=True)
