@@ -245,16 +245,16 @@ struct Ad8Geom {
 };
 __device__ __forceinline__ int rows_valid(const Ad8Geom& g, int ty) { const int r = g.y1 - (g.y0 + ty * TS); return r < TS ? r : TS; }
 
-// LDS word of the local sweep: cnt[0:32) arrivals[32:36) contam[36:40) poison[40:44) indeg[44:48)
-__device__ __forceinline__ unsigned long long lw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi, unsigned indeg) {
-    return (unsigned long long)cnt | ((unsigned long long)arr << 32) | ((unsigned long long)con << 36) | ((unsigned long long)poi << 40) |
-           ((unsigned long long)indeg << 44);
+// LDS word of the local sweep (32 bits: a tile holds at most 4096 cells):
+// cnt[0:13) arrivals[13:17) contam[17:21) poison[21:25) indeg[25:29)
+__device__ __forceinline__ unsigned lw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi, unsigned indeg) {
+    return cnt | (arr << 13) | (con << 17) | (poi << 21) | (indeg << 25);
 }
-__device__ __forceinline__ unsigned lw_cnt(unsigned long long w) { return unsigned(w); }
-__device__ __forceinline__ unsigned lw_arr(unsigned long long w) { return unsigned(w >> 32) & 15u; }
-__device__ __forceinline__ unsigned lw_con(unsigned long long w) { return unsigned(w >> 36) & 15u; }
-__device__ __forceinline__ unsigned lw_poi(unsigned long long w) { return unsigned(w >> 40) & 15u; }
-__device__ __forceinline__ unsigned lw_indeg(unsigned long long w) { return unsigned(w >> 44) & 15u; }
+__device__ __forceinline__ unsigned lw_cnt(unsigned w) { return w & 0x1FFFu; }
+__device__ __forceinline__ unsigned lw_arr(unsigned w) { return (w >> 13) & 15u; }
+__device__ __forceinline__ unsigned lw_con(unsigned w) { return (w >> 17) & 15u; }
+__device__ __forceinline__ unsigned lw_poi(unsigned w) { return (w >> 21) & 15u; }
+__device__ __forceinline__ unsigned lw_indeg(unsigned w) { return (w >> 25) & 15u; }
 // node word of the forest walk: cnt[0:32) arrivals[32:42) contam[42:52) poison[52:62)
 __device__ __forceinline__ unsigned long long nw_pack(unsigned cnt, unsigned arr, unsigned con, unsigned poi) {
     return (unsigned long long)cnt | ((unsigned long long)arr << 32) | ((unsigned long long)con << 42) | ((unsigned long long)poi << 52);
@@ -339,9 +339,10 @@ __device__ __forceinline__ bool ring_cell(int j, int rv, int& hx, int& hy) {
 __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, unsigned long long* __restrict__ node_acc,
                                                              uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next) {
+    // 26 KB of LDS per tile (6 workgroups per CU): the in-tile targets overwrite the interior of the staged P tile
+    // once every lane has derived its topology from it; the ring cells keep their directions for the entry search
     __shared__ int16_t sP[TH * TH];
-    __shared__ unsigned long long sAcc[TS * TS];
-    __shared__ int16_t sTgt[TS * TS];
+    __shared__ unsigned sAcc[TS * TS];
     __shared__ unsigned sIn[256];   // crossings that end at each perimeter cell
     const int tile = blockIdx.x;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
@@ -350,27 +351,39 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
     sIn[tid] = 0u;
     __syncthreads();
-    unsigned src = 0;   // rows of this lane that start a walk
+    unsigned src = 0;       // rows of this lane that start a walk
+    unsigned exit_up = 0, exit_down = 0;   // rows whose crossing leaves towards the row above / below the cell
+    int16_t tgt[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r;
         const TileTopo t = tile_topo(sP, lx, ly, rv, nodata);
-        sTgt[ly * TS + lx] = t.tgt;
+        tgt[r] = t.tgt;
+        if (t.tgt == -2) {
+            const int dy = d2(sP[(ly + 1) * TH + lx + 1]);
+            if (dy < 0) exit_up |= 1u << r;
+            if (dy > 0) exit_down |= 1u << r;
+        }
         sAcc[ly * TS + lx] = t.part ? lw_pack(1u, 0u, t.con ? 1u : 0u, t.poison ? 1u : 0u, t.indeg) : lw_pack(0u, 0u, 0u, 0u, 15u);
         if (t.part && t.indeg == 0) src |= 1u << r;
     }
+    __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
+#define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = tgt[r];   // row rv is the bottom ring row of a partial tile: keep it
     __syncthreads();
-    // Kahn sweep of the in-tile flows: one returning LDS atomic per hop
+    // Kahn sweep of the in-tile flows: one returning 32-bit LDS atomic per hop
     while (src) {
         const int r = __ffs(int(src)) - 1;
         src &= src - 1u;
         int c = (ry0 + r) * TS + lx;
-        unsigned long long w = sAcc[c];
+        unsigned w = sAcc[c];
         for (;;) {
-            const int t = sTgt[c];
+            const int t = S_TGT(c);
             if (t < 0) break;
-            const unsigned long long add = lw_pack(lw_cnt(w), 1u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u, 0u);
-            const unsigned long long nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
+            const unsigned add = lw_pack(lw_cnt(w), 1u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u, 0u);
+            const unsigned nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
             if (lw_arr(nw) != lw_indeg(nw)) break;   // someone else will be the last contributor
             c = t; w = nw;
         }
@@ -380,15 +393,15 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     for (int j = tid; j < 4 * TH; j += 256) {
         int hx, hy;
         if (!ring_cell(j, rv, hx, hy)) continue;
-        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
+        const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
         if (ph == nodata || ph < 1 || ph > 8) continue;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
         if (!in_tile(vx, vy, rv)) continue;
-        if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
         int cur = vy * TS + vx, hops = 0;
-        while (sTgt[cur] >= 0 && hops < TS * TS) { cur = sTgt[cur]; hops++; }
+        if (lw_indeg(sAcc[cur]) == 15u) continue;        // the entry cell does not participate
+        while (S_TGT(cur) >= 0 && hops < TS * TS) { cur = S_TGT(cur); hops++; }
         uint32_t nxt = NEXT_NONE;
-        if (sTgt[cur] == -2) {
+        if (S_TGT(cur) == -2) {
             const int pp = perim_pos(cur % TS, cur / TS, rv);
             atomicAdd(&sIn[pp], 1u);
             nxt = uint32_t(tile) * 256u + uint32_t(pp);
@@ -401,20 +414,21 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
         const int ly = ry0 + r, c = ly * TS + lx;
         const int gx = x0 + lx, gy = ya0 + ly;
         if (gx >= g.nx || ly >= rv) continue;
-        const unsigned long long w = sAcc[c];
+        const unsigned w = sAcc[c];
         const bool part = lw_indeg(w) != 15u;
         const bool complete = part && lw_arr(w) == lw_indeg(w);
         cellw[size_t(gy) * size_t(g.nx) + size_t(gx)] = part ? cw_pack(lw_cnt(w), lw_con(w) != 0u, lw_poi(w) != 0u || !complete) : 0u;
-        if (part && sTgt[c] == -2) {
+        if (part && tgt[r] == -2) {
             const int pp = perim_pos(lx, ly, rv);
             const uint32_t nid = uint32_t(tile) * 256u + uint32_t(pp);
             node_acc[nid] = nw_pack(lw_cnt(w), 0u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u);
             node_indeg[nid] = complete ? sIn[pp] : NODE_DEAD;
-            const int tgy = gy + d2(sP[(ly + 1) * TH + lx + 1]);
+            const int tgy = gy + (((exit_up >> r) & 1u) ? -1 : (((exit_down >> r) & 1u) ? 1 : 0));
             if (tgy < g.y0) node_next[nid] = NEXT_REMOTE_UP;        // the tile that would record next(node) lives on another rank
             else if (tgy >= g.y1) node_next[nid] = NEXT_REMOTE_DOWN;
         }
     }
+#undef S_TGT
 }
 
 // Walk the crossing forest from the completed node u (word w): the last arrival at a node continues.
@@ -479,29 +493,46 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
                                                              unsigned long long* __restrict__ nbig) {
+    // 26 KB of LDS per tile: counts (32 bit), the two flags as a bit set, and the staged P tile whose interior is
+    // overwritten with the in-tile targets once the topology has been derived
     __shared__ int16_t sP[TH * TH];
-    __shared__ unsigned long long sAcc[TS * TS];
-    __shared__ int16_t sTgt[TS * TS];
+    __shared__ unsigned sCnt[TS * TS];
+    __shared__ unsigned sFlag[TS * TS / 16];   // 2 bits per cell: contaminated, not evaluated
     const int tile = blockIdx.x;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, ya0 = g.y0 + ty * TS, rv = rows_valid(g, ty);
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
     stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
+    sFlag[tid] = 0u;
     __syncthreads();
+    int16_t tgt[16];
+    unsigned partmask = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r;
         const int gx = x0 + lx, gy = ya0 + ly;
         const int16_t p = sP[(ly + 1) * TH + lx + 1];
-        int16_t tgt = -1;
-        if (ly < rv && p_part(p, nodata) && p >= 1 && p <= 8) {
-            const int tlx = lx + d1(p), tly = ly + d2(p);
-            if (in_tile(tlx, tly, rv) && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt = int16_t(tly * TS + tlx);
+        tgt[r] = -1;
+        if (ly < rv && p_part(p, nodata)) {
+            partmask |= 1u << r;
+            if (p >= 1 && p <= 8) {
+                const int tlx = lx + d1(p), tly = ly + d2(p);
+                if (in_tile(tlx, tly, rv) && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt[r] = int16_t(tly * TS + tlx);
+            }
         }
-        sTgt[ly * TS + lx] = tgt;
         uint32_t cw = 0u;
         if (gx < g.nx && ly < rv) cw = cellw[size_t(gy) * size_t(g.nx) + size_t(gx)];
-        sAcc[ly * TS + lx] = (unsigned long long)(cw & 0x3FFFFFFFu) | ((unsigned long long)((cw >> 30) & 1u) << 32) | ((unsigned long long)(cw >> 31) << 44);
+        sCnt[ly * TS + lx] = cw & 0x3FFFFFFFu;
+        const unsigned fl = cw >> 30;   // bit 0 contaminated, bit 1 not evaluated
+        if (fl) atomicOr(&sFlag[(ly * TS + lx) >> 4], fl << (2 * ((ly * TS + lx) & 15)));
+    }
+    __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
+#define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
+    // entry cells are looked up through the ring directions, which stay in place
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        // participation of an entry cell: remembered as target code -3 ("participates, leaves the tile or ends") vs -1
+        if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = (tgt[r] >= 0) ? tgt[r] : (((partmask >> r) & 1u) ? int16_t(-3) : int16_t(-1));
     }
     __syncthreads();
     for (int j = tid; j < 4 * TH; j += 256) {
@@ -511,17 +542,17 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         if (ph == nodata || ph < 1 || ph > 8) continue;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
         if (!in_tile(vx, vy, rv)) continue;
-        if (!p_part(sP[(vy + 1) * TH + vx + 1], nodata)) continue;
+        int cur = vy * TS + vx, hops = 0;
+        if (S_TGT(cur) == -1) continue;   // the entry cell does not participate
         const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
         const uint32_t ind = node_indeg[nid];
         const unsigned long long w = node_acc[nid];
-        unsigned long long add;
-        if (ind < NODE_DEAD && nw_arr(w) == ind) add = (unsigned long long)unsigned(w) | ((unsigned long long)(nw_con(w) ? 1u : 0u) << 32) | ((unsigned long long)(nw_poi(w) ? 1u : 0u) << 44);
-        else add = 1ull << 44;   // the crossing never delivers: everything below it stays unevaluated
-        int cur = vy * TS + vx, hops = 0;
+        unsigned addc = 0, addf = 2u;     // a crossing that never delivers leaves everything below it unevaluated
+        if (ind < NODE_DEAD && nw_arr(w) == ind) { addc = unsigned(w); addf = (nw_con(w) ? 1u : 0u) | (nw_poi(w) ? 2u : 0u); }
         for (;;) {
-            __hip_atomic_fetch_add(&sAcc[cur], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int t = sTgt[cur];
+            if (addc) __hip_atomic_fetch_add(&sCnt[cur], addc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (addf) atomicOr(&sFlag[cur >> 4], addf << (2 * (cur & 15)));
+            const int t = S_TGT(cur);
             if (t < 0 || ++hops >= TS * TS) break;
             cur = t;
         }
@@ -530,13 +561,13 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
     unsigned bigmask = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int ly = ry0 + r;
+        const int ly = ry0 + r, c = ly * TS + lx;
         const int gx = x0 + lx, gy = ya0 + ly;
         if (gx >= g.nx || ly >= rv) continue;
-        const unsigned long long w = sAcc[ly * TS + lx];
-        const bool part = p_part(sP[(ly + 1) * TH + lx + 1], nodata);
-        const unsigned cnt = unsigned(w);
-        const bool con = ((w >> 32) & 0xFFFull) != 0ull, poi = ((w >> 44) & 0xFFFull) != 0ull;
+        const unsigned cnt = sCnt[c];
+        const unsigned fl = (sFlag[c >> 4] >> (2 * (c & 15))) & 3u;
+        const bool part = (partmask >> r) & 1u;
+        const bool con = (fl & 1u) != 0u, poi = (fl & 2u) != 0u;
         float a = TDX_AREA_NODATA;
         if (part && !poi && !(con && contcheck == 1)) {
             if (cnt > big_threshold) { a = BIG_MARK; bigmask |= 1u << r; cellw[size_t(gy) * size_t(g.nx) + size_t(gx)] = cnt; }
@@ -544,6 +575,7 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         }
         A[size_t(gy) * size_t(g.nx) + size_t(gx)] = a;
     }
+#undef S_TGT
     const unsigned long long pos0 = block_reserve(unsigned(__popc(bigmask)), nbig);
     unsigned long long pos = pos0;
 #pragma unroll
