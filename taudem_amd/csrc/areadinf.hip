@@ -355,7 +355,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         int32_t* reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
         uint8_t* mask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
         float* aprime = static_cast<float*>(ctx->scratch(TDX_S_P, n * 4));
-        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * 2));
+        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
         unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
         int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
         if (!reach || !mask || !aprime || !flags || !counts || !d_oxy) return TDX_ERR_NOMEM;

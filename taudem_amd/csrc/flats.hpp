@@ -226,7 +226,7 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     uint8_t* fmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_E, n));
     uint8_t* rmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_F, n));
     uint32_t* flags0 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ntiles) * 4 * 2));
-    uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ntiles) * 4));
+    uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ntiles) * 4 * tilek::SCHED_LIST_WORDS));
     unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_K, size_t(tilek::COUNT_RING) * 16));
     if (!fmask || !rmask || !flags0 || !list || !counts) return TDX_ERR_NOMEM;
     uint32_t* flags = flags0 + ntiles;
@@ -249,7 +249,7 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;
     if (!st.multi() && !ctx->kernel_timing && !no_pair) {
         // the two level fields are independent: relax them side by side on two streams (own flags / list / counts each)
-        uint32_t* flagsB = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * 2));
+        uint32_t* flagsB = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS)));
         unsigned long long* countsB = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
         if (!flagsB || !countsB) return TDX_ERR_NOMEM;
         uint32_t* listB = flagsB + ntiles;

@@ -121,7 +121,10 @@ struct PitOp {
     __device__ __forceinline__ void store(size_t idx, float v) const { W[idx] = v; }
     __device__ __forceinline__ float cell_raw(size_t idx) const { return Z[idx]; }
     static __device__ __forceinline__ void cell_decode(float z, float& cst, unsigned& mask) { cst = z; mask = (NBR == 4) ? 0x55u : 0xFFu; }
-    static __device__ __forceinline__ float apply(float z, float w, float m) { return (w > z) ? fmaxf(z, fminf(w, m)) : w; }
+    static __device__ __forceinline__ float apply(float z, float w, float m) {
+        const float t = tilek::max_raw(z, tilek::min_raw(w, m));   // computed unconditionally: a select, not a branch
+        return (w > z) ? t : w;
+    }
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
 };
 
@@ -161,7 +164,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
     const int ntiles = geom.tiles_x * geom.tiles_y;
     uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, size_t(ntiles) * 4));
-    uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_B, size_t(ntiles) * 4));
+    uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_B, size_t(ntiles) * 4 * tilek::SCHED_LIST_WORDS));
     unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_C, size_t(tilek::COUNT_RING) * 16));
     if (!flags || !list || !counts) return TDX_ERR_NOMEM;
 
@@ -179,7 +182,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     int64_t rounds = 0, launches = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
-        static const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;
+        const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;   // (test hook: read per call)
         if (!fourway && !no_coarse) {
             // on the OWNED rows of the strip: paths that leave the strip are ignored, which only loosens the bound
             const size_t off = size_t(st.y0) * size_t(st.nx);

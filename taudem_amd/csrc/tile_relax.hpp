@@ -11,10 +11,11 @@
 //     neighbourhood moved, until a sweep moves nothing (details at relax_kernel);
 //   * changed cells are written back; a tile whose rim changed raises the activation flag of the
 //     neighbouring tiles that see that rim in their halo;
-//   * rounds (compact the flags into a tile list, relax the listed tiles) are enqueued in batches
-//     with NO host round trip in between: the list length lives in device memory and the resident
-//     workgroups pull tiles from a per-round cursor; the host reads back one batch of per-round counts
-//     at a time and stops at the first empty round.
+//   * rounds (ONE launch each: relax the tiles of this round's list; the workgroup that first raises a
+//     tile's flag appends it to the next round's list) are enqueued in batches with NO host round trip in
+//     between: the list length lives in device memory and the resident workgroups pull tiles from a
+//     per-round cursor; the host reads back one batch of per-round counts at a time and stops at the
+//     first empty round.
 //
 // HBM traffic per activation of a tile: one tile image of v (+ the per-cell constant) in, changed
 // cells out.  Critical path: (longest dependency path measured in tiles) rounds x one launch.
@@ -121,7 +122,6 @@ struct TileLds {   // LDS of one workgroup
 // itself, which nobody else writes).  FLAG_FULL: look at every cell (first activation, capped activation, or a
 // strip halo ROW inside the tile's area was rewritten by the exchange).
 constexpr uint32_t FLAG_HALO = 1u, FLAG_FULL = 2u;
-constexpr uint32_t LIST_FULL = 0x80000000u;   // top bit of a tile-list entry: FLAG_FULL
 
 constexpr int RES_CHANGED = 1 << 8;   // some cell of the tile moved (bits 0-7: which rim parts moved: N S W E NW NE SW SE)
 constexpr int RES_CAPPED = 1 << 9;    // stopped at max_sweeps before the tile-local fixed point
@@ -337,26 +337,297 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
         return res;
 }
 
-__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags) {
+// ---- register-resident variant ------------------------------------------------------------------------------------
+// The LDS variant above spends its time waiting for LDS round trips (every row of a sweep is a read-compute-write chain
+// through LDS).  Here a lane keeps its 16-row column segment in VGPRs; the values of the two neighbouring columns come
+// from the neighbouring LANES through DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1: one VALU op, no
+// LDS), the tile's left / right halo column enters as the `old` operand of the shift in lane 0 / lane 63, and a value
+// that moves is seen by the next row of the same sweep simply because it sits in a register.  LDS only carries what
+// crosses waves: the first and last row of every 16-row band (double-buffered by sweep parity) and three flags per
+// band and sweep.  Dirty tracking is per ROW and wave-uniform (a row costs the same VALU time whether 1 or 64 lanes
+// have something to do): rows in which nothing can have changed cost one scalar branch.
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+template <class T>
+__device__ __forceinline__ T lane_left(T x, T edge) {    // value held by lane - 1; lane 0 gets `edge`
+    static_assert(sizeof(T) == 4, "32-bit values");
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+template <class T>
+__device__ __forceinline__ T lane_right(T x, T edge) {   // value held by lane + 1; lane 63 gets `edge`
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), DPP_WAVE_SHL1, 0xf, 0xf, false));
+}
+
+constexpr int REG_LDS_WORDS = 2 * LH + 2 * NWAVE * 2 * TS;   // halo columns + double-buffered band boundary rows
+
+// three-input minimum as ONE instruction (the C++ pattern a < b ? a : b compiles to compare + select per pair for floats)
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {   // (fminf / fmaxf add a canonicalising v_max x, x per operand)
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int min3_raw(int a, int b, int c) {
+    int d;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// bit k of m8 ? x : inf, as bit-field extract + bit-field insert (no compare, nothing for the compiler to hoist into SGPR pairs)
+template <class T>
+__device__ __forceinline__ T keep_if_bit(unsigned m8, int k, T x, T inf) {
+    const int t = __builtin_amdgcn_sbfe(int(m8), k, 1);   // 0 or -1
+    const int xi = __builtin_bit_cast(int, x), fi = __builtin_bit_cast(int, inf);
+    return __builtin_bit_cast(T, (xi & t) | (fi & ~t));
+}
+
+// Six scratch registers for the lane shifts.  A wave_shr:1 never writes lane 0 and a wave_shl:1 never writes lane 63,
+// so those lanes keep the +inf they are initialised with: "no neighbour lane" reads as +inf without a copy of the `old`
+// operand in front of every DPP move.  What lanes 0 / 63 really have on that side - the tile's halo column - is constant
+// during an activation and enters through a per-row precomputed minimum (halo_min).
+template <class T>
+struct ShiftRegs { T la, lc, lb, ra, rc, rb; };
+
+// Minimum over the 8 (4) neighbours of one row of cells.  a / c / b: this column in the row above / this row / the row
+// below; hm: precomputed minimum over this row's neighbours in the halo column (lanes 0 and 63; +inf elsewhere).
+template <class Op>
+__device__ __forceinline__ typename Op::T reg_row_min(unsigned m8, typename Op::T a, typename Op::T c, typename Op::T b, typename Op::T hm,
+                                                      ShiftRegs<typename Op::T>& s) {
+    using T = typename Op::T;
+    s.lc = lane_left(c, s.lc);
+    s.rc = lane_right(c, s.rc);
+    if (Op::kUniform == 4) return min3_raw(min3_raw(a, b, s.lc), s.rc, hm);
+    s.la = lane_left(a, s.la);
+    s.ra = lane_right(a, s.ra);
+    s.lb = lane_left(b, s.lb);
+    s.rb = lane_right(b, s.rb);
+    if (Op::kUniform == 8) return min3_raw(min3_raw(a, s.la, s.ra), min3_raw(s.lc, s.rc, b), min3_raw(s.lb, s.rb, hm));
+    const T inf = Op::inf();   // bit k-1 of m8 selects neighbour k (1 E, 2 NE, 3 N, 4 NW, 5 W, 6 SW, 7 S, 8 SE)
+    return min3_raw(min3_raw(keep_if_bit(m8, 0, s.rc, inf), keep_if_bit(m8, 1, s.ra, inf), keep_if_bit(m8, 2, a, inf)),
+                    min3_raw(keep_if_bit(m8, 3, s.la, inf), keep_if_bit(m8, 4, s.lc, inf), keep_if_bit(m8, 5, s.lb, inf)),
+                    min3_raw(keep_if_bit(m8, 6, b, inf), keep_if_bit(m8, 7, s.rb, inf), hm));
+}
+// The halo-column part of a row's neighbourhood: ha / hc / hb = halo-column cell beside the row above / this row / the
+// row below (left column in lane 0, right column in lane 63).
+template <class Op>
+__device__ __forceinline__ typename Op::T halo_min(unsigned m8, bool left, bool right, typename Op::T ha, typename Op::T hc, typename Op::T hb) {
+    using T = typename Op::T;
+    const T inf = Op::inf();
+    if (!left && !right) return inf;
+    if (Op::kUniform == 4) return hc;
+    if (Op::kUniform == 8) return min3_raw(ha, hc, hb);
+    return left ? min3_raw(keep_if_bit(m8, 3, ha, inf), keep_if_bit(m8, 4, hc, inf), keep_if_bit(m8, 5, hb, inf))
+                : min3_raw(keep_if_bit(m8, 1, ha, inf), keep_if_bit(m8, 0, hc, inf), keep_if_bit(m8, 7, hb, inf));
+}
+
+// Same contract as relax_tile (sV must hold REG_LDS_WORDS words).
+template <class Op>
+__device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, int tile, typename Op::T* sV, TileLds& L, unsigned long long* __restrict__ dbg) {
+    using T = typename Op::T;
+    const int tid = threadIdx.x;
+    const int lx = tid & 63;
+    const int wv = tid >> 6;
+    const int ry0 = wv * RPW;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    T* sSide = sV;            // [2][LH]: left / right halo column, window rows 0..65 (window row j = raster row y0 - 1 + j)
+    T* sRow = sV + 2 * LH;    // [parity][band][top, bottom][TS]
+    const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
+    if (tid == 0) L.rim = 0;
+    if (lx == 0) L.rows[wv] = 0u;
+    // ---- load: 16 + 16 + 2 global loads per lane, issued back to back (addresses clamped, validity applied afterwards)
+    const int gx = x0 + lx;
+    const bool col_ok = gx < g.nx;
+    const int gxc = col_ok ? gx : g.nx - 1;
+    const long long row_pitch = (long long)g.nx;
+    typename Op::Raw raw[RPW], raw_edge, raw_side;
+    typename Op::CellRaw craw[RPW];
+    {
+        int gy = y0 + ry0;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int gyc = gy >= g.ny ? g.ny - 1 : gy;
+            const size_t idx = size_t((long long)gyc * row_pitch + gxc);
+            raw[r] = op.load_raw(idx);
+            craw[r] = op.cell_raw(idx);
+            gy++;
+        }
+    }
+    const int ey = (wv == 0) ? y0 - 1 : y0 + TS;   // tile halo row above (first band) / below (last band); unused by the inner bands
+    const bool edge_ok = col_ok && ey >= 0 && ey < g.ny;
+    bool side_ok;
+    {
+        const int eyc = ey < 0 ? 0 : (ey >= g.ny ? g.ny - 1 : ey);
+        raw_edge = op.load_raw(size_t((long long)eyc * row_pitch + gxc));
+        const int row = (tid >> 1) < LH ? (tid >> 1) : LH - 1, right = tid & 1;
+        const int sx = right ? x0 + TS : x0 - 1, sy = y0 - 1 + row;
+        side_ok = tid < 2 * LH && sx >= 0 && sx < g.nx && sy >= 0 && sy < g.ny;
+        const int sxc = sx < 0 ? 0 : (sx >= g.nx ? g.nx - 1 : sx), syc = sy < 0 ? 0 : (sy >= g.ny ? g.ny - 1 : sy);
+        raw_side = op.load_raw(size_t((long long)syc * row_pitch + sxc));
+    }
+    T v[RPW], cst[RPW];
+    unsigned mk[RPW / 4] = {};
+    unsigned live = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+        const int gy = y0 + ry0 + r;
+        v[r] = (col_ok && gy < g.ny) ? Op::decode(raw[r]) : Op::inf();
+        T c = Op::inf();
+        unsigned m = 0;
+        if (col_ok && gy >= g.y_own0 && gy < g.y_own1) Op::cell_decode(craw[r], c, m);
+        cst[r] = c;
+        mk[r >> 2] |= (m & 0xFFu) << (8 * (r & 3));
+        if (m && !Op::settled(c, v[r])) live |= 1u << r;
+    }
+    const T edge_row = edge_ok ? Op::decode(raw_edge) : Op::inf();
+    if (tid < 2 * LH) sSide[(tid & 1) * LH + (tid >> 1)] = side_ok ? Op::decode(raw_side) : Op::inf();
+    sRow[((0 * NWAVE + wv) * 2 + 0) * TS + lx] = v[0];
+    sRow[((0 * NWAVE + wv) * 2 + 1) * TS + lx] = v[RPW - 1];
+    if (live) atomicOr(&L.rows[wv], live);
+    __syncthreads();
+    // per row: minimum over the neighbours in the tile's halo column (window rows ry0 + r .. ry0 + r + 2), lanes 0 and 63 only
+    T hm[RPW];
+    {
+        const bool left = lx == 0, right = lx == TS - 1;
+        T sd[RPW + 2];
+#pragma unroll
+        for (int j = 0; j < RPW + 2; j++) sd[j] = sSide[(right ? LH : 0) + ry0 + j];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) hm[r] = halo_min<Op>(mask_at(mk, r), left, right, sd[r], sd[r + 1], sd[r + 2]);
+    }
+    ShiftRegs<T> sh = {Op::inf(), Op::inf(), Op::inf(), Op::inf(), Op::inf(), Op::inf()};
+    const unsigned rows_live = __builtin_amdgcn_readfirstlane(L.rows[wv]);   // rows of this band with a cell that can still move
+    unsigned moved = 0;     // rows of this lane that changed during this activation
+    const unsigned long long tc1 = dbg ? __builtin_readcyclecounter() : 0ull;
+    bool any_change = false, capped = false;
+    unsigned rows = rows_live;
+    for (int iter = 0;; iter++) {
+        const int cur = iter & 1;
+        const T up = (wv == 0) ? edge_row : sRow[((cur * NWAVE + wv - 1) * 2 + 1) * TS + lx];
+        const T dn = (wv == NWAVE - 1) ? edge_row : sRow[((cur * NWAVE + wv + 1) * 2 + 0) * TS + lx];
+        unsigned chg_rows = 0;   // wave-uniform: rows in which some cell moved in this sweep
+        if ((iter & 1) == 0) {   // downward: a row that moved pulls in the next one in the same sweep
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                if (!((rows >> r) & 1u)) continue;
+                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                unsigned m8 = mask_at(mk, r);
+                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
+                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                const T wn = Op::apply(cst[r], c, m);
+                const bool ch = wn != c;
+                v[r] = wn;
+                if (ch) moved |= 1u << r;
+                if (__ballot(ch) != 0ull) { chg_rows |= 1u << r; rows |= (2u << r) & rows_live; }
+            }
+        } else {                 // upward
+#pragma unroll
+            for (int r = RPW - 1; r >= 0; r--) {
+                if (!((rows >> r) & 1u)) continue;
+                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                unsigned m8 = mask_at(mk, r);
+                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
+                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                const T wn = Op::apply(cst[r], c, m);
+                const bool ch = wn != c;
+                v[r] = wn;
+                if (ch) moved |= 1u << r;
+                if (__ballot(ch) != 0ull) { chg_rows |= 1u << r; rows |= ((1u << r) >> 1) & rows_live; }
+            }
+        }
+        // publish this band's boundary rows for the next sweep (other parity: a slow wave may still be reading this one)
+        sRow[(((cur ^ 1) * NWAVE + wv) * 2 + 0) * TS + lx] = v[0];
+        sRow[(((cur ^ 1) * NWAVE + wv) * 2 + 1) * TS + lx] = v[RPW - 1];
+        if (lx == 0) {
+            L.any[cur][wv] = chg_rows != 0u;
+            L.top[cur][wv] = chg_rows & 1u;
+            L.bot[cur][wv] = (chg_rows >> (RPW - 1)) & 1u;
+        }
+        __syncthreads();   // the only barrier of a sweep
+        unsigned any = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; w++) any |= L.any[cur][w];
+        if (any) any_change = true;
+        if (!any || iter + 1 >= g.max_sweeps) {
+            capped = any != 0;
+            if (dbg && tid == 0) { atomicAdd(dbg, (unsigned long long)(iter + 1)); atomicAdd(dbg + 1, 1ull); }
+            break;
+        }
+        unsigned nd = (chg_rows | (chg_rows << 1) | (chg_rows >> 1)) & ((1u << RPW) - 1u);
+        const unsigned above = wv > 0 ? unsigned(L.bot[cur][wv > 0 ? wv - 1 : 0]) : 0u, below = wv < NWAVE - 1 ? unsigned(L.top[cur][wv < NWAVE - 1 ? wv + 1 : 0]) : 0u;
+        if (above) nd |= 1u;
+        if (below) nd |= 1u << (RPW - 1);
+        rows = __builtin_amdgcn_readfirstlane(nd) & rows_live;
+    }
+    const unsigned long long tc2 = dbg ? __builtin_readcyclecounter() : 0ull;
+    if (any_change) {   // uniform
+        int rim = 0;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int ly = ry0 + r;
+            if ((moved >> r) & 1u) {
+                op.store(size_t(y0 + ly) * size_t(g.nx) + size_t(gx), v[r]);   // changed cells are in-grid and owned
+                const bool top = (ly == 0), bot = (ly == TS - 1), lef = (lx == 0), rig = (lx == TS - 1);
+                if (top) rim |= 1;
+                if (bot) rim |= 2;
+                if (lef) rim |= 4;
+                if (rig) rim |= 8;
+                if (top && lef) rim |= 16;
+                if (top && rig) rim |= 32;
+                if (bot && lef) rim |= 64;
+                if (bot && rig) rim |= 128;
+            }
+        }
+        if (rim) atomicOr(&L.rim, rim);
+    }
+    __syncthreads();
+    if (dbg && tid == 0) {   // phase cycles: load, sweeps, write-back
+        const unsigned long long tc3 = __builtin_readcyclecounter();
+        atomicAdd(dbg + 6, tc1 - tc0); atomicAdd(dbg + 7, tc2 - tc1); atomicAdd(dbg + 8, tc3 - tc2);
+    }
+    const int res = (any_change ? (L.rim | RES_CHANGED) : 0) | (capped ? RES_CAPPED : 0);
+    __syncthreads();   // L.rim and the LDS rows are reused by the next tile
+    return res;
+}
+
+// Activates a tile for the NEXT round: the first workgroup that raises its flag from 0 also appends it to the next
+// round's tile list, so no pass over all the flags is needed between rounds.
+__device__ __forceinline__ void activate_next(int tile, uint32_t flag, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
+                                              unsigned long long* __restrict__ count_next) {
+    if (atomicMax(&flags_next[tile], flag) == 0u) list_next[atomicAdd(count_next, 1ull)] = uint32_t(tile);
+}
+__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
+                                                unsigned long long* __restrict__ count_next) {
     const int tid = threadIdx.x;
     if (tid < 8 && ((res >> tid) & 1)) {
         const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
         const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
-        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) atomicMax(&flags[nty * g.tiles_x + ntx], FLAG_HALO);
+        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) activate_next(nty * g.tiles_x + ntx, FLAG_HALO, flags_next, list_next, count_next);
     }
-    if (tid == 8 && (res & RES_CAPPED)) atomicMax(&flags[tile], FLAG_FULL);   // not yet at its fixed point: run again, everything dirty
+    // not yet at its fixed point: run again, everything dirty
+    if (tid == 8 && (res & RES_CAPPED)) activate_next(tile, FLAG_FULL, flags_next, list_next, count_next);
 }
 
-// ---- schedule 1: rounds.  Workgroups pull the tiles of the current round's list from a device cursor.
-template <class Op>
-__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list,
-                                                    unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_next,
-                                                    unsigned long long* __restrict__ dbg) {
+// ---- schedule 1: rounds, ONE launch per round.  Workgroups pull the tiles of the current round's list from a device
+// cursor, consume (read + clear) their activation flags in this round's flag half and activate tiles for the next
+// round in the other half / the other list (count[1] = the next round's size).  Flags raised in round r are only read
+// in round r + 1, so everything a tile loads was written before its launch started.
+template <class Op, bool REG>
+__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
+                                                    uint32_t* __restrict__ list_next, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
     static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
-    __shared__ T sV[LH * LP];
+    __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
     __shared__ TileLds L;
     const unsigned nact = unsigned(count[0]);
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
@@ -365,10 +636,11 @@ __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const
         __syncthreads();
         const unsigned it = L.next;
         if (it >= nact) break;
-        const uint32_t entry = list[it];
-        const int tile = int(entry & ~LIST_FULL);
-        const int res = relax_tile(op, g, tile, (entry & LIST_FULL) != 0u, sV, L, dbg);
-        if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next);
+        const int tile = int(list[it]);
+        const bool full = flags_cur[tile] >= FLAG_FULL;
+        const int res = REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);   // (ends with a barrier: every lane has read the flag)
+        if (threadIdx.x == 0) flags_cur[tile] = 0u;
+        if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, list_next, count + 1);
     }
 }
 
@@ -506,16 +778,20 @@ static __global__ void async_start_kernel(AsyncCtl c, const unsigned long long* 
     *c.error = 0u;
 }
 
-// activation flags -> compact tile list; clears the flags; count must be zero on entry
-static __global__ __launch_bounds__(256) void compact_kernel(uint32_t* __restrict__ flags, int ntiles, uint32_t* __restrict__ list,
-                                                             unsigned long long* __restrict__ count) {
+// round 0: activation flags -> tile list (the flags stay: the relaxation kernel consumes them); count must be zero on entry
+static __global__ __launch_bounds__(256) void first_list_kernel(const uint32_t* __restrict__ flags, int ntiles, uint32_t* __restrict__ list,
+                                                                unsigned long long* __restrict__ count) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t f = 0u;
-    if (t < ntiles) {
-        f = flags[t];
-        if (f) flags[t] = 0u;
-    }
-    wave_append(f != 0u, uint32_t(t) | (f >= FLAG_FULL ? LIST_FULL : 0u), list, count);
+    wave_append(t < ntiles && flags[t] != 0u, uint32_t(t), list, count);
+}
+
+// The ring of per-round counts is full: the pending round's size moves to the front of a cleared ring.
+static __global__ __launch_bounds__(256) void ring_wrap_kernel(unsigned long long* __restrict__ counts, int r) {
+    const unsigned long long pending = counts[r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * COUNT_RING; i += 256) counts[i] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[0] = pending;
 }
 
 static __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
@@ -524,10 +800,11 @@ static __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
 }
 
 struct Sched {
-    uint32_t* flags;              // [ntiles] activation flags (input: tiles active in round 0)
-    uint32_t* list;               // [ntiles]
+    uint32_t* flags;              // [ntiles] activation flags (input: tiles active in round 0; all zero again when a run returns)
+    uint32_t* list;               // [SCHED_LIST_WORDS * ntiles]: tile lists of even / odd rounds, activation flags of odd rounds
     unsigned long long* counts;   // [2 * COUNT_RING]: per-round active counts, then per-round work cursors
 };
+constexpr size_t SCHED_LIST_WORDS = 3;
 
 }  // namespace tilek
 
@@ -570,14 +847,16 @@ static int tile_relax_async_finish(tdx_context* ctx, hipStream_t s, Op op, tilek
     return TDX_OK;
 }
 
-// The round schedule of ONE relaxation as a resumable object: batches of (compact, relax) launch pairs are enqueued on
-// `s`; after the stream has been synchronised collect() reads the batch's per-round tile counts and notes the first
-// empty round.  Two runners on two streams interleave two independent relaxations (tile_relax_run_pair).
+// The round schedule of ONE relaxation as a resumable object: batches of rounds (one launch each) are enqueued on `s`;
+// after the stream has been synchronised collect() reads the batch's per-round tile counts and notes the first empty
+// round.  Two runners on two streams interleave two independent relaxations (tile_relax_run_pair).
 template <class Op>
 struct RoundRunner {
     tdx_context* ctx; hipStream_t s; Op op; tilek::TileGeom g; tilek::Sched sc; uint64_t* h; unsigned long long* dbg;
     int ntiles; unsigned cgrid, grid;
-    int r = 0, batch = 4, last_batch = 0;
+    int ring_len;                        // rounds that fit the count ring before it wraps (TDX_RELAX_RING: test hook)
+    bool lds_variant;                    // TDX_RELAX_LDS=1: the LDS-resident tile kernel instead of the register-resident one
+    int r = 0, parity = 0, batch = 4, last_batch = 0;
     bool done = false;
     int64_t rounds = 0, launches = 0;
     unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
@@ -586,22 +865,37 @@ struct RoundRunner {
         ntiles = g.tiles_x * g.tiles_y;
         cgrid = tdx_blocks_for(size_t(ntiles), 256);
         grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
+        const char* e = getenv("TDX_RELAX_RING");
+        ring_len = e ? std::max(3, std::min(atoi(e), tilek::COUNT_RING)) : tilek::COUNT_RING;
+        lds_variant = getenv("TDX_RELAX_LDS") != nullptr;
     }
+    uint32_t* list_of(int p) const { return sc.list + size_t(p) * size_t(ntiles); }
+    uint32_t* flags_of(int p) const { return p ? sc.list + 2 * size_t(ntiles) : sc.flags; }
     int start() {
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * tilek::COUNT_RING) * sizeof(unsigned long long), s));
+        using namespace tilek;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(flags_of(1), 0, size_t(ntiles) * 4, s));
+        hipLaunchKernelGGL(first_list_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, list_of(0), sc.counts);
+        r = 0; parity = 0;
         return TDX_OK;
     }
     int enqueue() {
         using namespace tilek;
-        if (r + batch > COUNT_RING) {
-            TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
+        if (batch > ring_len - 2) batch = ring_len - 2;
+        if (r + batch + 1 > ring_len) {   // counts[r + batch] (written by the batch's last round) must be inside the ring
+            hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, sc.counts, r);
             r = 0;
         }
         const bool timed = ctx->kernel_timing && s == ctx->stream;
         for (int b = 0; b < batch; b++) {
-            hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, sc.list, sc.counts + r + b);
+            const int p = (parity + b) & 1;
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
-            hipLaunchKernelGGL((relax_kernel<Op>), dim3(grid), dim3(NTHR), 0, s, op, g, sc.list, sc.counts + r + b, sc.flags, dbg);
+            if (lds_variant)
+                hipLaunchKernelGGL((relax_kernel<Op, false>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
+                                   list_of(p ^ 1), dbg);
+            else
+                hipLaunchKernelGGL((relax_kernel<Op, true>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
+                                   list_of(p ^ 1), dbg);
             ctx->span_end(sp);
             if (timed && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
         }
@@ -615,8 +909,10 @@ struct RoundRunner {
             if (h[b] == 0) { done = true; break; }
             last_count = h[b];
             rounds++;
+            if (dbg) fprintf(stderr, " %llu", (unsigned long long)h[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
         }
         r += last_batch;
+        parity = (parity + last_batch) & 1;
         if (batch < 64) batch *= 2;
     }
 };
@@ -682,22 +978,11 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
         int rc = run.start();
         if (rc != TDX_OK) return rc;
-        static const long hybrid = getenv("TDX_RELAX_HYBRID") ? atol(getenv("TDX_RELAX_HYBRID")) : 0;   // experiment: finish the tail asynchronously
         while (!run.done) {
             rc = run.enqueue();
             if (rc != TDX_OK) return rc;
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             run.collect();
-            if (hybrid > 0 && !run.done && run.rounds >= 8 && long(run.last_count) < hybrid) {
-                bool gave_up = false;
-                rc = tile_relax_async_finish(ctx, s, op, g, sc, TDX_S_Q, ctx->h_mail, dbg, &gave_up);
-                if (rc != TDX_OK) return rc;
-                launches += 1;
-                if (!gave_up) break;
-                rc = run.start();
-                if (rc != TDX_OK) return rc;
-                run.r = 0;
-            }
         }
         rounds += run.rounds;
         launches += run.launches;

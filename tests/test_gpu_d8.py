@@ -59,6 +59,20 @@ def test_pipeline_vs_oracle(shape, seed, ctx, oracle):
         assert bits_equal(a, a_o), describe_diff(a, a_o, f"ad8 contcheck={cc}")
 
 
+def test_round_schedule_count_ring_wraps(ctx, oracle, monkeypatch):
+    """The per-round count ring of the tile engine wraps (tiny ring, no coarse start: many rounds) without losing the pending round."""
+    dem = oracle.synth_dem((700, 900), 31)
+    fel_o = oracle.pitremove(dem, -9999.0)
+    p_o, sd8_o, _ = oracle.d8flowdir(fel_o, -3.0e38, 30.0, 30.0)
+    monkeypatch.setenv("TDX_PIT_NO_COARSE", "1")
+    for ring in ("3", "4", "7"):
+        monkeypatch.setenv("TDX_RELAX_RING", ring)
+        fel = ctx.pitremove(dem, -9999.0)
+        assert bits_equal(fel, fel_o), describe_diff(fel, fel_o, f"fel ring={ring}")
+        p, sd8 = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+        assert bits_equal(p, p_o), describe_diff(p, p_o, f"p ring={ring}")
+
+
 def test_nodata_holes_and_weights(ctx, oracle):
     rng = np.random.default_rng(5)
     dem = oracle.synth_dem((300, 400), 21)
