@@ -37,6 +37,7 @@ constexpr int NWAVE = TS / RPW; // waves per tile
 constexpr int NTHR = NWAVE * 64;
 constexpr int COUNT_RING = 1024;
 constexpr int MAX_SWEEPS = 8;
+constexpr int PULL_MAX = 16;    // tiles a workgroup takes from the round's list per cursor atomic (large rounds)
 
 struct TileGeom {
     int nx, ny;             // raster (strip incl. halo rows) size
@@ -115,6 +116,9 @@ struct TileLds {   // LDS of one workgroup
     unsigned any[2][NWAVE];                            // per wave: did any cell move in this sweep
     unsigned rows[NWAVE];                              // per wave: OR of the lanes' dirty masks
     unsigned next;
+    unsigned long long base;
+    unsigned npend;                   // tiles activated by this workgroup and not yet appended to the next round's list
+    uint32_t pend[PULL_MAX * 9];
 };
 
 // Activation flag of a tile.  FLAG_HALO: only cells of its halo ring moved since the tile last reached its local
@@ -597,50 +601,63 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
     return res;
 }
 
-// Activates a tile for the NEXT round: the first workgroup that raises its flag from 0 also appends it to the next
-// round's tile list, so no pass over all the flags is needed between rounds.
-__device__ __forceinline__ void activate_next(int tile, uint32_t flag, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
-                                              unsigned long long* __restrict__ count_next) {
-    if (atomicMax(&flags_next[tile], flag) == 0u) list_next[atomicAdd(count_next, 1ull)] = uint32_t(tile);
-}
-__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
-                                                unsigned long long* __restrict__ count_next) {
+// Activates tiles for the NEXT round.  The first workgroup that raises a tile's flag from 0 owns its list entry; the entries
+// are collected in LDS and appended with ONE atomic on the next round's counter per pull of the cursor: a single hot
+// address sustains only ~90 M atomics/s on MI355X, which is 0.7 ms for a round over all 65536 tiles of a 16384^2 raster.
+// Only lanes of wave 0 push; relax_kernel flushes with the whole workgroup between two barriers.
+__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, TileLds& L) {
     const int tid = threadIdx.x;
+    int target = -1;
+    uint32_t flag = FLAG_HALO;
     if (tid < 8 && ((res >> tid) & 1)) {
         const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
         const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
-        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) activate_next(nty * g.tiles_x + ntx, FLAG_HALO, flags_next, list_next, count_next);
+        if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) target = nty * g.tiles_x + ntx;
     }
-    // not yet at its fixed point: run again, everything dirty
-    if (tid == 8 && (res & RES_CAPPED)) activate_next(tile, FLAG_FULL, flags_next, list_next, count_next);
+    if (tid == 8 && (res & RES_CAPPED)) { target = tile; flag = FLAG_FULL; }   // not yet at its fixed point: run again, everything dirty
+    if (target >= 0 && atomicMax(&flags_next[target], flag) == 0u) L.pend[atomicAdd(&L.npend, 1u)] = uint32_t(target);
 }
-
 // ---- schedule 1: rounds, ONE launch per round.  Workgroups pull the tiles of the current round's list from a device
-// cursor, consume (read + clear) their activation flags in this round's flag half and activate tiles for the next
-// round in the other half / the other list (count[1] = the next round's size).  Flags raised in round r are only read
-// in round r + 1, so everything a tile loads was written before its launch started.
+// cursor (1 ... PULL_MAX list entries per atomic, depending on the size of the round), consume (read + clear) their
+// activation flags in this round's flag half and activate tiles for the next round in the other half / the other list
+// (count[1] = the next round's size).  Flags raised in round r are only read in round r + 1, so everything a tile loads
+// was written before its launch started.
 template <class Op, bool REG>
 __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                     uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
-                                                    uint32_t* __restrict__ list_next, unsigned long long* __restrict__ dbg) {
+                                                    uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
     static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
     __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
     __shared__ TileLds L;
     const unsigned nact = unsigned(count[0]);
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
+    unsigned pull = nact / (2u * gridDim.x);
+    pull = pull < 1u ? 1u : (pull > pull_max ? pull_max : pull);
+    if (threadIdx.x == 0) L.npend = 0u;
     for (;;) {
-        if (threadIdx.x == 0) L.next = unsigned(atomicAdd(cursor, 1ull));
+        __syncthreads();   // the activations of the previous pull are all in L.pend
+        const unsigned npend = L.npend;
+        if (threadIdx.x == 0) {
+            L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;
+            L.next = unsigned(atomicAdd(cursor, (unsigned long long)pull));
+        }
         __syncthreads();
-        const unsigned it = L.next;
-        if (it >= nact) break;
-        const int tile = int(list[it]);
-        const bool full = flags_cur[tile] >= FLAG_FULL;
-        const int res = REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);   // (ends with a barrier: every lane has read the flag)
-        if (threadIdx.x == 0) flags_cur[tile] = 0u;
-        if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, list_next, count + 1);
+        const unsigned first = L.next;
+        const unsigned long long base = L.base;
+        for (unsigned i = threadIdx.x; i < npend; i += unsigned(NTHR)) list_next[base + i] = L.pend[i];
+        if (threadIdx.x == 0) L.npend = 0u;   // the next push comes after the first barrier of the next tile
+        if (first >= nact) break;
+        const unsigned last = first + pull < nact ? first + pull : nact;
+        for (unsigned it = first; it < last; it++) {
+            const int tile = int(list[it]);
+            const bool full = flags_cur[tile] >= FLAG_FULL;
+            const int res = REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);   // (ends with a barrier: every lane has read the flag)
+            if (threadIdx.x == 0) flags_cur[tile] = 0u;
+            if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, L);
+        }
     }
 }
 
@@ -856,6 +873,7 @@ struct RoundRunner {
     int ntiles; unsigned cgrid, grid;
     int ring_len;                        // rounds that fit the count ring before it wraps (TDX_RELAX_RING: test hook)
     bool lds_variant;                    // TDX_RELAX_LDS=1: the LDS-resident tile kernel instead of the register-resident one
+    unsigned pull_max;                   // list entries per cursor atomic in large rounds (TDX_RELAX_PULL: test hook)
     int r = 0, parity = 0, batch = 4, last_batch = 0;
     bool done = false;
     int64_t rounds = 0, launches = 0;
@@ -868,6 +886,8 @@ struct RoundRunner {
         const char* e = getenv("TDX_RELAX_RING");
         ring_len = e ? std::max(3, std::min(atoi(e), tilek::COUNT_RING)) : tilek::COUNT_RING;
         lds_variant = getenv("TDX_RELAX_LDS") != nullptr;
+        const char* pm = getenv("TDX_RELAX_PULL");
+        pull_max = pm ? unsigned(std::max(1, std::min(atoi(pm), tilek::PULL_MAX))) : unsigned(tilek::PULL_MAX);
     }
     uint32_t* list_of(int p) const { return sc.list + size_t(p) * size_t(ntiles); }
     uint32_t* flags_of(int p) const { return p ? sc.list + 2 * size_t(ntiles) : sc.flags; }
@@ -892,10 +912,10 @@ struct RoundRunner {
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
             if (lds_variant)
                 hipLaunchKernelGGL((relax_kernel<Op, false>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
-                                   list_of(p ^ 1), dbg);
+                                   list_of(p ^ 1), pull_max, dbg);
             else
                 hipLaunchKernelGGL((relax_kernel<Op, true>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
-                                   list_of(p ^ 1), dbg);
+                                   list_of(p ^ 1), pull_max, dbg);
             ctx->span_end(sp);
             if (timed && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
         }
