@@ -37,7 +37,7 @@ constexpr int NWAVE = TS / RPW; // waves per tile
 constexpr int NTHR = NWAVE * 64;
 constexpr int COUNT_RING = 1024;
 constexpr int MAX_SWEEPS = 8;
-constexpr int PULL_MAX = 16;    // tiles a workgroup takes from the round's list per cursor atomic (large rounds)
+constexpr int PULL_MAX = 64;    // tiles a workgroup takes from the round's list per cursor atomic (large rounds)
 
 struct TileGeom {
     int nx, ny;             // raster (strip incl. halo rows) size
@@ -636,6 +636,9 @@ __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
     unsigned pull = nact / (2u * gridDim.x);
     pull = pull < 1u ? 1u : (pull > pull_max ? pull_max : pull);
+    // at most ceil(nact / pull) pulls find work: the other workgroups of the (fixed-size) grid leave without touching the
+    // cursor - 2048 atomics on one address are ~20 us, more than a whole small round
+    if (blockIdx.x * pull >= nact) return;
     if (threadIdx.x == 0) L.npend = 0u;
     for (;;) {
         __syncthreads();   // the activations of the previous pull are all in L.pend
@@ -887,7 +890,7 @@ struct RoundRunner {
         ring_len = e ? std::max(3, std::min(atoi(e), tilek::COUNT_RING)) : tilek::COUNT_RING;
         lds_variant = getenv("TDX_RELAX_LDS") != nullptr;
         const char* pm = getenv("TDX_RELAX_PULL");
-        pull_max = pm ? unsigned(std::max(1, std::min(atoi(pm), tilek::PULL_MAX))) : unsigned(tilek::PULL_MAX);
+        pull_max = pm ? unsigned(std::max(1, std::min(atoi(pm), tilek::PULL_MAX))) : 16u;
     }
     uint32_t* list_of(int p) const { return sc.list + size_t(p) * size_t(ntiles); }
     uint32_t* flags_of(int p) const { return p ? sc.list + 2 * size_t(ntiles) : sc.flags; }
