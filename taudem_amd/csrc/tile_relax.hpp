@@ -636,16 +636,19 @@ __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
     unsigned pull = nact / (2u * gridDim.x);
     pull = pull < 1u ? 1u : (pull > pull_max ? pull_max : pull);
-    // at most ceil(nact / pull) pulls find work: the other workgroups of the (fixed-size) grid leave without touching the
-    // cursor - 2048 atomics on one address are ~20 us, more than a whole small round
+    // A small round (the long tail of a relaxation is one dependency front crossing one tile per round) is pure latency:
+    // with no more tiles than workgroups every workgroup takes the list entry of its index and the cursor is not used.
+    const bool fixed = nact <= gridDim.x;
+    // at most ceil(nact / pull) pulls find work: the other workgroups of the grid (sized before the round's length is
+    // known) leave without touching the cursor - 2048 atomics on one address are ~20 us, as much as a whole small round
     if (blockIdx.x * pull >= nact) return;
     if (threadIdx.x == 0) L.npend = 0u;
-    for (;;) {
+    for (unsigned turn = 0;; turn++) {
         __syncthreads();   // the activations of the previous pull are all in L.pend
         const unsigned npend = L.npend;
         if (threadIdx.x == 0) {
             L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;
-            L.next = unsigned(atomicAdd(cursor, (unsigned long long)pull));
+            L.next = fixed ? (turn == 0u ? blockIdx.x : nact) : unsigned(atomicAdd(cursor, (unsigned long long)pull));
         }
         __syncthreads();
         const unsigned first = L.next;
@@ -873,7 +876,8 @@ static int tile_relax_async_finish(tdx_context* ctx, hipStream_t s, Op op, tilek
 template <class Op>
 struct RoundRunner {
     tdx_context* ctx; hipStream_t s; Op op; tilek::TileGeom g; tilek::Sched sc; uint64_t* h; unsigned long long* dbg;
-    int ntiles; unsigned cgrid, grid;
+    int ntiles; unsigned cgrid, grid_full, grid_small;
+    bool print_counts = false;
     int ring_len;                        // rounds that fit the count ring before it wraps (TDX_RELAX_RING: test hook)
     bool lds_variant;                    // TDX_RELAX_LDS=1: the LDS-resident tile kernel instead of the register-resident one
     unsigned pull_max;                   // list entries per cursor atomic in large rounds (TDX_RELAX_PULL: test hook)
@@ -885,7 +889,8 @@ struct RoundRunner {
         : ctx(c), s(st), op(o), g(geom), sc(sched), h(host_mail), dbg(d) {
         ntiles = g.tiles_x * g.tiles_y;
         cgrid = tdx_blocks_for(size_t(ntiles), 256);
-        grid = unsigned(std::min(ntiles, 8 * ctx->num_cus));
+        grid_full = unsigned(std::min(ntiles, 8 * ctx->num_cus));
+        grid_small = unsigned(std::min(ntiles, ctx->num_cus));
         const char* e = getenv("TDX_RELAX_RING");
         ring_len = e ? std::max(3, std::min(atoi(e), tilek::COUNT_RING)) : tilek::COUNT_RING;
         lds_variant = getenv("TDX_RELAX_LDS") != nullptr;
@@ -910,6 +915,8 @@ struct RoundRunner {
             r = 0;
         }
         const bool timed = ctx->kernel_timing && s == ctx->stream;
+        // the tail of a relaxation: a small grid launches faster (any grid size is correct, the cursor covers the list)
+        const unsigned grid = (rounds > 0 && last_count <= 256ull) ? grid_small : grid_full;
         for (int b = 0; b < batch; b++) {
             const int p = (parity + b) & 1;
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
@@ -932,7 +939,7 @@ struct RoundRunner {
             if (h[b] == 0) { done = true; break; }
             last_count = h[b];
             rounds++;
-            if (dbg) fprintf(stderr, " %llu", (unsigned long long)h[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
+            if (print_counts) fprintf(stderr, " %llu", (unsigned long long)h[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
         }
         r += last_batch;
         parity = (parity + last_batch) & 1;
@@ -978,7 +985,10 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     using namespace tilek;
     hipStream_t s = ctx->stream;
     const int ntiles = g.tiles_x * g.tiles_y;
-    static const bool debug = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // schedule statistics on stderr
+    // TDX_DEBUG_ROUNDS=1: schedule statistics and in-kernel cycle counters on stderr (the counters' atomics slow the
+    // kernels down); =2: only the active tiles per round (no kernel-side instrumentation)
+    static const int debug_level = getenv("TDX_DEBUG_ROUNDS") ? atoi(getenv("TDX_DEBUG_ROUNDS")) : 0;
+    static const bool debug = debug_level == 1;
     // The worklist schedule is opt-in (TDX_RELAX_ASYNC=1): measured on MI355X it does not beat the round schedule
     // (the relaxation is bound by VALU work per tile, not by the number of launches) - see DESIGN.md 4.2.
     static const bool force_rounds = getenv("TDX_RELAX_ASYNC") == nullptr;
@@ -999,6 +1009,8 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     }
     if (need_rounds) {
         RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
+        run.print_counts = debug_level > 0;
+        if (debug_level == 2) fprintf(stderr, "\nrounds(%d tiles):", ntiles);
         int rc = run.start();
         if (rc != TDX_OK) return rc;
         while (!run.done) {
