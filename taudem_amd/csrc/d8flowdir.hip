@@ -251,56 +251,88 @@ __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __res
 // while a large share of the raster is in the queue; the list kernels above are cheaper for a sparse queue).
 // A cell's new direction depends on the elevations and level markers of its neighbours, never on their directions,
 // so P can be rewritten in place.
+// A wave covers 62 columns x 16 rows: lanes 0 and 63 only carry the columns beside them, so every neighbour value is a
+// DPP lane shift of a register (3 coalesced loads per window row instead of 9), and only the window rows next to a row
+// that holds a flat cell are loaded at all (wave-uniform branches; flats are clustered).
+constexpr int SF2_COLS = 62;
 __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
                                                                  const double* __restrict__ fact, const int32_t* __restrict__ lvl,
                                                                  const int32_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
                                                                  uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
-    const bool colok = x < nx;
-    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    struct Row { float z0, z1, z2; int l0, l1, l2, r0, r1, r2; };
-    auto ldrow = [&](int y, Row& w) {
-        if (y >= 0 && y < ny) {
-            const size_t o = size_t(y) * size_t(nx);
-            w.z0 = Z[o + xm]; w.z1 = Z[o + xc]; w.z2 = Z[o + xp];
-            w.l0 = lvl[o + xm]; w.l1 = lvl[o + xc]; w.l2 = lvl[o + xp];
-            w.r0 = rq[o + xm]; w.r1 = rq[o + xc]; w.r2 = rq[o + xp];
-        } else { w.z0 = w.z1 = w.z2 = 0.f; w.l0 = w.l1 = w.l2 = -1; w.r0 = w.r1 = w.r2 = -1; }
-    };
-    Row n, c, s;
-    ldrow(ybase - 1, n);
-    ldrow(ybase, c);
-    unsigned keep = 0;
+    using tilek::lane_left;
+    using tilek::lane_right;
+    const int lx = threadIdx.x & 63;
+    const int x = blockIdx.x * SF2_COLS - 1 + lx;
+    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
+    const bool mine = lx >= 1 && lx <= SF2_COLS && x < nx;
+    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+    int16_t p[SLOPE_ROWS];
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
-        const int y = ybase + r;
-        ldrow(y + 1, s);
-        if (colok && y < y_own1) {
-            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-            if (P[idx] == 0) {
+        const int y = ybase + r, yc = y >= ny ? ny - 1 : y;
+        p[r] = P[size_t(yc) * size_t(nx) + size_t(xc)];
+    }
+    unsigned flat = 0;      // this lane's flat cells
+    unsigned rows0 = 0;     // wave-uniform: rows with a flat cell
+#pragma unroll
+    for (int r = 0; r < SLOPE_ROWS; r++) {
+        const bool f0 = mine && ybase + r < y_own1 && p[r] == 0;
+        if (f0) flat |= 1u << r;
+        if (__ballot(f0) != 0ull) rows0 |= 1u << r;
+    }
+    unsigned keep = 0;
+    if (rows0) {
+        // window row j = raster row ybase - 1 + j; row r looks at window rows r, r + 1, r + 2
+        const unsigned need = rows0 | (rows0 << 1) | (rows0 << 2);
+        float z[SLOPE_ROWS + 2];
+        int e2[SLOPE_ROWS + 2], rr[SLOPE_ROWS + 2];
+#pragma unroll
+        for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+            z[j] = 0.f; e2[j] = -1; rr[j] = -1;
+            if ((need >> j) & 1u) {   // (flat cells are interior cells: the rows and columns they look at exist; clamping only keeps halo lanes in bounds)
+                const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+                const size_t o = size_t(yc) * size_t(nx) + size_t(xc);
+                z[j] = Z[o]; e2[j] = lvl[o]; rr[j] = rq[o];
+            }
+        }
+        unsigned pit = 0;       // window rows whose cell never stopped incrementing (lvl == 0)
+#pragma unroll
+        for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+            if (e2[j] == 0) pit |= 1u << j;
+            e2[j] = int(flat_elev2(e2[j], rr[j], fl));
+        }
+#pragma unroll
+        for (int r = 0; r < SLOPE_ROWS; r++) {
+            if (!((rows0 >> r) & 1u)) continue;
+            const int y = ybase + r;
+            // neighbours k = 1..8 (E NE N NW W SW S SE): elevation, rq marker, elev2
+            const float zk[9] = {0.f, lane_right(z[r + 1], 0.f), lane_right(z[r], 0.f), z[r], lane_left(z[r], 0.f), lane_left(z[r + 1], 0.f),
+                                 lane_left(z[r + 2], 0.f), z[r + 2], lane_right(z[r + 2], 0.f)};
+            const int rk[9] = {0, lane_right(rr[r + 1], -1), lane_right(rr[r], -1), rr[r], lane_left(rr[r], -1), lane_left(rr[r + 1], -1),
+                               lane_left(rr[r + 2], -1), rr[r + 2], lane_right(rr[r + 2], -1)};
+            const int ek[9] = {0, lane_right(e2[r + 1], 0), lane_right(e2[r], 0), e2[r], lane_left(e2[r], 0), lane_left(e2[r + 1], 0),
+                               lane_left(e2[r + 2], 0), e2[r + 2], lane_right(e2[r + 2], 0)};
+            if ((flat >> r) & 1u) {
                 const double* f = fact + size_t(y) * 9;
-                const int e2c = int(flat_elev2(c.l1, c.r1, fl));
-                const float z0 = c.z1;
+                const int e2c = e2[r + 1];
+                const float z0 = z[r + 1];
                 float smax = 0.f;
-                int16_t dir = (fl.has_pits && c.l1 == 0) ? TDX_P_NODATA : int16_t(0);   // enclosed pit (src/d8.cpp:559-585)
+                int16_t dir = (fl.has_pits && ((pit >> (r + 1)) & 1u)) ? TDX_P_NODATA : int16_t(0);   // enclosed pit (src/d8.cpp:559-585)
                 bool done = false;
                 // candidate order 1,3,5,7,2,4,6,8; the first non-marked neighbour that is not higher ends the search (src/d8.cpp:444-451)
-#define TDX_SF2(K, ZN, LN, RN)                                                              \
-    if (!done) {                                                                             \
-        if ((RN) > 0) {                                                                      \
-            const float slope = (float)(f[K] * (double)(e2c - int(flat_elev2((LN), (RN), fl)))); \
-            if (slope > smax) { dir = int16_t(K); smax = slope; }                            \
-        } else if (z0 - (ZN) >= 0) { dir = int16_t(K); done = true; }                        \
+#define TDX_SF2(K)                                                                     \
+    if (!done) {                                                                        \
+        if (rk[K] > 0) {                                                                \
+            const float slope = (float)(f[K] * (double)(e2c - ek[K]));                 \
+            if (slope > smax) { dir = int16_t(K); smax = slope; }                       \
+        } else if (z0 - zk[K] >= 0) { dir = int16_t(K); done = true; }                  \
     }
-                TDX_SF2(1, c.z2, c.l2, c.r2) TDX_SF2(3, n.z1, n.l1, n.r1) TDX_SF2(5, c.z0, c.l0, c.r0) TDX_SF2(7, s.z1, s.l1, s.r1)
-                TDX_SF2(2, n.z2, n.l2, n.r2) TDX_SF2(4, n.z0, n.l0, n.r0) TDX_SF2(6, s.z0, s.l0, s.r0) TDX_SF2(8, s.z2, s.l2, s.r2)
+                TDX_SF2(1) TDX_SF2(3) TDX_SF2(5) TDX_SF2(7) TDX_SF2(2) TDX_SF2(4) TDX_SF2(6) TDX_SF2(8)
 #undef TDX_SF2
-                P[idx] = dir;
+                P[size_t(y) * size_t(nx) + size_t(x)] = dir;
                 if (dir == 0) keep |= 1u << r;
             }
         }
-        n = c; c = s;
     }
     unsigned long long pos = block_reserve(unsigned(__popc(keep)), counter);
 #pragma unroll
@@ -390,7 +422,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
                 if (nq > n / 32) {   // dense queue: one streaming pass
-                    const dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                    const dim3 grid((st.nx + SF2_COLS - 1) / SF2_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                     hipLaunchKernelGGL(d8_setflow2_stream_kernel, grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
                                        d_cnt);
                 } else if (nq) {
