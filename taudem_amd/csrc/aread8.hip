@@ -600,58 +600,105 @@ __global__ __launch_bounds__(256) void ad8_big_pos_kernel(const uint32_t* __rest
     if (q < nbig) pos[sorted[q]] = uint32_t(q);
 }
 
-__global__ __launch_bounds__(64) void ad8_big_ordered_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                             int contcheck, const uint32_t* __restrict__ sorted, unsigned long long nbig,
-                                                             const uint32_t* __restrict__ pos, float* __restrict__ A,
-                                                             unsigned long long* __restrict__ nfinal) {
-    __shared__ float s_val[64];
-    const int lane = threadIdx.x;
-    unsigned long long done = 0;
-    for (unsigned long long chunk0 = 0; chunk0 < nbig; chunk0 += 64) {
-        const unsigned long long q = chunk0 + (unsigned long long)lane;
-        const bool live = q < nbig;
-        const size_t c = live ? size_t(sorted[q]) : 0;
-        const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-        const float mine = live ? ld_agent(&A[c]) : 0.f;
-        const bool pending = live && mine == BIG_MARK;
-        float ak[8];
-        unsigned contrib = 0, inchunk = 0, jl[2] = {0u, 0u};   // jl: 8 x 6-bit lane numbers of in-chunk contributors
-        bool con = false, blocked = false;
-        if (pending) {
+// Step 1 (parallel over the sorted list): everything about a big cell that does not depend on other pending cells - which
+// neighbours drain into it, the values of the contributors that are final, the list positions of those that are pending.
+constexpr uint32_t BIG_NODEP = 0xFFFFFFFFu;
+constexpr uint32_t BIGF_PENDING = 1u, BIGF_BLOCKED = 2u, BIGF_CON = 4u;   // bits 8-15: contributor mask
+__global__ __launch_bounds__(256) void ad8_big_gather_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
+                                                             const uint32_t* __restrict__ sorted, unsigned long long nbig,
+                                                             const uint32_t* __restrict__ pos, const float* __restrict__ A, float* __restrict__ vals,
+                                                             uint32_t* __restrict__ deps, uint32_t* __restrict__ flags, float* __restrict__ bigval) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nbig) return;
+    const size_t c = size_t(sorted[q]);
+    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
+    const float mine = A[c];
+    bigval[q] = mine;   // final value, or BIG_MARK while pending
+    uint32_t f = 0;
+    if (mine == BIG_MARK) {
+        f = BIGF_PENDING;
 #pragma unroll
-            for (int k = 1; k <= 8; k++) {
-                ak[k - 1] = 0.f;
-                const int xn = x + d1(k), yn = y + d2(k);
-                if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { con = true; continue; }
+        for (int k = 1; k <= 8; k++) {
+            float v = 0.f;
+            uint32_t dep = BIG_NODEP;
+            const int xn = x + d1(k), yn = y + d2(k);
+            if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) f |= BIGF_CON;
+            else {
                 const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
                 const int16_t pn = P[n];
-                if (is_nodata_s(pn, nodata)) { con = true; continue; }
-                if (pn - k == 4 || pn - k == -4) {
-                    const float a = ld_agent(&A[n]);
-                    contrib |= 1u << (k - 1);
-                    ak[k - 1] = a;
-                    if (a == BIG_MARK) {
-                        unsigned long long pq = ~0ull;
-                        if (yn >= y_own0 && yn < y_own1) pq = pos[n];
-                        if (pq >= chunk0 && pq < q) {   // evaluated earlier in THIS chunk: its value comes through LDS
-                            inchunk |= 1u << (k - 1);
-                            const unsigned j = unsigned(pq - chunk0);
-                            jl[(k - 1) >> 2] |= j << (6 * ((k - 1) & 3));
-                        } else blocked = true;          // a neighbour rank's cell, or an own cell that is itself still waiting
+                if (is_nodata_s(pn, nodata)) f |= BIGF_CON;
+                else if (pn - k == 4 || pn - k == -4) {
+                    f |= 0x100u << (k - 1);
+                    v = A[n];
+                    if (v == BIG_MARK) {
+                        // a pending own cell is earlier in the list (smaller count); a pending cell of a neighbouring strip blocks this round
+                        if (yn >= y_own0 && yn < y_own1) dep = pos[n];
+                        else f |= BIGF_BLOCKED;
                     }
                 }
             }
+            vals[q * 8 + (k - 1)] = v;
+            deps[q * 8 + (k - 1)] = dep;
         }
-        s_val[lane] = mine;   // final value, or BIG_MARK while pending
+    }
+    flags[q] = f;
+}
+
+// Step 2 (ONE wave, 64 consecutive list entries at a time): the fold of the reference in k order.  The values of the
+// first BIG_LDS list entries live in LDS (an agent-scope round trip per chunk would dominate: the list is a few thousand
+// main-stem cells); longer lists continue through bigval (written by this wave: program order + drained stores).  Values
+// of the same chunk are handed on in list order.  A cell with a blocked contributor stays pending (BIG_MARK) for the
+// next outer round.
+constexpr unsigned BIG_LDS = 15360;
+__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const uint32_t* __restrict__ sorted, unsigned long long nbig,
+                                                          const float* __restrict__ vals, const uint32_t* __restrict__ deps,
+                                                          const uint32_t* __restrict__ flags, float* __restrict__ bigval, float* __restrict__ A,
+                                                          unsigned long long* __restrict__ nfinal) {
+    __shared__ float s_big[BIG_LDS];
+    const int lane = threadIdx.x;
+    unsigned long long done = 0;
+    for (unsigned long long i = lane; i < nbig && i < BIG_LDS; i += 64) s_big[i] = bigval[i];
+    const bool spill = nbig > BIG_LDS;
+    // operands of the first chunk; the next chunk's are fetched while the current one is folded
+    uint32_t f = 0, c = 0, dp[8];
+    float ak[8];
+    auto fetch = [&](unsigned long long q) {
+        f = 0; c = 0;
+        if (q < nbig) {
+            f = flags[q]; c = sorted[q];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { ak[k] = vals[q * 8 + k]; dp[k] = deps[q * 8 + k]; }
+        }
+    };
+    fetch((unsigned long long)lane);
+    for (unsigned long long chunk0 = 0; chunk0 < nbig; chunk0 += 64) {
+        const unsigned long long q = chunk0 + (unsigned long long)lane;
+        const uint32_t fl = f, cell = c;
+        float a8[8];
+        uint32_t d8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a8[k] = ak[k]; d8[k] = dp[k]; }
+        fetch(q + 64);
+        const bool pending = (fl & BIGF_PENDING) != 0u;
+        bool blocked = (fl & BIGF_BLOCKED) != 0u;
+        unsigned inchunk = 0;
+        if (pending) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (d8[k] == BIG_NODEP) continue;
+                if ((unsigned long long)d8[k] >= q) blocked = true;                // (cannot happen: a contributor's count is smaller)
+                else if ((unsigned long long)d8[k] >= chunk0) inchunk |= 1u << k;
+                else a8[k] = d8[k] < BIG_LDS ? s_big[d8[k]] : ld_agent(&bigval[d8[k]]);
+            }
+        }
         float result = BIG_MARK;
         auto fold = [&]() {
             float a = 1.0f;
-            bool c2 = con, blk = false;
+            bool c2 = (fl & BIGF_CON) != 0u, blk = false;
 #pragma unroll
-            for (int k = 1; k <= 8; k++) {
-                if (!((contrib >> (k - 1)) & 1u)) continue;
-                float v = ak[k - 1];
-                if ((inchunk >> (k - 1)) & 1u) v = s_val[(jl[(k - 1) >> 2] >> (6 * ((k - 1) & 3))) & 63u];
+            for (int k = 0; k < 8; k++) {
+                if (!((fl >> (8 + k)) & 1u)) continue;
+                const float v = a8[k];
                 if (v == BIG_MARK) blk = true;
                 else if (is_nodata_f(v, TDX_AREA_NODATA)) c2 = true;
                 else a = a + v;
@@ -659,15 +706,30 @@ __global__ __launch_bounds__(64) void ad8_big_ordered_kernel(const int16_t* __re
             if (c2 && contcheck == 1) a = TDX_AREA_NODATA;
             return blk ? BIG_MARK : a;
         };
-        if (pending && !blocked && inchunk == 0u) { result = fold(); s_val[lane] = result; }
+        if (pending && !blocked && inchunk == 0u) result = fold();
+        // Cells that depend on a cell of the same chunk (consecutive main-stem cells): one after the other in list order.
+        // The hand-over is register to register (v_readlane with wave-uniform lane numbers), no LDS round trip per step.
         unsigned long long serial = __ballot(pending && !blocked && inchunk != 0u);
-        while (serial) {   // ascending list position = dependency order; LDS operations of one wave execute in order
+        while (serial) {
             const int i = __ffsll((long long)serial) - 1;
             serial &= serial - 1ull;
-            if (lane == i) { result = fold(); s_val[lane] = result; }
+            const unsigned ic = unsigned(__builtin_amdgcn_readlane(int(inchunk), i));
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (!((ic >> k) & 1u)) continue;
+                const int j = int(unsigned(__builtin_amdgcn_readlane(int(d8[k]), i)) - unsigned(chunk0));
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, result), j));
+                if (lane == i) a8[k] = v;
+            }
+            if (lane == i) result = fold();
         }
-        if (pending && result != BIG_MARK) { st_agent(&A[c], result); done++; }
-        drain_stores();   // the next chunk reads these values back through the L2
+        if (pending && result != BIG_MARK) {
+            if (q < BIG_LDS) s_big[q] = result;
+            else st_agent(&bigval[q], result);
+            A[cell] = result;   // read again only after this kernel (exchange / host)
+            done++;
+        }
+        if (spill) drain_stores();   // later chunks read these values back through the L2
     }
     if (done) atomicAdd(nfinal, done);
 }
@@ -767,12 +829,21 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
             if (rc != TDX_OK) return rc;
             hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, sorted, nbig, pos);
         }
+        // per big cell: 8 contributor values, 8 dependency positions, flags, current value
+        float* big_vals = static_cast<float*>(ctx->scratch(TDX_S_J, size_t(nbig ? nbig : 1) * 4 * 18));
+        if (!big_vals) return TDX_ERR_NOMEM;
+        uint32_t* big_deps = reinterpret_cast<uint32_t*>(big_vals) + size_t(nbig ? nbig : 1) * 8;
+        uint32_t* big_flags = big_deps + size_t(nbig ? nbig : 1) * 8;
+        float* big_val = reinterpret_cast<float*>(big_flags + size_t(nbig ? nbig : 1));
         rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);   // which halo cells await re-evaluation
         if (rc != TDX_OK) return rc;
         for (;;) {
-            if (nbig)
-                hipLaunchKernelGGL(ad8_big_ordered_kernel, dim3(1), dim3(64), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, contcheck, sorted, nbig, pos,
-                                   d_ad8, d_cnt + 2);
+            if (nbig) {
+                hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, sorted,
+                                   nbig, pos, d_ad8, big_vals, big_deps, big_flags, big_val);
+                hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, sorted, nbig, big_vals, big_deps, big_flags, big_val, d_ad8,
+                                   d_cnt + 2);
+            }
             if (stats) stats->launches[TDX_K_MISC]++;
             if (!st.multi()) break;
             int64_t changed = 0;   // halo cells that became final on the neighbouring ranks
