@@ -709,10 +709,47 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
         if (pending && !blocked && inchunk == 0u) result = fold();
         // Cells that depend on a cell of the same chunk (consecutive main-stem cells): one after the other in list order.
         // The hand-over is register to register (v_readlane with wave-uniform lane numbers), no LDS round trip per step.
+        // The common case - exactly ONE contributor in the chunk, at neighbour kd - is prepared in parallel so that a serial
+        // step is a dozen instructions: pre = 1 + (contributors before kd), then the handed-over value, then the
+        // contributors after kd; a non-contributor adds 0.0f, which leaves a sum >= 1 unchanged, so the order of the
+        // reference's float32 additions is kept.
+        const bool single = __popc(inchunk) == 1;
+        float pre = 1.0f, suf[8];
+        bool c2pre = (fl & BIGF_CON) != 0u, blkpre = false;
+        int jdep = 0;
+        {
+            const int kd = single ? __ffs(int(inchunk)) - 1 : 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float v = 0.f;
+                if (((fl >> (8 + k)) & 1u) && k != kd) {
+                    v = a8[k];
+                    if (v == BIG_MARK) { blkpre = true; v = 0.f; }
+                    else if (is_nodata_f(v, TDX_AREA_NODATA)) { c2pre = true; v = 0.f; }
+                }
+                pre = pre + (k < kd ? v : 0.f);
+                suf[k] = k > kd ? v : 0.f;
+                if (k == kd) jdep = int(d8[k] - unsigned(chunk0));
+            }
+        }
         unsigned long long serial = __ballot(pending && !blocked && inchunk != 0u);
+        const unsigned long long singles = __ballot(single);
         while (serial) {
             const int i = __ffsll((long long)serial) - 1;
             serial &= serial - 1ull;
+            if ((singles >> i) & 1ull) {
+                const int j = __builtin_amdgcn_readlane(jdep, i);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, result), j));
+                if (lane == i) {
+                    const bool bad = v == BIG_MARK, nod = is_nodata_f(v, TDX_AREA_NODATA);
+                    float a = pre + ((bad || nod) ? 0.f : v);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a = a + suf[k];
+                    if ((c2pre || nod) && contcheck == 1) a = TDX_AREA_NODATA;
+                    result = (bad || blkpre) ? BIG_MARK : a;
+                }
+                continue;
+            }
             const unsigned ic = unsigned(__builtin_amdgcn_readlane(int(inchunk), i));
 #pragma unroll
             for (int k = 0; k < 8; k++) {
