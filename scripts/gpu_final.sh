@@ -8,8 +8,8 @@ timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d -o r1 -- python $R/bench.py --cpu-sample 0 > $R/gpurun_out/prof_d.log 2>&1)
 find gpurun_out/prof_d -name "*kernel_trace.csv" -delete; find gpurun_out/prof_d -name "*.db" -delete
 cd /tmp
-for pass in fetch write; do
-  case $pass in fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
+for pass in fetch write sq; do
+  case $pass in fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; sq) C="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU";; esac
   timeout 400 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_$pass -o p -- python $R/bench.py --cpu-sample 0 > $R/gpurun_out/pmc_$pass.log 2>&1
   python $R/scripts/pmc_summary.py $R/gpurun_out/pmc_$pass $R/gpurun_out/pmc_${pass}_summary.json | head -8
   find $R/gpurun_out/pmc_$pass -name "*.csv" -size +2M -delete; find $R/gpurun_out/pmc_$pass -name "*.db" -delete
