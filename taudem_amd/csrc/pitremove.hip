@@ -80,18 +80,29 @@ __global__ __launch_bounds__(256) void pit_coarsen_kernel(const float* __restric
     if (xc >= nxc || yc >= nyc) return;
     float zmax = -FLT_MAX;
     bool seed = false, any = false;
-    for (int j = 0; j < CF; j++) {
-        const int y = yc * CF + j;
-        if (y >= ny) break;
-        for (int i = 0; i < CF; i++) {
-            const int x = xc * CF + i;
-            if (x >= nx) break;
-            const float w = W0[size_t(y) * size_t(nx) + size_t(x)];
-            if (w == TDX_FEL_NODATA) continue;            // nodata cell of the fine raster
-            any = true;
-            const float z = Z[size_t(y) * size_t(nx) + size_t(x)];
-            zmax = fmaxf(zmax, z);
-            if (w != FLT_MAX) seed = true;                 // fine seed: W0 == Z
+    auto cell = [&](float w, float z) {
+        if (w == TDX_FEL_NODATA) return;              // nodata cell of the fine raster
+        any = true;
+        zmax = fmaxf(zmax, z);
+        if (w != FLT_MAX) seed = true;                // fine seed: W0 == Z
+    };
+    if ((nx & 3) == 0 && xc * CF + CF <= nx && yc * CF + CF <= ny) {   // whole block, 16-byte aligned rows: two 128-bit loads per row and array
+        for (int j = 0; j < CF; j++) {
+            const size_t o = size_t(yc * CF + j) * size_t(nx) + size_t(xc * CF);
+            const float4 w0 = *reinterpret_cast<const float4*>(W0 + o), w1 = *reinterpret_cast<const float4*>(W0 + o + 4);
+            const float4 z0 = *reinterpret_cast<const float4*>(Z + o), z1 = *reinterpret_cast<const float4*>(Z + o + 4);
+            cell(w0.x, z0.x); cell(w0.y, z0.y); cell(w0.z, z0.z); cell(w0.w, z0.w);
+            cell(w1.x, z1.x); cell(w1.y, z1.y); cell(w1.z, z1.z); cell(w1.w, z1.w);
+        }
+    } else {
+        for (int j = 0; j < CF; j++) {
+            const int y = yc * CF + j;
+            if (y >= ny) break;
+            for (int i = 0; i < CF; i++) {
+                const int x = xc * CF + i;
+                if (x >= nx) break;
+                cell(W0[size_t(y) * size_t(nx) + size_t(x)], Z[size_t(y) * size_t(nx) + size_t(x)]);
+            }
         }
     }
     const size_t c = size_t(yc) * size_t(nxc) + size_t(xc);
