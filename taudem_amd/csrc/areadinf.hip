@@ -21,6 +21,11 @@ using namespace tdxk;
 #define TDX_PI 3.14159265359   /* src/commonLib.h:76 */
 constexpr int32_t CNT_NOT_PART = 0x40000000;
 constexpr int32_t CNT_SOURCE = -1;
+// Result of a participating cell before it has been evaluated: a quiet NaN with a payload no arithmetic produces.  A
+// walker publishes a cell's value and decrements the downstream counters WITHOUT waiting for the store in between (that
+// wait was one of three memory round trips per hop); the lane that later evaluates a downstream cell re-reads a
+// contributor that still shows this pattern (the store was issued before the decrement it has observed, so it lands).
+constexpr uint32_t DINF_PENDING_BITS = 0x7FC0DEADu;
 constexpr int32_t CNT_DONE = -2;       // evaluated: what a strip neighbour looks for in the exchanged boundary rows
 constexpr int WALK_STACK = 8;
 constexpr float ANG_OUTSIDE = 100.0f, ANG_SINK = 200.0f;   // re-coded angles of outlets mode, see dinf_apply_reach_kernel
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict
     if (is_nodata_f(ANG[idx], nodata) || ANG[idx] == ANG_OUTSIDE) c = CNT_NOT_PART;
     info[idx] = uint16_t(inf);
     if (cnt) cnt[idx] = c;
-    OUT[idx] = out_nodata;
+    OUT[idx] = (c == CNT_NOT_PART) ? out_nodata : __uint_as_float(DINF_PENDING_BITS);
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
@@ -155,6 +160,19 @@ __global__ __launch_bounds__(256) void dinf_apply_reach_kernel(const float* __re
     out[i] = (reach[i] == 1) ? (nd ? ANG_SINK : a) : (nd ? a : ANG_OUTSIDE);
 }
 
+__device__ __forceinline__ float ld_ready(const float* p) {
+    float v = ld_agent(p);
+    for (unsigned spins = 0; __float_as_uint(v) == DINF_PENDING_BITS && spins < (1u << 20); spins++) {   // bounded: a NaN result, never a hang
+        __builtin_amdgcn_s_sleep(1);
+        v = ld_agent(p);
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void dinf_finish_kernel(float* __restrict__ OUT, size_t first, size_t n, float out_nodata) {
+    const size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < first + n && __float_as_uint(OUT[i]) == DINF_PENDING_BITS) OUT[i] = out_nodata;   // never evaluated (cycle, or upstream of one)
+}
+
 // ---- flow algebra ---------------------------------------------------------------------------------
 struct AreaAlg {   // src/areadinf.cpp:187-217
     const float* W;
@@ -168,7 +186,7 @@ struct AreaAlg {   // src/areadinf.cpp:187-217
             const int yn = y + d2(k);
             const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
             const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
-            const float v = ld_agent(&OUT[n]);
+            const float v = ld_ready(&OUT[n]);
             if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
             else areares = (float)(areares + p * v);
         }
@@ -192,7 +210,7 @@ struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
             const int yn = y + d2(k);
             const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
             const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
-            const float area = ld_agent(&OUT[n]);
+            const float area = ld_ready(&OUT[n]);
             const float dm = DM[n];
             if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
             else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
@@ -217,10 +235,9 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
         const float ang = ANG[idx];
         const double a2 = rows[y].a2;
         const float v = alg.evaluate(ANG, rows, OUT, nx, x, y, idx, unsigned(info[idx]), contcheck);
-        st_agent(&OUT[idx], v);
-        cnt[idx] = CNT_DONE;   // nobody decrements an evaluated cell any more
+        st_agent(&OUT[idx], v);   // not waited for: see DINF_PENDING_BITS
+        cnt[idx] = CNT_DONE;      // nobody decrements an evaluated cell any more
         done++;
-        drain_stores();
         go = false;
         // prop(ang, k) can be positive only for the two directions that bracket the angle (src/commonLib.cpp:83-88):
         // sector i = number of aref[1..8] that are <= ang; candidates k = i and i % 8 + 1
@@ -438,6 +455,10 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             rounds++;
         }
         if (stats) stats->launches[TDX_K_ACCUM] += rounds;
+    }
+    {
+        const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);
+        hipLaunchKernelGGL(dinf_finish_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, d_out, first, nown, out_nodata);
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
     tdx_stats* stt = stats;
