@@ -180,13 +180,23 @@ struct AreaAlg {   // src/areadinf.cpp:187-217
                                               int nx, int x, int y, size_t idx, unsigned inf, int contcheck) const {
         float areares = 0.f;
         bool con = (inf & 0x100u) != 0u;
+        // all contributor values are requested before the first one is used: one memory round trip per cell, not one per contributor
+        float vk[8], ak[8];
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            vk[k - 1] = 0.f; ak[k - 1] = 0.f;
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const size_t n = size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k));
+            ak[k - 1] = ANG[n];
+            vk[k - 1] = ld_agent(&OUT[n]);
+        }
 #pragma unroll
         for (int k = 1; k <= 8; k++) {
             if (!((inf >> (k - 1)) & 1u)) continue;
             const int yn = y + d2(k);
-            const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
-            const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
-            const float v = ld_ready(&OUT[n]);
+            const double p = prop_dev(ak[k - 1], (k + 4) % 8, rows[yn].a2);
+            float v = vk[k - 1];
+            if (__float_as_uint(v) == DINF_PENDING_BITS) v = ld_ready(&OUT[size_t(yn) * size_t(nx) + size_t(x + d1(k))]);
             if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
             else areares = (float)(areares + p * v);
         }
@@ -204,14 +214,24 @@ struct DecayAlg {   // src/dinfdecayaccum.cpp:213-245
                                               int nx, int x, int y, size_t idx, unsigned inf, int contcheck) const {
         float acc = W ? W[idx] : (float)rows[y].dx;
         bool con = (inf & 0x100u) != 0u;
+        float vk[8], ak[8], dk[8];
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            vk[k - 1] = 0.f; ak[k - 1] = 0.f; dk[k - 1] = 0.f;
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const size_t n = size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k));
+            ak[k - 1] = ANG[n];
+            dk[k - 1] = DM[n];
+            vk[k - 1] = ld_agent(&OUT[n]);
+        }
 #pragma unroll
         for (int k = 1; k <= 8; k++) {
             if (!((inf >> (k - 1)) & 1u)) continue;
             const int yn = y + d2(k);
-            const size_t n = size_t(yn) * size_t(nx) + size_t(x + d1(k));
-            const double p = prop_dev(ANG[n], (k + 4) % 8, rows[yn].a2);
-            const float area = ld_ready(&OUT[n]);
-            const float dm = DM[n];
+            const double p = prop_dev(ak[k - 1], (k + 4) % 8, rows[yn].a2);
+            float area = vk[k - 1];
+            if (__float_as_uint(area) == DINF_PENDING_BITS) area = ld_ready(&OUT[size_t(yn) * size_t(nx) + size_t(x + d1(k))]);
+            const float dm = dk[k - 1];
             if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
             else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
         }
@@ -230,11 +250,12 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
     unsigned long long done = 0;
     size_t idx = start;
     bool go = true;
+    float ang = ANG[idx];
+    unsigned inf = info[idx];
     while (go) {
         const int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
-        const float ang = ANG[idx];
         const double a2 = rows[y].a2;
-        const float v = alg.evaluate(ANG, rows, OUT, nx, x, y, idx, unsigned(info[idx]), contcheck);
+        const float v = alg.evaluate(ANG, rows, OUT, nx, x, y, idx, inf, contcheck);
         st_agent(&OUT[idx], v);   // not waited for: see DINF_PENDING_BITS
         cnt[idx] = CNT_DONE;      // nobody decrements an evaluated cell any more
         done++;
@@ -256,11 +277,16 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
         int32_t old[2] = {0, 0};
         if (tv[0]) old[0] = __hip_atomic_fetch_sub(&cnt[tn[0]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tv[1]) old[1] = __hip_atomic_fetch_sub(&cnt[tn[1]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // what the next hop needs from its cell (read-only during the sweep) travels with the atomics, not after them
+        float pang[2] = {0.f, 0.f};
+        unsigned pinf[2] = {0u, 0u};
+        if (tv[0]) { pang[0] = ANG[tn[0]]; pinf[0] = info[tn[0]]; }
+        if (tv[1]) { pang[1] = ANG[tn[1]]; pinf[1] = info[tn[1]]; }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             if (tv[t] && old[t] == 1) {
                 const size_t n = tn[t];
-                if (!go) { idx = n; go = true; }
+                if (!go) { idx = n; ang = pang[t]; inf = pinf[t]; go = true; }
                 else if (sp < WALK_STACK) stack[sp++] = uint32_t(n);
                 else {
                     const unsigned long long slot = atomicAdd(ovf_count, 1ull);
@@ -268,7 +294,7 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
                 }
             }
         }
-        if (!go && sp > 0) { idx = stack[--sp]; go = true; }
+        if (!go && sp > 0) { idx = stack[--sp]; ang = ANG[idx]; inf = info[idx]; go = true; }
     }
     return done;
 }
