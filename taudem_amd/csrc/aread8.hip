@@ -115,46 +115,70 @@ __global__ void fill_f32_kernel(float* p, float v, size_t n) {
 }
 
 // Evaluate cell (x,y) exactly as src/aread8.cpp:231-256.
-__device__ __forceinline__ float ad8_evaluate(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata,
-                                              float* __restrict__ A, int nx, int ny, int x, int y, size_t idx, int16_t nodata, int contcheck) {
-    float a;
-    if (Wt) { const float w = Wt[idx]; a = is_nodata_f(w, w_nodata) ? TDX_AREA_NODATA : w; }   // nodata weight: keeps the initial -1
-    else a = 1.0f;
-    bool con = false;
+// The 3x3 window of directions around a cell (read-only during the sweep): pk[0] = the cell itself, pk[k] = neighbour k;
+// bit k of `out` = neighbour k lies outside the raster.
+struct D8Window { int16_t pk[9]; unsigned out; };
+__device__ __forceinline__ void ad8_load_window(const int16_t* __restrict__ P, int nx, int ny, int x, int y, size_t idx, D8Window& w) {
+    w.pk[0] = P[idx];
+    w.out = 0;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
         const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { con = true; continue; }
-        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-        const int16_t pn = P[n];
+        const bool in = xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+        if (!in) w.out |= 1u << k;
+        w.pk[k] = P[in ? size_t(yn) * size_t(nx) + size_t(xn) : idx];
+    }
+}
+// a = w(c) [or 1]; for k = 1..8: a += A[neighbour k] if it drains into c (float32, src/aread8.cpp:231-256).  The values of
+// all contributors are requested before the first one is used: one memory round trip per cell.
+__device__ __forceinline__ float ad8_evaluate(const D8Window& w, const float* __restrict__ Wt, float w_nodata, float* __restrict__ A, int nx, int x,
+                                              int y, size_t idx, int16_t nodata, int contcheck) {
+    float a;
+    if (Wt) { const float wt = Wt[idx]; a = is_nodata_f(wt, w_nodata) ? TDX_AREA_NODATA : wt; }   // nodata weight: keeps the initial -1
+    else a = 1.0f;
+    bool con = false;
+    unsigned contrib = 0;
+    float ak[9];
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        ak[k] = 0.f;
+        if ((w.out >> k) & 1u) { con = true; continue; }
+        const int16_t pn = w.pk[k];
         if (is_nodata_s(pn, nodata)) { con = true; continue; }
         if (pn - k == 4 || pn - k == -4) {
-            const float an = ld_agent(&A[n]);
-            if (is_nodata_f(an, TDX_AREA_NODATA)) con = true;
-            else a = a + an;
+            contrib |= 1u << k;
+            ak[k] = ld_agent(&A[size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k))]);
         }
+    }
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        if (!((contrib >> k) & 1u)) continue;
+        if (is_nodata_f(ak[k], TDX_AREA_NODATA)) con = true;
+        else a = a + ak[k];
     }
     if (con && contcheck == 1) a = TDX_AREA_NODATA;
     return a;
 }
-
-// evaluate idx and keep walking downstream through OWNED cells while this lane is the last contributor
 __device__ __forceinline__ void ad8_walk_from(size_t idx, const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata, int nx, int ny,
                                               int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A) {
     int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
+    D8Window w;
+    ad8_load_window(P, nx, ny, x, y, idx, w);
     for (;;) {
-        const float a = ad8_evaluate(P, Wt, w_nodata, A, nx, ny, x, y, idx, nodata, contcheck);
+        const float a = ad8_evaluate(w, Wt, w_nodata, A, nx, x, y, idx, nodata, contcheck);
         st_agent(&A[idx], a);
         cnt[idx] = CNT_DONE;   // nobody decrements an evaluated cell any more
-        const int16_t k = P[idx];
+        const int16_t k = w.pk[0];
         if (k < 1 || k > 8) return;
         const int xn = x + d1(k), yn = y + d2(k);
         if (xn < 0 || xn >= nx || yn < y_own0 || yn >= y_own1) return;   // off the raster, or a neighbour rank's row (released there)
         const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
         drain_stores();                 // value must be at the coherence point before the counter moves
         const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        D8Window wn;                    // the next hop's window travels with the atomic, not after it
+        ad8_load_window(P, nx, ny, xn, yn, n, wn);
         if (old != 1) return;           // somebody else is the last contributor
-        x = xn; y = yn; idx = n;
+        x = xn; y = yn; idx = n; w = wn;
     }
 }
 
