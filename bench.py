@@ -189,6 +189,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    line = None
     if rank == 0:
         cells = float(n) * float(n)          # cells per GPU
         ms_per_step = elapsed / args.steps * 1e3
@@ -251,9 +252,19 @@ def main():
             out["comm"] = {"exchanges_per_step": comm.exchanges / (args.steps + args.warmup), "allreduces_per_step": comm.allreduces / (args.steps + args.warmup)}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.seed)
-        print(json.dumps(out))
+        line = json.dumps(out)
+    # The JSON line is the LAST thing on stdout: whatever any rank or the C runtimes (RCCL prints a version banner
+    # through C stdio) have buffered goes out first, and the ranks leave without running teardown code that prints.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     if dist.is_initialized():
-        dist.destroy_process_group()
+        dist.barrier()
+    if rank == 0:
+        print(line, flush=True)
+    if dist.is_initialized():
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
