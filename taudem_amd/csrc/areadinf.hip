@@ -27,7 +27,7 @@ constexpr int32_t CNT_SOURCE = -1;
 // contributor that still shows this pattern (the store was issued before the decrement it has observed, so it lands).
 constexpr uint32_t DINF_PENDING_BITS = 0x7FC0DEADu;
 constexpr int32_t CNT_DONE = -2;       // evaluated: what a strip neighbour looks for in the exchanged boundary rows
-constexpr int WALK_STACK = 8;
+constexpr int WALK_STACK = 48;
 constexpr float ANG_OUTSIDE = 100.0f, ANG_SINK = 200.0f;   // re-coded angles of outlets mode, see dinf_apply_reach_kernel
 
 struct RowProp { double a2; double dx; };   // a2 = atan2(dyc[j], dxc[j]) from the host libm
