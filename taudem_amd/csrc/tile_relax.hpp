@@ -5,10 +5,12 @@
 // that only ever DEcreases v from +inf, so any schedule that runs to convergence yields the same
 // values.  The schedule used on gfx950:
 //
-//   * the raster is cut into 64x64 tiles; a 256-thread workgroup stages a tile of v plus a one-cell
-//     halo in LDS (66x67 x 4 B = 17.7 KB), every lane owns a 16-row column segment and relaxes it in
-//     place ("chaotic" relaxation) in alternating downward / upward sweeps, looking only at cells whose
-//     neighbourhood moved, until a sweep moves nothing (details at relax_kernel);
+//   * the raster is cut into 64x64 tiles; a 256-thread workgroup loads a tile of v plus a one-cell halo, every
+//     lane owns a 16-row column segment and relaxes it in place ("chaotic" relaxation) in alternating
+//     downward / upward sweeps, looking only at rows in which something can have moved, until a sweep
+//     moves nothing.  Two tile kernels implement this: relax_tile_reg (default: the segment lives in
+//     VGPRs, neighbour columns come from neighbour LANES through DPP wave shifts, LDS only carries the
+//     rows that cross waves) and relax_tile (the tile lives in LDS, 66x67 x 4 B = 17.7 KB; TDX_RELAX_LDS=1);
 //   * changed cells are written back; a tile whose rim changed raises the activation flag of the
 //     neighbouring tiles that see that rim in their halo;
 //   * rounds (ONE launch each: relax the tiles of this round's list; the workgroup that first raises a
