@@ -128,6 +128,22 @@ int tdx_aread8(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16
                const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
                float* ad8, tdx_stats* stats);
 
+/* ---- GridNet / Threshold (the step after AreaD8) ------------------------- */
+/* gridnet() src/gridnet.cpp:54-514 without outlets: plen / tlen = longest / total upstream path length (float, -1 nodata),
+ * gord = Strahler order (int16, -1 nodata).  mask: optional int32 grid, only cells with mask >= thresh are evaluated
+ * (NULL = all cells).  dxc / dyc: per-row cell sizes (ny doubles, HOST). */
+int tdx_gridnet_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
+                    const double* dxc, const double* dyc, const int32_t* d_mask, int32_t thresh,
+                    float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats);
+int tdx_gridnet(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata,
+                const double* dxc, const double* dyc, const int32_t* mask, int32_t thresh,
+                float* plen, float* tlen, int16_t* gord, tdx_stats* stats);
+/* threshold() src/Threshold.cpp:49-162: src = 1 where ssa >= thresh (and mask >= 0), else 0; -32768 where ssa is nodata */
+int tdx_threshold_dev(tdx_context* ctx, const float* d_ssa, int64_t nx, int64_t ny, float ssa_nodata,
+                      const float* d_mask, float thresh, int16_t* d_src, tdx_stats* stats);
+int tdx_threshold(tdx_context* ctx, const float* ssa, int64_t nx, int64_t ny, float ssa_nodata,
+                  const float* mask, float thresh, int16_t* src, tdx_stats* stats);
+
 /* ---- DinfFlowDir -------------------------------------------------------------------------- */
 int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
                         const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats);
@@ -256,6 +272,13 @@ int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* data
 int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const char* dmfile, const char* datasrc,
                             const char* lyrname, int uselyrname, int lyrno, const char* wfile,
                             int useOutlets, int usew, int contcheck);
+/* int gridnet(char*,char*,char*,char*,char*,char*,char*,int,int,int,int,int)  src/gridnet.cpp:54-55
+ * (useOutlets = 1 is not built yet: returns TDX_ERR_ARG) */
+int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile,
+                     const char* maskfile, const char* datasrc, const char* lyrname, int uselyrname, int lyrno,
+                     int useMask, int useOutlets, int thresh);
+/* int threshold(char*,char*,char*,float,int)                       src/Threshold.cpp:49 */
+int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask);
 /* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */
 int tdx_tool_set_device(int device);
 

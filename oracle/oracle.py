@@ -103,6 +103,31 @@ def aread8(p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=Tru
     return ad8
 
 
+def gridnet(p, nodata=-32768, dx=1.0, dy=1.0, mask=None, thresh=0):
+    """(plen, tlen, gord) of src/gridnet.cpp without outlets; mask: int32 raster (cells with mask >= thresh are evaluated)."""
+    p = np.ascontiguousarray(p, dtype=np.int16)
+    ny, nx = p.shape
+    plen = np.empty((ny, nx), dtype=np.float32)
+    tlen = np.empty((ny, nx), dtype=np.float32)
+    gord = np.empty((ny, nx), dtype=np.int16)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+    lib().orc_gridnet(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(dxc), _p(dyc), _p(mask), C.c_int(int(thresh)), _p(plen), _p(tlen), _p(gord))
+    return plen, tlen, gord
+
+
+def threshold(ssa, thresh, nodata=-1.0, mask=None):
+    """src of src/Threshold.cpp: 1 where ssa >= thresh (and mask >= 0), 0 elsewhere, -32768 where ssa is nodata."""
+    ssa = np.ascontiguousarray(ssa, dtype=np.float32)
+    ny, nx = ssa.shape
+    src = np.empty((ny, nx), dtype=np.int16)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.float32)
+    lib().orc_threshold(_p(ssa), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(mask), C.c_float(thresh), _p(src))
+    return src
+
+
 def dinfflowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0):
     fel = np.ascontiguousarray(fel, dtype=np.float32)
     ny, nx = fel.shape

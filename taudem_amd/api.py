@@ -159,6 +159,40 @@ class Context:
         del keep
         return (ad8, st.as_dict()) if stats else ad8
 
+    def gridnet(self, p, nodata=int(P_NODATA), dx=1.0, dy=1.0, mask=None, thresh=0, stats=False):
+        """plen, tlen, gord = gridnet(p)  (src/gridnet.cpp:54, no outlets).  mask: int32 raster, cells with mask >= thresh are evaluated."""
+        ny, nx = p.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        plen = self._out(p, np.float32, (ny, nx))
+        tlen = self._out(p, np.float32, (ny, nx))
+        gord = self._out(p, np.int16, (ny, nx))
+        pp, dev = self._ptr(p, np.int16, name="p")
+        pm, mdev = self._ptr(mask, np.int32, (ny, nx), "mask")
+        ppl, _ = self._ptr(plen, np.float32, (ny, nx), "plen")
+        ptl, _ = self._ptr(tlen, np.float32, (ny, nx), "tlen")
+        pgo, _ = self._ptr(gord, np.int16, (ny, nx), "gord")
+        if mask is not None and mdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(p, mask)
+        check(self._pick(dev, "tdx_gridnet")(self._h, pp, nx, ny, int(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pm, int(thresh),
+                                              ppl, ptl, pgo, C.byref(st)), self._h)
+        return (plen, tlen, gord, st.as_dict()) if stats else (plen, tlen, gord)
+
+    def threshold(self, ssa, thresh, nodata=-1.0, mask=None, stats=False):
+        """src = threshold(ssa)  (src/Threshold.cpp:49): 1 where ssa >= thresh (and mask >= 0), 0 elsewhere, -32768 where ssa is nodata."""
+        ny, nx = ssa.shape
+        src = self._out(ssa, np.int16, (ny, nx))
+        pa, dev = self._ptr(ssa, np.float32, name="ssa")
+        pm, mdev = self._ptr(mask, np.float32, (ny, nx), "mask")
+        ps, _ = self._ptr(src, np.int16, (ny, nx), "src")
+        if mask is not None and mdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(ssa, mask)
+        check(self._pick(dev, "tdx_threshold")(self._h, pa, nx, ny, float(nodata), pm, float(thresh), ps, C.byref(st)), self._h)
+        return (src, st.as_dict()) if stats else src
+
     def dinfflowdir(self, fel, nodata=float(FEL_NODATA), dx=1.0, dy=1.0, out=None, stats=False):
         """ang, slp = setdir(fel)  (src/dinf.cpp:109)."""
         ny, nx = fel.shape

@@ -42,6 +42,7 @@ struct Raster {
     tdx::RasterInfo info;
     std::vector<float> f;
     std::vector<int16_t> s;
+    std::vector<int32_t> l;
 };
 
 // tiffIO constructor + CreateNewPartition prints + read (src/tiffIO.cpp:54-183, src/createpart.h:49-87)
@@ -63,6 +64,10 @@ int load_raster(const char* path, tdx::DType type, Raster& r) {
         printf("Nodata value recast to float used in partition raster: %f\n", (float)r.info.nodata);
         r.f.resize(n);
         ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.f.data());
+    } else if (type == tdx::DType::I32) {
+        printf("Nodata value recast to int32_t used in partition raster: %d\n", (int32_t)r.info.nodata);
+        r.l.resize(n);
+        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.l.data());
     } else {
         printf("Nodata value recast to int16_t used in partition raster: %d\n", (int16_t)r.info.nodata);
         r.s.resize(n);
@@ -144,6 +149,76 @@ void print_gpu_stats(const char* tool, const tdx_stats& st, int64_t cells) {
 }  // namespace
 
 extern "C" {
+
+int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile, const char* maskfile, const char* /*datasrc*/,
+                     const char* /*lyrname*/, int /*uselyrname*/, int /*lyrno*/, int useMask, int useOutlets, int thresh) {
+    printf("GridNet version %s\n", TDVERSION);
+    fflush(stdout);
+    if (useOutlets == 1) {
+        g_tdx_thread_error = "gridnet: the outlets branch (-o) is not built yet";
+        fprintf(stderr, "taudem_amd: %s\n", g_tdx_thread_error.c_str());
+        return TDX_ERR_ARG;
+    }
+    const double begint = now_s();
+    Raster p, mask;
+    int rc = load_raster(pfile, tdx::DType::I16, p);
+    if (rc != TDX_OK) return rc;
+    if (useMask == 1) {
+        rc = load_raster(maskfile, tdx::DType::I32, mask);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(p.info, pfile, mask.info, maskfile)) { printf("File sizes do not match\n%s\n", maskfile); fflush(stdout); return TDX_ERR_OUTLETS; }   // src/gridnet.cpp:147-152
+    }
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    const size_t n = p.s.size();
+    std::vector<float> plen(n), tlen(n);
+    std::vector<int16_t> gord(n);
+    tdx_stats st;
+    rc = tdx_gridnet(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, p.info.dxc.data(), p.info.dyc.data(),
+                     useMask ? mask.l.data() : nullptr, thresh, plen.data(), tlen.data(), gord.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(gordfile, tdx::DType::I16, gord.data(), p.info, -1.0);   // src/gridnet.cpp:474-481
+    if (rc != TDX_OK) return rc;
+    rc = save_raster(plenfile, tdx::DType::F32, plen.data(), p.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    rc = save_raster(tlenfile, tdx::DType::F32, tlen.data(), p.info, -1.0);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    print_gpu_stats("gridnet", st, p.info.nx * p.info.ny);
+    return 0;
+}
+
+int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask) {
+    printf("Threshold version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster ssa, mask;
+    int rc = load_raster(ssafile, tdx::DType::F32, ssa);
+    if (rc != TDX_OK) return rc;
+    if (usemask == 1) {
+        rc = load_raster(maskfile, tdx::DType::F32, mask);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(ssa.info, ssafile, mask.info, maskfile)) return TDX_ERR_MISMATCH;   // src/Threshold.cpp:90
+    }
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<int16_t> src(ssa.f.size());
+    tdx_stats st;
+    rc = tdx_threshold(g.c, ssa.f.data(), ssa.info.nx, ssa.info.ny, (float)ssa.info.nodata, usemask ? mask.f.data() : nullptr, thresh, src.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(srcfile, tdx::DType::I16, src.data(), ssa.info, -32768.0);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    return 0;
+}
 
 int tdx_tool_set_device(int device) { g_tool_device = device; return TDX_OK; }
 

@@ -47,6 +47,15 @@ def dmarea(angfile, adecfile, dmfile, datasrc="", lyrname="", uselyrname=0, lyrn
                                               _b(wfile), int(useOutlets), int(usew), int(contcheck))
 
 
+def gridnet(pfile, plenfile, tlenfile, gordfile, maskfile="", datasrc="", lyrname="", uselyrname=0, lyrno=0, useMask=0, useOutlets=0, thresh=0):
+    return _lib.load().tdx_tool_gridnet(_b(pfile), _b(plenfile), _b(tlenfile), _b(gordfile), _b(maskfile), _b(datasrc), _b(lyrname), int(uselyrname),
+                                       int(lyrno), int(useMask), int(useOutlets), int(thresh))
+
+
+def threshold(ssafile, srcfile, maskfile="", thresh=100.0, usemask=0):
+    return _lib.load().tdx_tool_threshold(_b(ssafile), _b(srcfile), _b(maskfile), float(thresh), int(usemask))
+
+
 def nameadd(arg: str, suff: str) -> str:
     """nameadd() of src/commonLib.cpp:53-73: insert `suff` before the extension of `arg`."""
     dot = arg.rfind(".")

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import bits_equal, describe_diff, golden_cases, load_golden, outlets_to_indices
+from conftest import bits_equal, describe_diff, golden_cases, load_golden, load_golden_gridnet, outlets_to_indices
 
 CASES = golden_cases()
 
@@ -57,3 +57,21 @@ def test_dinfdecayaccum(g, oracle, key, kw):
     s = oracle.dinfdecayaccum(g["ang"], g["dm"], -3.402823466e38, -9999.0, g["dxc"], g["dyc"], weights=g["w"] if kw.get("w") else None,
                               contcheck=kw.get("contcheck", True), outlets=outlets_to_indices(g) if kw.get("o") else None)
     assert bits_equal(s, g[key]), describe_diff(s, g[key], key)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gridnet_and_threshold(name, oracle):
+    """GridNet (plain and with -mask/-thresh) and Threshold (plain and with -mask) against the reference's rasters."""
+    g, h = load_golden(name), load_golden_gridnet(name)
+    plen, tlen, gord = oracle.gridnet(g["p"], -32768, g["dxc"], g["dyc"])
+    assert bits_equal(plen, h["plen"]), describe_diff(plen, h["plen"], "plen")
+    assert bits_equal(tlen, h["tlen"]), describe_diff(tlen, h["tlen"], "tlen")
+    assert bits_equal(gord, h["gord"]), describe_diff(gord, h["gord"], "gord")
+    plen, tlen, gord = oracle.gridnet(g["p"], -32768, g["dxc"], g["dyc"], mask=h["mask_i32"], thresh=int(h["gn_thresh"]))
+    assert bits_equal(plen, h["plen_m"]), describe_diff(plen, h["plen_m"], "plen (mask)")
+    assert bits_equal(tlen, h["tlen_m"]), describe_diff(tlen, h["tlen_m"], "tlen (mask)")
+    assert bits_equal(gord, h["gord_m"]), describe_diff(gord, h["gord_m"], "gord (mask)")
+    src = oracle.threshold(g["ad8_nc"], float(h["ssa_thresh"]), -1.0)
+    assert bits_equal(src, h["src"]), describe_diff(src, h["src"], "src")
+    src = oracle.threshold(g["ad8_nc"], float(h["ssa_thresh"]), -1.0, mask=h["tmask"])
+    assert bits_equal(src, h["src_m"]), describe_diff(src, h["src_m"], "src (mask)")
