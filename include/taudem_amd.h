@@ -144,6 +144,17 @@ int tdx_threshold_dev(tdx_context* ctx, const float* d_ssa, int64_t nx, int64_t 
 int tdx_threshold(tdx_context* ctx, const float* ssa, int64_t nx, int64_t ny, float ssa_nodata,
                   const float* mask, float thresh, int16_t* src, tdx_stats* stats);
 
+/* d8flowpathextremeup() src/D8flowpathextremeup.cpp:58-285: ssa = maximum (usemax = 1) or minimum of the grid sa over everything
+ * upstream of a cell along D8 flow paths (float, nodata -FLT_MAX).  contcheck / outlets as for AreaD8; strips: as tdx_aread8_strip. */
+int tdx_d8flowpathextremeup_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
+                                const float* d_sa, int usemax, int contcheck,
+                                const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                                float* d_ssa, tdx_stats* stats);
+int tdx_d8flowpathextremeup(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata,
+                            const float* sa, int usemax, int contcheck,
+                            const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                            float* ssa, tdx_stats* stats);
+
 /* ---- DinfFlowDir -------------------------------------------------------------------------- */
 int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,
                         const double* dxc, const double* dyc, float* d_ang, float* d_slp, tdx_stats* stats);
@@ -222,6 +233,10 @@ int tdx_dinfdecayaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_an
 int tdx_aread8_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                         const float* d_w, float w_nodata, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
                         int64_t n_outlets, float* d_ad8, tdx_stats* stats);
+int tdx_d8flowpathextremeup_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local,
+                                  int16_t p_nodata, const float* d_sa, int usemax, int contcheck,
+                                  const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
+                                  float* d_ssa, tdx_stats* stats);
 
 /* ---- synthetic benchmark input (not in the reference) -------------------------------------- */
 /* Fills d_out (nx*ny float32) with the seeded fractal surface of taudem_amd/csrc/synth_dem.h for
@@ -277,6 +292,9 @@ int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const cha
 int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile,
                      const char* maskfile, const char* datasrc, const char* lyrname, int uselyrname, int lyrno,
                      int useMask, int useOutlets, int thresh);
+/* int d8flowpathextremeup(char*,char*,char*,int,char*,char*,int,int,int,int)   src/D8flowpathextremeup.cpp:58 */
+int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const char* ssafile, int usemax, const char* datasrc,
+                                 const char* lyrname, int uselyrname, int lyrno, int useOutlets, int contcheck);
 /* int threshold(char*,char*,char*,float,int)                       src/Threshold.cpp:49 */
 int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask);
 /* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */

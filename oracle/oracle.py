@@ -103,6 +103,18 @@ def aread8(p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=Tru
     return ad8
 
 
+def d8flowpathextremeup(p, sa, nodata=-32768, usemax=True, contcheck=True, outlets=None):
+    """ssa of src/D8flowpathextremeup.cpp: max / min of `sa` over everything upstream of a cell (nodata -FLT_MAX)."""
+    p = np.ascontiguousarray(p, dtype=np.int16)
+    sa = np.ascontiguousarray(sa, dtype=np.float32)
+    ny, nx = p.shape
+    ssa = np.empty((ny, nx), dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    lib().orc_d8flowpathextremeup(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(sa), C.c_int(int(usemax)), C.c_int(int(contcheck)),
+                                  ox, oy, C.c_int(no), C.c_int(use), _p(ssa))
+    return ssa
+
+
 def gridnet(p, nodata=-32768, dx=1.0, dy=1.0, mask=None, thresh=0):
     """(plen, tlen, gord) of src/gridnet.cpp without outlets; mask: int32 raster (cells with mask >= thresh are evaluated)."""
     p = np.ascontiguousarray(p, dtype=np.int16)

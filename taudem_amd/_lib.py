@@ -115,6 +115,9 @@ _SIGNATURES = {
     "tdx_d8flowdir": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
     "tdx_aread8_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_aread8": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_d8flowpathextremeup_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_d8flowpathextremeup": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_d8flowpathextremeup_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_gridnet_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "tdx_gridnet": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "tdx_threshold_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _F, _P, _P]),
@@ -143,6 +146,7 @@ _SIGNATURES = {
     "tdx_tool_areadinf": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_dinfdecayaccum": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_gridnet": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tdx_tool_d8flowpathextremeup": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_threshold": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int]),
     "tdx_tool_set_device": (C.c_int, [C.c_int]),
 }

@@ -159,6 +159,23 @@ class Context:
         del keep
         return (ad8, st.as_dict()) if stats else ad8
 
+    def d8flowpathextremeup(self, p, sa, nodata=int(P_NODATA), usemax=True, contcheck=True, outlets=None, out=None, stats=False):
+        """ssa = d8flowpathextremeup(p, sa)  (src/D8flowpathextremeup.cpp:58): upstream max / min of sa along D8 flow paths (nodata -FLT_MAX)."""
+        ny, nx = p.shape
+        ssa = out if out is not None else self._out(p, np.float32, (ny, nx))
+        pp, dev = self._ptr(p, np.int16, name="p")
+        pa, adev = self._ptr(sa, np.float32, (ny, nx), "sa")
+        ps, sdev = self._ptr(ssa, np.float32, (ny, nx), "ssa")
+        if adev != dev or sdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(p, sa)
+        check(self._pick(dev, "tdx_d8flowpathextremeup")(self._h, pp, nx, ny, int(nodata), pa, int(bool(usemax)), int(bool(contcheck)), ox, oy, no, ps,
+                                                          C.byref(st)), self._h)
+        del keep
+        return (ssa, st.as_dict()) if stats else ssa
+
     def gridnet(self, p, nodata=int(P_NODATA), dx=1.0, dy=1.0, mask=None, thresh=0, stats=False):
         """plen, tlen, gord = gridnet(p)  (src/gridnet.cpp:54, no outlets).  mask: int32 raster, cells with mask >= thresh are evaluated."""
         ny, nx = p.shape

@@ -37,6 +37,11 @@ constexpr int32_t CNT_DONE = -2;        // evaluated: what a strip neighbour loo
 // contribute (codes 16..24 = 16 + p); an outlet placed on a cell without direction participates as a pure sink
 // (code 32) - the reference evaluates such a cell from the neighbours that drain into it (src/commonLib.cpp:285-359).
 constexpr int16_t P_OUTSIDE = 16, P_SINK = 32;
+
+// The per-cell expression of the D8 dependency sweep.  SUM: AreaD8 (src/aread8.cpp:231-256).  MAX / MIN: D8FlowPathExtremeUp
+// (src/D8flowpathextremeup.cpp:167-199): the cell's own value of the input grid, then max / min with every contributor.
+enum { D8X_SUM = 0, D8X_MAX = 1, D8X_MIN = 2 };
+struct D8Expr { int mode; float out_nodata; };
 __device__ __forceinline__ bool d8_participates(int16_t p, int16_t nodata) { return !is_nodata_s(p, nodata) && ((p >= 0 && p <= 8) || p == P_SINK); }
 
 // in-degree as in initNeighborD8up (src/commonLib.cpp:251-282)
@@ -54,7 +59,7 @@ __device__ __forceinline__ int d8_indegree(const int16_t* __restrict__ P, int nx
 }
 
 __global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                        int32_t* __restrict__ cnt, float* __restrict__ A) {
+                                                        int32_t* __restrict__ cnt, float* __restrict__ A, float out_nodata) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= y_own1) return;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void ad8_setup_kernel(const int16_t* __restric
         if (c == 0) c = CNT_SOURCE;
     }
     cnt[idx] = c;
-    A[idx] = TDX_AREA_NODATA;
+    A[idx] = out_nodata;
 }
 
 // ---- outlets: upstream closure through the tile relaxation engine (flats.hpp: reach_closure) ----
@@ -132,9 +137,10 @@ __device__ __forceinline__ void ad8_load_window(const int16_t* __restrict__ P, i
 // a = w(c) [or 1]; for k = 1..8: a += A[neighbour k] if it drains into c (float32, src/aread8.cpp:231-256).  The values of
 // all contributors are requested before the first one is used: one memory round trip per cell.
 __device__ __forceinline__ float ad8_evaluate(const D8Window& w, const float* __restrict__ Wt, float w_nodata, float* __restrict__ A, int nx, int x,
-                                              int y, size_t idx, int16_t nodata, int contcheck) {
+                                              int y, size_t idx, int16_t nodata, int contcheck, D8Expr ex) {
     float a;
-    if (Wt) { const float wt = Wt[idx]; a = is_nodata_f(wt, w_nodata) ? TDX_AREA_NODATA : wt; }   // nodata weight: keeps the initial -1
+    if (ex.mode != D8X_SUM) a = Wt[idx];   // the input grid's value as it is (src/D8flowpathextremeup.cpp:170)
+    else if (Wt) { const float wt = Wt[idx]; a = is_nodata_f(wt, w_nodata) ? TDX_AREA_NODATA : wt; }   // nodata weight: keeps the initial -1
     else a = 1.0f;
     bool con = false;
     unsigned contrib = 0;
@@ -153,19 +159,22 @@ __device__ __forceinline__ float ad8_evaluate(const D8Window& w, const float* __
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
         if (!((contrib >> k) & 1u)) continue;
-        if (is_nodata_f(ak[k], TDX_AREA_NODATA)) con = true;
-        else a = a + ak[k];
+        if (is_nodata_f(ak[k], ex.out_nodata)) con = true;
+        else if (ex.mode == D8X_SUM) a = a + ak[k];
+        else if (ex.mode == D8X_MAX) { if (ak[k] > a) a = ak[k]; }
+        else { if (ak[k] < a) a = ak[k]; }
     }
-    if (con && contcheck == 1) a = TDX_AREA_NODATA;
+    if (con && contcheck == 1) a = ex.out_nodata;
     return a;
 }
 __device__ __forceinline__ void ad8_walk_from(size_t idx, const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata, int nx, int ny,
-                                              int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A) {
+                                              int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt, float* __restrict__ A,
+                                              D8Expr ex) {
     int x = int(idx % size_t(nx)), y = int(idx / size_t(nx));
     D8Window w;
     ad8_load_window(P, nx, ny, x, y, idx, w);
     for (;;) {
-        const float a = ad8_evaluate(w, Wt, w_nodata, A, nx, x, y, idx, nodata, contcheck);
+        const float a = ad8_evaluate(w, Wt, w_nodata, A, nx, x, y, idx, nodata, contcheck, ex);
         st_agent(&A[idx], a);
         cnt[idx] = CNT_DONE;   // nobody decrements an evaluated cell any more
         const int16_t k = w.pk[0];
@@ -184,13 +193,13 @@ __device__ __forceinline__ void ad8_walk_from(size_t idx, const int16_t* __restr
 
 __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata,
                                                        int nx, int ny, int y_own0, int y_own1, int16_t nodata, int contcheck,
-                                                       int32_t* __restrict__ cnt, float* __restrict__ A) {
+                                                       int32_t* __restrict__ cnt, float* __restrict__ A, D8Expr ex) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= y_own1) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     if (cnt[idx] != CNT_SOURCE) return;          // participates and has no contributor
-    ad8_walk_from(idx, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+    ad8_walk_from(idx, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A, ex);
 }
 
 // A halo row after an exchange: cells the neighbouring rank has evaluated since the last look release the owned cell
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256) void ad8_walk_kernel(const int16_t* __restrict
 __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict__ P, const float* __restrict__ Wt, float w_nodata, int nx, int ny,
                                                        int y_own0, int y_own1, int16_t nodata, int contcheck, int32_t* __restrict__ cnt,
                                                        float* __restrict__ A, int yh, const float* __restrict__ recv_a, const int32_t* __restrict__ recv_cnt,
-                                                       unsigned long long* __restrict__ nchanged) {
+                                                       unsigned long long* __restrict__ nchanged, D8Expr ex) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     bool ch = false;
     if (x < nx) {
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict
                     const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
                     drain_stores();
                     const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old == 1) ad8_walk_from(n, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A);
+                    if (old == 1) ad8_walk_from(n, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A, ex);
                 }
             }
         }
@@ -926,13 +935,14 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
 // One strip of aread8() (src/aread8.cpp:175-307).  Outlets (array coordinates) restrict the sweep to their upstream
 // closure; unit weights without TDX_AD8_WALK take the tile-contraction path, everything else the exact pull walk.
 static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_nodata, const float* d_w, float w_nodata, int contcheck,
-                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_ad8, tdx_stats* stats) {
+                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_ad8, tdx_stats* stats,
+                       D8Expr ex = D8Expr{D8X_SUM, TDX_AREA_NODATA}) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int inx = st.nx, iny = st.ny_arr;
     const size_t n = size_t(inx) * size_t(iny);
     const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
-    const bool tiled = !d_w && n < (size_t(1) << 30) && !force_walk;
+    const bool tiled = ex.mode == D8X_SUM && !d_w && n < (size_t(1) << 30) && !force_walk;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     int16_t* p_use = d_p;
     int rc;
@@ -977,17 +987,17 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_setup_kernel, grid2d, dim3(256), 0, s, p_use, inx, iny, st.y0, st.y1, p_nodata, cnt, d_ad8);
+        hipLaunchKernelGGL(ad8_setup_kernel, grid2d, dim3(256), 0, s, p_use, inx, iny, st.y0, st.y1, p_nodata, cnt, d_ad8, ex.out_nodata);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
-    rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);
+    rc = strip_exchange<float>(ctx, st, d_ad8, ex.out_nodata);
     if (rc != TDX_OK) return rc;
     rc = strip_exchange<int32_t>(ctx, st, cnt, CNT_NOT_PART);
     if (rc != TDX_OK) return rc;
     int64_t outer = 1;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL(ad8_walk_kernel, grid2d, dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8);
+        hipLaunchKernelGGL(ad8_walk_kernel, grid2d, dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8, ex);
         if (stats) stats->launches[TDX_K_ACCUM]++;
         while (st.multi()) {
             const size_t rowb = size_t(inx) * 4;
@@ -1001,10 +1011,10 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
             const unsigned gx = tdx_blocks_for(size_t(inx), 256);
             if (st.up)
                 hipLaunchKernelGGL(ad8_halo_kernel, dim3(gx), dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8,
-                                   st.y0 - 1, r_a_up, r_c_up, d_cnt + 1);
+                                   st.y0 - 1, r_a_up, r_c_up, d_cnt + 1, ex);
             if (st.down)
                 hipLaunchKernelGGL(ad8_halo_kernel, dim3(gx), dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8,
-                                   st.y1, r_a_dn, r_c_dn, d_cnt + 1);
+                                   st.y1, r_a_dn, r_c_dn, d_cnt + 1, ex);
             TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             int64_t changed = int64_t(ctx->h_mail[0]);
@@ -1060,6 +1070,52 @@ extern "C" int tdx_aread8(tdx_context* ctx, const int16_t* p, int64_t nx, int64_
     int rc = tdx_aread8_dev(ctx, d_p, nx, ny, p_nodata, d_w, w_nodata, contcheck, outlet_x, outlet_y, n_outlets, d_a, stats);
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ad8, d_a, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
+}
+
+// ---- D8FlowPathExtremeUp (src/D8flowpathextremeup.cpp:58-285): the same dependency sweep, outlets closure and strip
+// protocol as the weighted AreaD8, with max / min instead of the sum.  sa: the grid whose upstream extreme is sought; ssa: result, nodata
+// -FLT_MAX (MISSINGFLOAT, src/commonLib.h:80).
+static int extremeup_check(tdx_context* ctx, const void* p, const void* sa, const void* ssa, int64_t nx, int64_t ny, const char* who) {
+    if (!ctx || !p || !sa || !ssa || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, who);
+    return TDX_OK;
+}
+extern "C" int tdx_d8flowpathextremeup_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata, const float* d_sa, int usemax,
+                                           int contcheck, const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_ssa,
+                                           tdx_stats* stats) {
+    int rc = extremeup_check(ctx, d_p, d_sa, d_ssa, nx, ny, "tdx_d8flowpathextremeup_dev: bad argument");
+    if (rc != TDX_OK) return rc;
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull) return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "outlets missing");
+    return aread8_impl(ctx, strip_single(int(nx), int(ny)), const_cast<int16_t*>(d_p), p_nodata, d_sa, 0.f, contcheck, outlet_x, outlet_y, n_outlets, d_ssa, stats,
+                       D8Expr{usemax ? D8X_MAX : D8X_MIN, -FLT_MAX});
+}
+extern "C" int tdx_d8flowpathextremeup_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                                             const float* d_sa, int usemax, int contcheck, const int32_t* outlet_x, const int32_t* outlet_row,
+                                             int64_t n_outlets, float* d_ssa, tdx_stats* stats) {
+    int rc = extremeup_check(ctx, d_p, d_sa, d_ssa, nx, ny_local, "tdx_d8flowpathextremeup_strip: bad argument");
+    if (rc != TDX_OK) return rc;
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    if (n_outlets > 0 && (!outlet_x || !outlet_row)) return tdx_fail(ctx, TDX_ERR_ARG, "outlets missing");
+    return aread8_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, d_sa, 0.f, contcheck, outlet_x, outlet_row, n_outlets, d_ssa, stats,
+                       D8Expr{usemax ? D8X_MAX : D8X_MIN, -FLT_MAX});
+}
+extern "C" int tdx_d8flowpathextremeup(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata, const float* sa, int usemax, int contcheck,
+                                       const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* ssa, tdx_stats* stats) {
+    int rc = extremeup_check(ctx, p, sa, ssa, nx, ny, "tdx_d8flowpathextremeup: bad argument");
+    if (rc != TDX_OK) return rc;
+    const size_t n = size_t(nx) * size_t(ny);
+    int16_t* d_p = static_cast<int16_t*>(ctx->scratch(TDX_S_IO0, n * 2));
+    float* d_a = static_cast<float*>(ctx->scratch(TDX_S_IO1, n * 4));
+    float* d_w = static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4));
+    if (!d_p || !d_a || !d_w) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_p, p, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_w, sa, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = tdx_d8flowpathextremeup_dev(ctx, d_p, nx, ny, p_nodata, d_w, usemax, contcheck, outlet_x, outlet_y, n_outlets, d_a, stats);
+    if (rc != TDX_OK) return rc;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ssa, d_a, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return TDX_OK;
 }

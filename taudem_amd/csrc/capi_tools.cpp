@@ -192,6 +192,37 @@ int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfi
     return 0;
 }
 
+int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const char* ssafile, int usemax, const char* datasrc, const char* /*lyrname*/,
+                                 int /*uselyrname*/, int /*lyrno*/, int useOutlets, int contcheck) {
+    printf("D8FlowPathExtremeUp version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster p, sa;
+    int rc = load_raster(pfile, tdx::DType::I16, p);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, p.info, ox, oy); if (rc != TDX_OK) return rc; }
+    rc = load_raster(safile, tdx::DType::F32, sa);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(p.info, pfile, sa.info, safile)) { printf("File sizes do not match\n%s\n", safile); fflush(stdout); return TDX_ERR_OUTLETS; }   // src/D8flowpathextremeup.cpp:120-125
+    const double readt = now_s();
+    CtxGuard g;
+    if (g.rc != TDX_OK) return g.rc;
+    std::vector<float> ssa(p.s.size());
+    tdx_stats st;
+    rc = tdx_d8flowpathextremeup(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, sa.f.data(), usemax, contcheck,
+                                 useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, ssa.data(), &st);
+    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const double computet = now_s();
+    rc = save_raster(ssafile, tdx::DType::F32, ssa.data(), p.info, (double)TDX_ANG_NODATA);   // MISSINGFLOAT = -FLT_MAX (src/commonLib.h:80)
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+           writet - computet, writet - begint);
+    print_gpu_stats("d8flowpathextremeup", st, p.info.nx * p.info.ny);
+    return 0;
+}
+
 int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask) {
     printf("Threshold version %s\n", TDVERSION);
     fflush(stdout);

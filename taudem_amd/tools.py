@@ -52,6 +52,11 @@ def gridnet(pfile, plenfile, tlenfile, gordfile, maskfile="", datasrc="", lyrnam
                                        int(lyrno), int(useMask), int(useOutlets), int(thresh))
 
 
+def d8flowpathextremeup(pfile, safile, ssafile, usemax=1, datasrc="", lyrname="", uselyrname=0, lyrno=0, useOutlets=0, contcheck=1):
+    return _lib.load().tdx_tool_d8flowpathextremeup(_b(pfile), _b(safile), _b(ssafile), int(usemax), _b(datasrc), _b(lyrname), int(uselyrname), int(lyrno),
+                                                   int(useOutlets), int(contcheck))
+
+
 def threshold(ssafile, srcfile, maskfile="", thresh=100.0, usemask=0):
     return _lib.load().tdx_tool_threshold(_b(ssafile), _b(srcfile), _b(maskfile), float(thresh), int(usemask))
 

@@ -50,6 +50,18 @@ def make(name, ranks=1):
         res["src"], _ = T.read_raster(f("src.tif"), np.int16)
         O.run_ref("threshold", ["-ssa", f("ad8.tif"), "-src", f("srcm.tif"), "-thresh", str(ssa_thresh), "-mask", f("tmask.tif")], ranks)
         res["src_m"], _ = T.read_raster(f("srcm.tif"), np.int16)
+        # D8FlowPathExtremeUp: upstream maximum / minimum of the D8 slope grid; with -nc; restricted to outlets
+        T.write_raster(f("sd8.tif"), g["sd8"], -1.0, geotransform=gt, geographic=geographic)
+        O.run_ref("d8flowpathextremeup", ["-p", f("p.tif"), "-sa", f("sd8.tif"), "-ssa", f("xmax.tif")], ranks)
+        res["xup_max"], _ = T.read_raster(f("xmax.tif"))
+        O.run_ref("d8flowpathextremeup", ["-p", f("p.tif"), "-sa", f("sd8.tif"), "-ssa", f("xmin.tif"), "-min", "-nc"], ranks)
+        res["xup_min_nc"], _ = T.read_raster(f("xmin.tif"))
+        xs, ys = g["outlet_xy"]
+        with open(f("outlets.txt"), "w") as fh:
+            for x_, y_ in zip(xs, ys):
+                fh.write(f"{float(x_)!r} {float(y_)!r}\n")
+        O.run_ref("d8flowpathextremeup", ["-p", f("p.tif"), "-sa", f("sd8.tif"), "-ssa", f("xo.tif"), "-o", f("outlets.txt"), "-nc"], ranks)
+        res["xup_max_outlets_nc"], _ = T.read_raster(f("xo.tif"))
     np.savez_compressed(os.path.join(OUT, f"case_{name}_gridnet.npz"), **res)
     print(name, p.shape, "ranks", ranks, "max gord", int(res["gord"].max()), "max plen", float(res["plen"].max()), "src cells", int((res["src"] == 1).sum()))
 

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import bits_equal, describe_diff, golden_cases, load_golden, load_golden_gridnet
+from conftest import bits_equal, describe_diff, golden_cases, load_golden, load_golden_gridnet, outlets_to_indices
 
 pytestmark = pytest.mark.gpu
 CASES = golden_cases()
@@ -35,6 +35,31 @@ def test_golden_threshold(name, ctx):
     assert bits_equal(src, h["src"]), describe_diff(src, h["src"], "src")
     src = ctx.threshold(ssa, float(h["ssa_thresh"]), -1.0, mask=np.ascontiguousarray(h["tmask"]))
     assert bits_equal(src, h["src_m"]), describe_diff(src, h["src_m"], "src (mask)")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_d8flowpathextremeup(name, ctx):
+    g, h = load_golden(name), load_golden_gridnet(name)
+    p, sa = np.ascontiguousarray(g["p"]), np.ascontiguousarray(g["sd8"])
+    a = ctx.d8flowpathextremeup(p, sa, -32768, usemax=True, contcheck=True)
+    assert bits_equal(a, h["xup_max"]), describe_diff(a, h["xup_max"], "xup_max")
+    a = ctx.d8flowpathextremeup(p, sa, -32768, usemax=False, contcheck=False)
+    assert bits_equal(a, h["xup_min_nc"]), describe_diff(a, h["xup_min_nc"], "xup_min_nc")
+    a = ctx.d8flowpathextremeup(p, sa, -32768, usemax=True, contcheck=False, outlets=outlets_to_indices(g))
+    assert bits_equal(a, h["xup_max_outlets_nc"]), describe_diff(a, h["xup_max_outlets_nc"], "xup_max_outlets_nc")
+
+
+def test_d8flowpathextremeup_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(4)
+    dem = oracle.synth_dem((900, 1100), 21)
+    dem[100:140, 300:360] = -9999.0
+    p, sd8, _ = oracle.d8flowdir(oracle.pitremove(dem, -9999.0), -3.0e38, 30.0, 30.0)
+    sa = (rng.random(p.shape, dtype=np.float32) * 100.0 - 20.0).astype(np.float32)
+    for usemax in (True, False):
+        for cc in (True, False):
+            a_o = oracle.d8flowpathextremeup(p, sa, -32768, usemax=usemax, contcheck=cc)
+            a = ctx.d8flowpathextremeup(p, sa, -32768, usemax=usemax, contcheck=cc)
+            assert bits_equal(a, a_o), describe_diff(a, a_o, f"usemax={usemax} contcheck={cc}")
 
 
 @pytest.mark.parametrize("shape,seed", [((1, 1), 2), ((3, 3), 3), ((5, 200), 4), ((257, 301), 5), ((1000, 777), 7)])
@@ -95,6 +120,11 @@ def test_cli_gridnet_threshold(tmp_path, ctx):
     for key, name, dt in (("plen_m", "plen.tif", np.float32), ("tlen_m", "tlen.tif", np.float32), ("gord_m", "gord.tif", np.int16)):
         a, _ = T.read_raster(f(name), dt)
         assert bits_equal(a, h[key]), describe_diff(a, h[key], key)
+    T.write_raster(f("sd8.tif"), np.ascontiguousarray(g["sd8"]), -1.0, geotransform=gt)
+    out = run("d8flowpathextremeup", "-p", f("p.tif"), "-sa", f("sd8.tif"), "-ssa", f("xmin.tif"), "-min", "-nc")
+    assert "D8FlowPathExtremeUp version 5.4.0" in out
+    a, _ = T.read_raster(f("xmin.tif"), np.float32)
+    assert bits_equal(a, h["xup_min_nc"]), describe_diff(a, h["xup_min_nc"], "xup_min_nc")
     out = run("threshold", "-ssa", f("ad8.tif"), "-src", f("src.tif"), "-thresh", str(float(h["ssa_thresh"])))
     assert "Threshold version 5.4.0" in out
     a, _ = T.read_raster(f("src.tif"), np.int16)

@@ -75,3 +75,15 @@ def test_gridnet_and_threshold(name, oracle):
     assert bits_equal(src, h["src"]), describe_diff(src, h["src"], "src")
     src = oracle.threshold(g["ad8_nc"], float(h["ssa_thresh"]), -1.0, mask=h["tmask"])
     assert bits_equal(src, h["src_m"]), describe_diff(src, h["src_m"], "src (mask)")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_d8flowpathextremeup(name, oracle):
+    """Upstream maximum (with contamination check), minimum (-min -nc) and maximum restricted to outlets (-o -nc) of the D8 slope grid."""
+    g, h = load_golden(name), load_golden_gridnet(name)
+    a = oracle.d8flowpathextremeup(g["p"], g["sd8"], -32768, usemax=True, contcheck=True)
+    assert bits_equal(a, h["xup_max"]), describe_diff(a, h["xup_max"], "xup_max")
+    a = oracle.d8flowpathextremeup(g["p"], g["sd8"], -32768, usemax=False, contcheck=False)
+    assert bits_equal(a, h["xup_min_nc"]), describe_diff(a, h["xup_min_nc"], "xup_min_nc")
+    a = oracle.d8flowpathextremeup(g["p"], g["sd8"], -32768, usemax=True, contcheck=False, outlets=outlets_to_indices(g))
+    assert bits_equal(a, h["xup_max_outlets_nc"]), describe_diff(a, h["xup_max_outlets_nc"], "xup_max_outlets_nc")
