@@ -115,8 +115,8 @@ def d8flowpathextremeup(p, sa, nodata=-32768, usemax=True, contcheck=True, outle
     return ssa
 
 
-def gridnet(p, nodata=-32768, dx=1.0, dy=1.0, mask=None, thresh=0):
-    """(plen, tlen, gord) of src/gridnet.cpp without outlets; mask: int32 raster (cells with mask >= thresh are evaluated)."""
+def gridnet(p, nodata=-32768, dx=1.0, dy=1.0, mask=None, thresh=0, outlets=None):
+    """(plen, tlen, gord) of src/gridnet.cpp; mask: int32 raster (cells with mask >= thresh are evaluated); outlets: (columns, rows)."""
     p = np.ascontiguousarray(p, dtype=np.int16)
     ny, nx = p.shape
     plen = np.empty((ny, nx), dtype=np.float32)
@@ -125,7 +125,9 @@ def gridnet(p, nodata=-32768, dx=1.0, dy=1.0, mask=None, thresh=0):
     dxc, dyc = _f64(dx, ny), _f64(dy, ny)
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.int32)
-    lib().orc_gridnet(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(dxc), _p(dyc), _p(mask), C.c_int(int(thresh)), _p(plen), _p(tlen), _p(gord))
+    ox, oy, no, use, keep = _outl(outlets)
+    lib().orc_gridnet(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(dxc), _p(dyc), _p(mask), C.c_int(int(thresh)), ox, oy, C.c_int(no),
+                      C.c_int(use), _p(plen), _p(tlen), _p(gord))
     return plen, tlen, gord
 
 

@@ -62,6 +62,15 @@ def make(name, ranks=1):
                 fh.write(f"{float(x_)!r} {float(y_)!r}\n")
         O.run_ref("d8flowpathextremeup", ["-p", f("p.tif"), "-sa", f("sd8.tif"), "-ssa", f("xo.tif"), "-o", f("outlets.txt"), "-nc"], ranks)
         res["xup_max_outlets_nc"], _ = T.read_raster(f("xo.tif"))
+        # GridNet restricted to the outlets' catchments (the last two points of the list lie on nodata / outside the raster; an outlet on a
+        # nodata cell makes the reference index its neighbour tables out of range, so only the in-catchment points are used here)
+        with open(f("outlets_in.txt"), "w") as fh:
+            for x_, y_ in list(zip(xs, ys))[:4]:
+                fh.write(f"{float(x_)!r} {float(y_)!r}\n")
+        O.run_ref("gridnet", ["-p", f("p.tif"), "-plen", f("pleno.tif"), "-tlen", f("tleno.tif"), "-gord", f("gordo.tif"), "-o", f("outlets_in.txt")], ranks)
+        res["plen_o"], _ = T.read_raster(f("pleno.tif"))
+        res["tlen_o"], _ = T.read_raster(f("tleno.tif"))
+        res["gord_o"], _ = T.read_raster(f("gordo.tif"), np.int16)
     np.savez_compressed(os.path.join(OUT, f"case_{name}_gridnet.npz"), **res)
     print(name, p.shape, "ranks", ranks, "max gord", int(res["gord"].max()), "max plen", float(res["plen"].max()), "src cells", int((res["src"] == 1).sum()))
 

@@ -71,6 +71,11 @@ def test_gridnet_and_threshold(name, oracle):
     assert bits_equal(plen, h["plen_m"]), describe_diff(plen, h["plen_m"], "plen (mask)")
     assert bits_equal(tlen, h["tlen_m"]), describe_diff(tlen, h["tlen_m"], "tlen (mask)")
     assert bits_equal(gord, h["gord_m"]), describe_diff(gord, h["gord_m"], "gord (mask)")
+    ox, oy = outlets_to_indices(g)
+    plen, tlen, gord = oracle.gridnet(g["p"], -32768, g["dxc"], g["dyc"], outlets=(ox[:4], oy[:4]))   # -o: the four in-catchment points
+    assert bits_equal(plen, h["plen_o"]), describe_diff(plen, h["plen_o"], "plen (outlets)")
+    assert bits_equal(tlen, h["tlen_o"]), describe_diff(tlen, h["tlen_o"], "tlen (outlets)")
+    assert bits_equal(gord, h["gord_o"]), describe_diff(gord, h["gord_o"], "gord (outlets)")
     src = oracle.threshold(g["ad8_nc"], float(h["ssa_thresh"]), -1.0)
     assert bits_equal(src, h["src"]), describe_diff(src, h["src"], "src")
     src = oracle.threshold(g["ad8_nc"], float(h["ssa_thresh"]), -1.0, mask=h["tmask"])
