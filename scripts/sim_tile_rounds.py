@@ -17,7 +17,7 @@ sys.path.insert(0, '/root/repo')
 from oracle import oracle as O
 O.build()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-TS = 64
+TS = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 FILTER = len(sys.argv) > 2 and sys.argv[2] == 'filter'
 Z = O.synth_dem(N, 1234).astype(np.float32)
 INF = np.float32(3.0e38)
