@@ -207,9 +207,43 @@ typedef struct tdx_comm {
     int (*allreduce)(void* user, int64_t* values, int32_t count, int32_t op);
     void* send_up; void* send_down; void* recv_up; void* recv_down;
     uint64_t capacity;
+    /* ---- optional extensions (zero / NULL = the host-synchronous contract above) ---- */
+    uint64_t flags;       /* TDX_COMM_STREAM_ORDERED: exchange() ENQUEUES on the context's stream (tdx_stream) and completes in
+                           * stream order; the library then neither synchronises before calling it nor expects completion on return */
+    /* in-place reduction of `count` int64 DEVICE values, enqueued on the context's stream (NULL: the library copies the values
+     * to the host and calls allreduce).  Lets a termination vote travel device -> RCCL -> device -> host with ONE synchronisation. */
+    int (*allreduce_dev)(void* user, int64_t* d_values, int32_t count, int32_t op);
 } tdx_comm;
 #define TDX_OP_SUM 0
 #define TDX_OP_MAX 1
+#define TDX_COMM_STREAM_ORDERED 1ull
+
+/* ---- native transports for tdx_comm (taudem_amd/csrc/comm.cpp) ------------------------------------------------------
+ * (1) RCCL, one process per GPU (the launch contract of `mpiexec -n P tool`, src/linearpart.h:133-134,194-219,343-384):
+ *     rank 0 calls tdx_rccl_unique_id and hands the 128 bytes to the other ranks by any means (torch.distributed store,
+ *     MPI_Bcast, a file); every rank calls tdx_rccl_comm_create.  Boundary rows travel as grouped ncclSend/ncclRecv on the
+ *     context's stream, votes as ncclAllReduce on device values: stream-ordered, no host round trip per exchange.
+ * (2) RCCL or peer copies, ONE process driving N GPUs with one thread per GPU (what `tool --gpus N` uses): tdx_group_create
+ *     builds N contexts and N communicators (ncclCommInitAll when the devices are distinct; host-synchronous peer copies
+ *     between the threads' buffers when TAUDEM_AMD_COMM=peer or when several ranks share a device); tdx_group_comm(g, r) is
+ *     rank r's tdx_comm, to be used from rank r's thread only. */
+typedef struct tdx_rccl_comm tdx_rccl_comm;
+#define TDX_RCCL_ID_BYTES 128
+int tdx_rccl_unique_id(void* id128);
+int tdx_rccl_comm_create(tdx_context* ctx, const void* id128, int32_t rank, int32_t size, int64_t nx, tdx_rccl_comm** out);
+const tdx_comm* tdx_rccl_comm_handle(tdx_rccl_comm* c);
+void tdx_rccl_comm_counters(const tdx_rccl_comm* c, int64_t* exchanges, int64_t* allreduces);
+void tdx_rccl_comm_destroy(tdx_rccl_comm* c);
+/* loop-back self test of the transport on one rank (send/recv to self + all-reduce): 0 = the RCCL calls work on this box */
+int tdx_rccl_selftest(tdx_context* ctx);
+
+typedef struct tdx_group tdx_group;
+/* devices[size]: HIP device of every rank (repeats allowed: several ranks then share a GPU and the peer transport is used) */
+int tdx_group_create(int32_t size, const int32_t* devices, int64_t nx, tdx_group** out);
+tdx_context* tdx_group_context(tdx_group* g, int32_t rank);
+const tdx_comm* tdx_group_comm(tdx_group* g, int32_t rank);
+const char* tdx_group_transport(const tdx_group* g);   /* "rccl" | "peer" */
+void tdx_group_destroy(tdx_group* g);
 
 /* Strip variants of the device entry points (comm == NULL or comm->size == 1: a single strip whose halo
  * rows lie outside the raster).  All raster pointers are DEVICE strip arrays of (ny_local + 2) x nx. */
@@ -299,6 +333,9 @@ int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const ch
 int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask);
 /* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */
 int tdx_tool_set_device(int device);
+/* number of GPUs the tdx_tool_* functions partition the raster over (row strips, one thread per GPU; default 1 / env
+ * TAUDEM_AMD_GPUS; the command-line tools take --gpus N).  Replaces `mpiexec -n P` (src/linearpart.h:133-134). */
+int tdx_tool_set_gpus(int ngpus);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,8 @@ class TdxComm(C.Structure):
         ("recv_up", C.c_void_p),
         ("recv_down", C.c_void_p),
         ("capacity", C.c_uint64),
+        ("flags", C.c_uint64),              # 0: host-synchronous contract (this Python transport)
+        ("allreduce_dev", C.c_void_p),      # NULL: votes travel through `allreduce` on host values
     ]
 
 
@@ -149,6 +151,18 @@ _SIGNATURES = {
     "tdx_tool_d8flowpathextremeup": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_threshold": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int]),
     "tdx_tool_set_device": (C.c_int, [C.c_int]),
+    "tdx_tool_set_gpus": (C.c_int, [C.c_int]),
+    "tdx_rccl_unique_id": (C.c_int, [_P]),
+    "tdx_rccl_comm_create": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _I64, C.POINTER(_P)]),
+    "tdx_rccl_comm_handle": (_P, [_P]),
+    "tdx_rccl_comm_counters": (None, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "tdx_rccl_comm_destroy": (None, [_P]),
+    "tdx_rccl_selftest": (C.c_int, [_P]),
+    "tdx_group_create": (C.c_int, [C.c_int32, _P, _I64, C.POINTER(_P)]),
+    "tdx_group_context": (_P, [_P, C.c_int32]),
+    "tdx_group_comm": (_P, [_P, C.c_int32]),
+    "tdx_group_transport": (C.c_char_p, [_P]),
+    "tdx_group_destroy": (None, [_P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -863,10 +863,8 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
             TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 1, 0, sizeof(unsigned long long), s));
             hipLaunchKernelGGL(ad8_forest_deliver_kernel, dim3(tdx_blocks_for(size_t(2 * st.nx), 256)), dim3(256), 0, s, g, inbox, delivered, node_acc,
                                node_indeg, node_next, outbox, d_cnt + 1);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            int64_t got = int64_t(ctx->h_mail[0]);
-            rc = strip_allreduce(ctx, st, &got, 1, TDX_OP_SUM);
+            int64_t got = 0;
+            rc = strip_allreduce_device(ctx, st, d_cnt + 1, 1, TDX_OP_SUM, &got);   // the vote: device counter -> all ranks -> host, one synchronisation
             if (rc != TDX_OK) return rc;
             if (stats) stats->launches[TDX_K_ACCUM]++;
             if (got == 0) break;
@@ -942,7 +940,18 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
     const int inx = st.nx, iny = st.ny_arr;
     const size_t n = size_t(inx) * size_t(iny);
     const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
-    const bool tiled = ex.mode == D8X_SUM && !d_w && n < (size_t(1) << 30) && !force_walk;
+    // The tile contraction carries exact cell counts in 32-bit words (node_acc, the apply pass's LDS counters, the big-cell
+    // sort keys): a count is at most the number of cells of the WHOLE raster, so the raster (all strips) must hold fewer
+    // than 2^32 cells.  Larger rasters take the pull walk, whose float32 adds have no such limit.
+    // TDX_AD8_COUNT_LIMIT: test hook for that switch.
+    bool tiled = ex.mode == D8X_SUM && !d_w && !force_walk;
+    if (tiled) {
+        int64_t cells = int64_t(st.nx) * int64_t(st.y1 - st.y0);
+        int rc0 = strip_allreduce(ctx, st, &cells, 1, TDX_OP_SUM);
+        if (rc0 != TDX_OK) return rc0;
+        const int64_t limit = getenv("TDX_AD8_COUNT_LIMIT") ? atoll(getenv("TDX_AD8_COUNT_LIMIT")) : int64_t(0xFFFFFFFFll);
+        if (cells > limit) tiled = false;
+    }
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     int16_t* p_use = d_p;
     int rc;
@@ -1015,10 +1024,8 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
             if (st.down)
                 hipLaunchKernelGGL(ad8_halo_kernel, dim3(gx), dim3(256), 0, s, p_use, d_w, w_nodata, inx, iny, st.y0, st.y1, p_nodata, contcheck, cnt, d_ad8,
                                    st.y1, r_a_dn, r_c_dn, d_cnt + 1, ex);
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            int64_t changed = int64_t(ctx->h_mail[0]);
-            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            int64_t changed = 0;
+            rc = strip_allreduce_device(ctx, st, d_cnt + 1, 1, TDX_OP_SUM, &changed);   // the vote: device counter -> all ranks -> host, one synchronisation
             if (rc != TDX_OK) return rc;
             if (stats) stats->launches[TDX_K_ACCUM]++;
             if (changed == 0) break;

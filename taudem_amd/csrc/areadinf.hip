@@ -471,10 +471,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                                    st.y1, r_out_dn, r_cnt_dn, lst, d_cnt, ovf_cap, d_cnt + 1);
             rc = drain_overflow();
             if (rc != TDX_OK) return rc;
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            int64_t changed = int64_t(ctx->h_mail[0]);
-            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            int64_t changed = 0;
+            rc = strip_allreduce_device(ctx, st, d_cnt + 1, 1, TDX_OP_SUM, &changed);   // the vote: device counter -> all ranks -> host, one synchronisation
             if (rc != TDX_OK) return rc;
             if (changed == 0) break;
             outer++;

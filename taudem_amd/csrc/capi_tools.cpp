@@ -1,6 +1,7 @@
 // File-level tool functions: same argument lists, banners, timing blocks and error codes as the
-// reference's tool functions, with the compute part on the GPU.  One process drives one device here;
-// multi-GPU strips are orchestrated one process per GPU by taudem_amd/distributed.py over RCCL.
+// reference's tool functions, with the compute part on the GPU.  `tool --gpus N` / TAUDEM_AMD_GPUS=N / tdx_tool_set_gpus(N)
+// partitions the raster into N row strips, one GPU (and one host thread) each, exchanging boundary rows over RCCL
+// (tool_strips.hpp, comm.cpp) - the place of `mpiexec -n N` in the reference.
 //   tdx_tool_pitremove       <- flood()     src/flood.cpp:50-526
 //   tdx_tool_d8flowdir       <- setdird8()  src/d8.cpp:181-355
 //   tdx_tool_aread8          <- aread8()    src/aread8.cpp:56-322
@@ -18,12 +19,14 @@
 #include "context.hpp"
 #include "geotiff.hpp"
 #include "outlets.hpp"
+#include "tool_strips.hpp"
 
 #define TDVERSION "5.4.0"   /* src/commonLib.h:63 */
 
 namespace {
 
 int g_tool_device = -1;
+int g_tool_gpus = -1;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -32,6 +35,12 @@ int tool_device() {
     const char* e = getenv("TAUDEM_AMD_DEVICE");
     return e ? atoi(e) : 0;
 }
+int tool_gpus() {
+    int n = g_tool_gpus;
+    if (n < 1) { const char* e = getenv("TAUDEM_AMD_GPUS"); n = e ? atoi(e) : 1; }
+    return n < 1 ? 1 : n;
+}
+void report(tdx_context* c) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(c)); }
 bool want_lzw() {
     const char* e = getenv("TAUDEM_AMD_COMPRESS");
     if (e && (strcmp(e, "NONE") == 0 || strcmp(e, "none") == 0)) return false;
@@ -206,18 +215,33 @@ int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const ch
     if (rc != TDX_OK) return rc;
     if (!compare_rasters(p.info, pfile, sa.info, safile)) { printf("File sizes do not match\n%s\n", safile); fflush(stdout); return TDX_ERR_OUTLETS; }   // src/D8flowpathextremeup.cpp:120-125
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     std::vector<float> ssa(p.s.size());
     tdx_stats st;
-    rc = tdx_d8flowpathextremeup(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, sa.f.data(), usemax, contcheck,
-                                 useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, ssa.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            int16_t* d_p = j.strip<int16_t>(p.s.data());
+            float* d_sa = j.strip<float>(sa.f.data());
+            float* d_out = j.strip<float>(nullptr);
+            if (!d_p || !d_sa || !d_out) return TDX_ERR_NOMEM;
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_d8flowpathextremeup_strip(j.ctx, j.comm, d_p, j.nx, j.nyl, (int16_t)p.info.nodata, d_sa, usemax, contcheck, useOutlets ? ox.data() : nullptr,
+                                                        useOutlets ? lrow.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, d_out, s);
+            return e != TDX_OK ? e : (j.fetch(ssa.data(), d_out) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_d8flowpathextremeup(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, sa.f.data(), usemax, contcheck,
+                                     useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, ssa.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     rc = save_raster(ssafile, tdx::DType::F32, ssa.data(), p.info, (double)TDX_ANG_NODATA);   // MISSINGFLOAT = -FLT_MAX (src/commonLib.h:80)
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
-    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt,
            writet - computet, writet - begint);
     print_gpu_stats("d8flowpathextremeup", st, p.info.nx * p.info.ny);
     return 0;
@@ -252,6 +276,7 @@ int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* mas
 }
 
 int tdx_tool_set_device(int device) { g_tool_device = device; return TDX_OK; }
+int tdx_tool_set_gpus(int ngpus) { g_tool_gpus = ngpus; return TDX_OK; }
 
 int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* /*sfdrfile*/, int /*usesfdr*/,
                        int verbose, int is_4Point, int use_mask, const char* maskfile) {
@@ -272,13 +297,26 @@ int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* /*s
     }
     const double readt = now_s();
     if (verbose) { printf("Header read\nData read\n"); if (use_mask) printf("Process: 0, Using depression mask data...\n"); fflush(stdout); }
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     std::vector<float> fel(dem.f.size());
     tdx_stats st;
-    rc = tdx_pitremove(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, use_mask ? mask.s.data() : nullptr,
-                       is_4Point, fel.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_dem = j.strip<float>(dem.f.data());
+            int16_t* d_mask = use_mask ? j.strip<int16_t>(mask.s.data()) : nullptr;
+            float* d_fel = j.strip<float>(nullptr);
+            if (!d_dem || !d_fel || (use_mask && !d_mask)) return TDX_ERR_NOMEM;
+            const int e = tdx_pitremove_strip(j.ctx, j.comm, d_dem, j.nx, j.nyl, (float)dem.info.nodata, d_mask, is_4Point, d_fel, s);
+            return e != TDX_OK ? e : (j.fetch(fel.data(), d_fel) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_pitremove(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, use_mask ? mask.s.data() : nullptr,
+                           is_4Point, fel.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     if (verbose) printf("Process: 0, Pass: %lld, Remaining: 0\n", (long long)st.rounds);
     const double computet = now_s();
     const float felNodata = -3.0e38f;
@@ -286,7 +324,7 @@ int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* /*s
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
     printf("Processes: %d\nHeader read time: %f\nData read time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n",
-           1, 0.0, readt - begint, computet - readt, writet - computet, writet - begint);
+           nproc, 0.0, readt - begint, computet - readt, writet - computet, writet - begint);
     print_gpu_stats("pitremove", st, dem.info.nx * dem.info.ny);
     return 0;
 }
@@ -305,15 +343,30 @@ int tdx_tool_d8flowdir(const char* demfile, const char* pointfile, const char* s
     int rc = load_raster(demfile, tdx::DType::F32, dem);
     if (rc != TDX_OK) return rc;
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     const size_t n = dem.f.size();
     std::vector<int16_t> p(n);
     std::vector<float> sd8(n);
     tdx_stats st;
-    rc = tdx_d8flowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
-                       p.data(), sd8.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_fel = j.strip<float>(dem.f.data());
+            int16_t* d_p = j.strip<int16_t>(nullptr);
+            float* d_sd8 = j.strip<float>(nullptr);
+            if (!d_fel || !d_p || !d_sd8) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(dem.info.dxc), dys = j.rows_of(dem.info.dyc);
+            const int e = tdx_d8flowdir_strip(j.ctx, j.comm, d_fel, j.nx, j.nyl, (float)dem.info.nodata, dxs.data(), dys.data(), d_p, d_sd8, s);
+            if (e != TDX_OK) return e;
+            return (j.fetch(p.data(), d_p) && j.fetch(sd8.data(), d_sd8)) ? TDX_OK : TDX_ERR_HIP;
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_d8flowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
+                           p.data(), sd8.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     fprintf(stderr, "All slopes evaluated. %ld flats to resolve.\n", (long)st.flats_initial);
     if (st.flat_iterations > 0 && st.flats_left > 0) fprintf(stderr, "Iteration complete. Number of flats remaining: %ld\n", (long)st.flats_left);
@@ -325,7 +378,7 @@ int tdx_tool_d8flowdir(const char* demfile, const char* pointfile, const char* s
     const double writet = now_s();
     const double slope_s = st.ms_kernel[TDX_K_STENCIL] / 1000.0;
     printf("Processors: %d\nHeader read time: %f\nData read time: %f\nCompute Slope time: %f\nWrite Slope time: %f\nResolve Flat time: %f\nWrite Flat time: %f\nTotal time: %f\n",
-           1, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
+           nproc, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
     print_gpu_stats("d8flowdir", st, dem.info.nx * dem.info.ny);
     return 0;
 }
@@ -350,18 +403,33 @@ int tdx_tool_aread8(const char* pfile, const char* afile, const char* datasrc, c
         if (!compare_rasters(p.info, pfile, w.info, wfile)) { printf("File sizes do not match\n%s\n", wfile); fflush(stdout); return TDX_ERR_OUTLETS; }
     }
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     std::vector<float> a(p.s.size());
     tdx_stats st;
-    rc = tdx_aread8(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, usew ? w.f.data() : nullptr, usew ? (float)w.info.nodata : 0.f,
-                    contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, a.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            int16_t* d_p = j.strip<int16_t>(p.s.data());
+            float* d_w = usew ? j.strip<float>(w.f.data()) : nullptr;
+            float* d_a = j.strip<float>(nullptr);
+            if (!d_p || !d_a || (usew && !d_w)) return TDX_ERR_NOMEM;
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_aread8_strip(j.ctx, j.comm, d_p, j.nx, j.nyl, (int16_t)p.info.nodata, d_w, usew ? (float)w.info.nodata : 0.f, contcheck,
+                                           useOutlets ? ox.data() : nullptr, useOutlets ? lrow.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, d_a, s);
+            return e != TDX_OK ? e : (j.fetch(a.data(), d_a) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_aread8(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, usew ? w.f.data() : nullptr, usew ? (float)w.info.nodata : 0.f,
+                        contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, a.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     rc = save_raster(afile, tdx::DType::F32, a.data(), p.info, -1.0);
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
-    printf("Number of Processes: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+    printf("Number of Processes: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt,
            writet - computet, writet - begint);
     print_gpu_stats("aread8", st, p.info.nx * p.info.ny);
     return 0;
@@ -375,14 +443,29 @@ int tdx_tool_dinfflowdir(const char* demfile, const char* angfile, const char* s
     int rc = load_raster(demfile, tdx::DType::F32, dem);
     if (rc != TDX_OK) return rc;
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     const size_t n = dem.f.size();
     std::vector<float> ang(n), slp(n);
     tdx_stats st;
-    rc = tdx_dinfflowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
-                         ang.data(), slp.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_fel = j.strip<float>(dem.f.data());
+            float* d_ang = j.strip<float>(nullptr);
+            float* d_slp = j.strip<float>(nullptr);
+            if (!d_fel || !d_ang || !d_slp) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(dem.info.dxc), dys = j.rows_of(dem.info.dyc);
+            const int e = tdx_dinfflowdir_strip(j.ctx, j.comm, d_fel, j.nx, j.nyl, (float)dem.info.nodata, dxs.data(), dys.data(), d_ang, d_slp, s);
+            if (e != TDX_OK) return e;
+            return (j.fetch(ang.data(), d_ang) && j.fetch(slp.data(), d_slp)) ? TDX_OK : TDX_ERR_HIP;
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinfflowdir(g.c, dem.f.data(), dem.info.nx, dem.info.ny, (float)dem.info.nodata, dem.info.dxc.data(), dem.info.dyc.data(),
+                             ang.data(), slp.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     fprintf(stderr, "All slopes evaluated. %ld flats to resolve.\n", (long)st.flats_initial);
     rc = save_raster(slopefile, tdx::DType::F32, slp.data(), dem.info, -1.0);
@@ -393,7 +476,7 @@ int tdx_tool_dinfflowdir(const char* demfile, const char* angfile, const char* s
     const double writet = now_s();
     const double slope_s = st.ms_kernel[TDX_K_STENCIL] / 1000.0;
     printf("Processors: %d\nHeader read time: %f\nData read time: %f\nCompute Slope time: %f\nWrite Slope time: %f\nResolve Flat time: %f\nWrite Flat time: %f\nTotal time: %f\n",
-           1, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
+           nproc, 0.0, readt - begint, slope_s, writeSlopet - computet, (computet - readt) - slope_s, writet - writeSlopet, writet - begint);
     print_gpu_stats("dinfflowdir", st, dem.info.nx * dem.info.ny);
     return 0;
 }
@@ -413,19 +496,35 @@ int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* data
         if (!compare_rasters(ang.info, angfile, w.info, wfile)) return TDX_ERR_MISMATCH;   // src/areadinf.cpp:134
     }
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     std::vector<float> sca(ang.f.size());
     tdx_stats st;
-    rc = tdx_areadinf(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
-                      usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr,
-                      useOutlets ? int64_t(ox.size()) : -1, sca.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            float* d_w = usew ? j.strip<float>(w.f.data()) : nullptr;
+            float* d_out = j.strip<float>(nullptr);
+            if (!d_ang || !d_out || (usew && !d_w)) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_areadinf_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_w, contcheck,
+                                             useOutlets ? ox.data() : nullptr, useOutlets ? lrow.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, d_out, s);
+            return e != TDX_OK ? e : (j.fetch(sca.data(), d_out) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_areadinf(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
+                          usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr,
+                          useOutlets ? int64_t(ox.size()) : -1, sca.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     rc = save_raster(scafile, tdx::DType::F32, sca.data(), ang.info, -1.0);
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
-    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt,
            writet - computet, writet - begint);
     print_gpu_stats("areadinf", st, ang.info.nx * ang.info.ny);
     return 0;
@@ -449,19 +548,37 @@ int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const cha
         if (!compare_rasters(ang.info, angfile, w.info, wfile)) { printf("File sizes do not match\n%s\n", wfile); fflush(stdout); return TDX_ERR_OUTLETS; }
     }
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     std::vector<float> out(ang.f.size());
     tdx_stats st;
-    rc = tdx_dinfdecayaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
-                            dm.f.data(), (float)dm.info.nodata, usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr,
-                            useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, out.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            float* d_dm = j.strip<float>(dm.f.data());
+            float* d_w = usew ? j.strip<float>(w.f.data()) : nullptr;
+            float* d_out = j.strip<float>(nullptr);
+            if (!d_ang || !d_dm || !d_out || (usew && !d_w)) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_dinfdecayaccum_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_dm, (float)dm.info.nodata, d_w,
+                                                   contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? lrow.data() : nullptr,
+                                                   useOutlets ? int64_t(ox.size()) : -1, d_out, s);
+            return e != TDX_OK ? e : (j.fetch(out.data(), d_out) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinfdecayaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(),
+                                dm.f.data(), (float)dm.info.nodata, usew ? w.f.data() : nullptr, contcheck, useOutlets ? ox.data() : nullptr,
+                                useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, out.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     rc = save_raster(adecfile, tdx::DType::F32, out.data(), ang.info, (double)TDX_ANG_NODATA);
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
-    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt,
            writet - computet, writet - begint);
     print_gpu_stats("dinfdecayaccum", st, ang.info.nx * ang.info.ny);
     return 0;

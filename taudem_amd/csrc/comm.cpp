@@ -1,0 +1,354 @@
+// Native transports behind tdx_comm (include/taudem_amd.h): what linearpart<T>::share() / passBorders() / ringTerm() /
+// MPI_Allreduce are in the reference (src/linearpart.h:194-219, 301-384), for row strips that live in HBM.
+//
+//   RCCL (xGMI)   one communicator rank per GPU.  A boundary-row exchange is ONE grouped ncclSend/ncclRecv pair per strip
+//                 neighbour, enqueued on the context's stream (stream-ordered: the library does not synchronise around it);
+//                 a termination vote is an ncclAllReduce on DEVICE int64 values followed by one device->host copy.  Used
+//                 by one-process-per-GPU launches (tdx_rccl_comm_create, ids distributed by the launcher) and by the
+//                 one-process-N-threads group (ncclCommInitAll).
+//   peer          one process, one thread per rank: a rank copies its neighbours' send buffers into its own receive
+//                 buffers (hipMemcpyAsync between peer devices = one xGMI transfer, or a local copy when ranks share a
+//                 GPU) between two host barriers.  Host-synchronous contract; needs no communication library, so it also
+//                 runs N ranks on ONE GPU (how the multi-strip command-line path is tested on a 1-GPU box).
+//
+// librccl is opened lazily (dlopen) the first time a transport needs it: single-GPU tools never load its 570 MB.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "context.hpp"
+
+namespace {
+
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string err;
+};
+
+RcclApi load_rccl() {
+    RcclApi a;
+    void* h = nullptr;
+    // a copy that is already mapped (PyTorch-ROCm bundles one) wins: two RCCLs in one process would each own a topology
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { a.err = std::string("cannot open librccl: ") + dlerror(); return a; }
+#define TDX_SYM(name)                                                                  \
+    a.name = reinterpret_cast<decltype(a.name)>(dlsym(h, "nccl" #name));              \
+    if (!a.name) { a.err = "librccl lacks nccl" #name; return a; }
+    TDX_SYM(GetUniqueId) TDX_SYM(CommInitRank) TDX_SYM(CommInitAll) TDX_SYM(CommDestroy) TDX_SYM(Send) TDX_SYM(Recv) TDX_SYM(AllReduce)
+    TDX_SYM(GroupStart) TDX_SYM(GroupEnd) TDX_SYM(GetErrorString)
+#undef TDX_SYM
+    a.ok = true;
+    return a;
+}
+RcclApi& rccl() {
+    static RcclApi api = load_rccl();
+    return api;
+}
+
+#define TDX_NCCL(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) {                                                                               \
+            g_tdx_thread_error = std::string(#expr) + ": " + rccl().GetErrorString(_r);                       \
+            return 1;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+
+class HostBarrier {   // sense-reversing barrier of the rank threads of one process
+public:
+    explicit HostBarrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        const unsigned gen = gen_;
+        if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen_ != gen; });
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    unsigned gen_ = 0;
+};
+
+constexpr int RED_MAX = 16;
+
+}  // namespace
+
+struct tdx_rccl_comm {
+    tdx_context* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    tdx_comm c{};
+    char* bufs = nullptr;        // 4 x capacity bytes of device memory: send_up send_down recv_up recv_down
+    int64_t* d_red = nullptr;    // RED_MAX device words for host-value votes
+    int64_t* h_red = nullptr;    // pinned twin
+    int64_t exchanges = 0, allreduces = 0;
+};
+
+namespace {
+
+int rccl_exchange(void* user, uint64_t bytes) {
+    tdx_rccl_comm* r = static_cast<tdx_rccl_comm*>(user);
+    RcclApi& a = rccl();
+    const int rank = r->c.rank, size = r->c.size;
+    hipStream_t s = r->ctx->stream;
+    r->exchanges++;
+    TDX_NCCL(a.GroupStart());
+    if (rank > 0) {
+        TDX_NCCL(a.Send(r->c.send_up, bytes, ncclChar, rank - 1, r->comm, s));
+        TDX_NCCL(a.Recv(r->c.recv_up, bytes, ncclChar, rank - 1, r->comm, s));
+    }
+    if (rank < size - 1) {
+        TDX_NCCL(a.Send(r->c.send_down, bytes, ncclChar, rank + 1, r->comm, s));
+        TDX_NCCL(a.Recv(r->c.recv_down, bytes, ncclChar, rank + 1, r->comm, s));
+    }
+    TDX_NCCL(a.GroupEnd());
+    return 0;
+}
+int rccl_allreduce_dev(void* user, int64_t* d_values, int32_t count, int32_t op) {
+    tdx_rccl_comm* r = static_cast<tdx_rccl_comm*>(user);
+    r->allreduces++;
+    TDX_NCCL(rccl().AllReduce(d_values, d_values, size_t(count), ncclInt64, op == TDX_OP_MAX ? ncclMax : ncclSum, r->comm, r->ctx->stream));
+    return 0;
+}
+int rccl_allreduce(void* user, int64_t* values, int32_t count, int32_t op) {
+    tdx_rccl_comm* r = static_cast<tdx_rccl_comm*>(user);
+    if (count > RED_MAX) { g_tdx_thread_error = "tdx_comm allreduce: more than 16 values"; return 1; }
+    hipStream_t s = r->ctx->stream;
+    memcpy(r->h_red, values, size_t(count) * 8);
+    if (hipMemcpyAsync(r->d_red, r->h_red, size_t(count) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+    if (rccl_allreduce_dev(user, r->d_red, count, op) != 0) return 1;
+    if (hipMemcpyAsync(r->h_red, r->d_red, size_t(count) * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    memcpy(values, r->h_red, size_t(count) * 8);
+    return 0;
+}
+
+// buffers + callbacks around an existing communicator rank
+int rccl_wrap(tdx_context* ctx, ncclComm_t comm, int rank, int size, int64_t nx, tdx_rccl_comm** out) {
+    tdx_rccl_comm* r = new tdx_rccl_comm;
+    r->ctx = ctx; r->comm = comm;
+    const uint64_t cap = uint64_t(nx) * 16;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&r->bufs), size_t(cap) * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&r->d_red), RED_MAX * 8) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&r->h_red), RED_MAX * 8) != hipSuccess) {
+        delete r;
+        return tdx_fail(ctx, TDX_ERR_NOMEM, "tdx_rccl_comm: cannot allocate the exchange buffers");
+    }
+    r->c.rank = rank; r->c.size = size; r->c.user = r;
+    r->c.exchange = rccl_exchange; r->c.allreduce = rccl_allreduce; r->c.allreduce_dev = rccl_allreduce_dev;
+    r->c.send_up = r->bufs; r->c.send_down = r->bufs + cap; r->c.recv_up = r->bufs + 2 * cap; r->c.recv_down = r->bufs + 3 * cap;
+    r->c.capacity = cap;
+    r->c.flags = TDX_COMM_STREAM_ORDERED;
+    *out = r;
+    return TDX_OK;
+}
+
+}  // namespace
+
+extern "C" int tdx_rccl_unique_id(void* id128) {
+    if (!id128) return tdx_fail(nullptr, TDX_ERR_ARG, "tdx_rccl_unique_id: null");
+    if (!rccl().ok) return tdx_fail(nullptr, TDX_ERR_HIP, rccl().err);
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return tdx_fail(nullptr, TDX_ERR_HIP, "ncclGetUniqueId failed");
+    static_assert(sizeof(id) == TDX_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return TDX_OK;
+}
+
+extern "C" int tdx_rccl_comm_create(tdx_context* ctx, const void* id128, int32_t rank, int32_t size, int64_t nx, tdx_rccl_comm** out) {
+    if (!ctx || !id128 || !out || size < 1 || rank < 0 || rank >= size || nx <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_rccl_comm_create: bad argument");
+    if (!rccl().ok) return tdx_fail(ctx, TDX_ERR_HIP, rccl().err);
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = rccl().CommInitRank(&comm, size, id, rank);
+    if (r != ncclSuccess) return tdx_fail(ctx, TDX_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    const int rc = rccl_wrap(ctx, comm, rank, size, nx, out);
+    if (rc != TDX_OK) rccl().CommDestroy(comm);
+    return rc;
+}
+extern "C" const tdx_comm* tdx_rccl_comm_handle(tdx_rccl_comm* c) { return c ? &c->c : nullptr; }
+extern "C" void tdx_rccl_comm_counters(const tdx_rccl_comm* c, int64_t* exchanges, int64_t* allreduces) {
+    if (exchanges) *exchanges = c ? c->exchanges : 0;
+    if (allreduces) *allreduces = c ? c->allreduces : 0;
+}
+extern "C" void tdx_rccl_comm_destroy(tdx_rccl_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) rccl().CommDestroy(c->comm);
+    (void)hipFree(c->bufs); (void)hipFree(c->d_red); (void)hipHostFree(c->h_red);
+    delete c;
+}
+
+// One rank talking to itself: the send/recv pair, the device vote and the host vote, on the context's stream.
+extern "C" int tdx_rccl_selftest(tdx_context* ctx) {
+    if (!ctx) return tdx_fail(nullptr, TDX_ERR_ARG, "tdx_rccl_selftest: null context");
+    unsigned char id[TDX_RCCL_ID_BYTES];
+    int rc = tdx_rccl_unique_id(id);
+    if (rc != TDX_OK) return rc;
+    tdx_rccl_comm* r = nullptr;
+    rc = tdx_rccl_comm_create(ctx, id, 0, 1, 1024, &r);
+    if (rc != TDX_OK) return rc;
+    RcclApi& a = rccl();
+    hipStream_t s = ctx->stream;
+    const size_t bytes = 4096;
+    int fail = 0;
+    std::vector<unsigned char> h(bytes), back(bytes, 0);
+    for (size_t i = 0; i < bytes; i++) h[i] = (unsigned char)(i * 7 + 3);
+    if (hipMemcpyAsync(r->c.send_up, h.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) fail = 1;
+    if (!fail && (a.GroupStart() != ncclSuccess || a.Send(r->c.send_up, bytes, ncclChar, 0, r->comm, s) != ncclSuccess ||
+                  a.Recv(r->c.recv_down, bytes, ncclChar, 0, r->comm, s) != ncclSuccess || a.GroupEnd() != ncclSuccess)) fail = 2;
+    if (!fail && hipMemcpyAsync(back.data(), r->c.recv_down, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) fail = 3;
+    int64_t v[2] = {41, -7};
+    if (!fail && r->c.allreduce(r, v, 2, TDX_OP_SUM) != 0) fail = 4;   // synchronises the stream
+    if (!fail && (v[0] != 41 || v[1] != -7 || back != h)) fail = 5;
+    if (!fail && r->c.exchange(r, 64) != 0) fail = 6;                  // size 1: no neighbour, an empty group
+    if (!fail && hipStreamSynchronize(s) != hipSuccess) fail = 7;
+    tdx_rccl_comm_destroy(r);
+    if (fail) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_rccl_selftest failed at step " + std::to_string(fail) + (g_tdx_thread_error.empty() ? "" : ": " + g_tdx_thread_error));
+    return TDX_OK;
+}
+
+// ---- one process, N rank threads ---------------------------------------------------------------------------------------
+struct tdx_group {
+    int size = 0;
+    std::string transport;
+    std::vector<tdx_context*> ctxs;
+    std::vector<tdx_rccl_comm*> rc;       // "rccl"
+    struct PeerRank { tdx_group* g; int rank; tdx_comm c; char* bufs; };
+    std::vector<PeerRank> pr;             // "peer"
+    HostBarrier* bar = nullptr;
+    std::vector<int64_t> red;             // size x RED_MAX vote slots
+};
+
+namespace {
+
+int peer_exchange(void* user, uint64_t bytes) {
+    tdx_group::PeerRank* me = static_cast<tdx_group::PeerRank*>(user);
+    tdx_group* g = me->g;
+    tdx_context* ctx = g->ctxs[size_t(me->rank)];
+    // every rank has synchronised its stream before calling (host-synchronous contract): after the barrier all send buffers are final
+    g->bar->wait();
+    int fail = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) fail = 1;
+    if (!fail && me->rank > 0 && hipMemcpyAsync(me->c.recv_up, g->pr[size_t(me->rank - 1)].c.send_down, bytes, hipMemcpyDefault, ctx->stream) != hipSuccess) fail = 1;
+    if (!fail && me->rank < g->size - 1 && hipMemcpyAsync(me->c.recv_down, g->pr[size_t(me->rank + 1)].c.send_up, bytes, hipMemcpyDefault, ctx->stream) != hipSuccess) fail = 1;
+    if (!fail && hipStreamSynchronize(ctx->stream) != hipSuccess) fail = 1;
+    g->bar->wait();   // nobody refills a send buffer before its neighbour has copied it
+    return fail;
+}
+int peer_allreduce(void* user, int64_t* values, int32_t count, int32_t op) {
+    tdx_group::PeerRank* me = static_cast<tdx_group::PeerRank*>(user);
+    tdx_group* g = me->g;
+    if (count > RED_MAX) return 1;
+    memcpy(&g->red[size_t(me->rank) * RED_MAX], values, size_t(count) * 8);
+    g->bar->wait();
+    int64_t acc[RED_MAX];
+    for (int i = 0; i < count; i++) {
+        int64_t a = g->red[size_t(i)];
+        for (int r = 1; r < g->size; r++) {
+            const int64_t b = g->red[size_t(r) * RED_MAX + size_t(i)];
+            a = op == TDX_OP_MAX ? (b > a ? b : a) : a + b;
+        }
+        acc[i] = a;
+    }
+    g->bar->wait();   // all ranks have read the slots
+    memcpy(values, acc, size_t(count) * 8);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int tdx_group_create(int32_t size, const int32_t* devices, int64_t nx, tdx_group** out) {
+    if (size < 1 || !devices || nx <= 0 || !out) return tdx_fail(nullptr, TDX_ERR_ARG, "tdx_group_create: bad argument");
+    tdx_group* g = new tdx_group;
+    g->size = size;
+    std::set<int> distinct(devices, devices + size);
+    const char* want = getenv("TAUDEM_AMD_COMM");
+    g->transport = want ? want : (int(distinct.size()) == size ? "rccl" : "peer");
+    if (g->transport != "rccl" && g->transport != "peer") { delete g; return tdx_fail(nullptr, TDX_ERR_ARG, "TAUDEM_AMD_COMM must be rccl or peer"); }
+    if (g->transport == "rccl" && int(distinct.size()) != size) { delete g; return tdx_fail(nullptr, TDX_ERR_ARG, "the RCCL transport needs one distinct GPU per rank"); }
+    int rc = TDX_OK;
+    for (int r = 0; r < size && rc == TDX_OK; r++) {
+        tdx_context* c = nullptr;
+        rc = tdx_context_create(devices[r], &c);
+        if (rc == TDX_OK) g->ctxs.push_back(c);
+    }
+    if (rc == TDX_OK && g->transport == "rccl") {
+        if (!rccl().ok) rc = tdx_fail(nullptr, TDX_ERR_HIP, rccl().err);
+        std::vector<ncclComm_t> comms(size_t(size), nullptr);
+        if (rc == TDX_OK) {
+            const ncclResult_t nr = rccl().CommInitAll(comms.data(), size, devices);
+            if (nr != ncclSuccess) rc = tdx_fail(nullptr, TDX_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(nr));
+        }
+        for (int r = 0; r < size && rc == TDX_OK; r++) {
+            tdx_rccl_comm* w = nullptr;
+            rc = rccl_wrap(g->ctxs[size_t(r)], comms[size_t(r)], r, size, nx, &w);
+            if (rc == TDX_OK) { g->rc.push_back(w); comms[size_t(r)] = nullptr; }
+        }
+        for (ncclComm_t c : comms) if (c) rccl().CommDestroy(c);
+    } else if (rc == TDX_OK) {
+        g->bar = new HostBarrier(size);
+        g->red.assign(size_t(size) * RED_MAX, 0);
+        g->pr.resize(size_t(size));
+        const uint64_t cap = uint64_t(nx) * 16;
+        for (int r = 0; r < size && rc == TDX_OK; r++) {
+            tdx_group::PeerRank& p = g->pr[size_t(r)];
+            p.g = g; p.rank = r; p.bufs = nullptr;
+            if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p.bufs), size_t(cap) * 4) != hipSuccess) {
+                rc = tdx_fail(nullptr, TDX_ERR_NOMEM, "tdx_group_create: cannot allocate the exchange buffers");
+                break;
+            }
+            for (int nb : {r - 1, r + 1})   // strip neighbours on other GPUs: direct xGMI access
+                if (nb >= 0 && nb < size && devices[nb] != devices[r]) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, devices[r], devices[nb]) == hipSuccess && can) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(devices[nb], 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    }
+                }
+            memset(&p.c, 0, sizeof(p.c));
+            p.c.rank = r; p.c.size = size; p.c.user = &p;
+            p.c.exchange = peer_exchange; p.c.allreduce = peer_allreduce;
+            p.c.send_up = p.bufs; p.c.send_down = p.bufs + cap; p.c.recv_up = p.bufs + 2 * cap; p.c.recv_down = p.bufs + 3 * cap;
+            p.c.capacity = cap;
+        }
+    }
+    if (rc != TDX_OK) { const std::string keep = g_tdx_thread_error; tdx_group_destroy(g); g_tdx_thread_error = keep; return rc; }
+    *out = g;
+    return TDX_OK;
+}
+extern "C" tdx_context* tdx_group_context(tdx_group* g, int32_t rank) { return (g && rank >= 0 && rank < g->size) ? g->ctxs[size_t(rank)] : nullptr; }
+extern "C" const tdx_comm* tdx_group_comm(tdx_group* g, int32_t rank) {
+    if (!g || rank < 0 || rank >= g->size) return nullptr;
+    return g->transport == "rccl" ? &g->rc[size_t(rank)]->c : &g->pr[size_t(rank)].c;
+}
+extern "C" const char* tdx_group_transport(const tdx_group* g) { return g ? g->transport.c_str() : ""; }
+extern "C" void tdx_group_destroy(tdx_group* g) {
+    if (!g) return;
+    for (tdx_rccl_comm* r : g->rc) tdx_rccl_comm_destroy(r);
+    for (auto& p : g->pr) if (p.bufs) { (void)hipSetDevice(g->ctxs[size_t(p.rank)]->device); (void)hipFree(p.bufs); }
+    for (tdx_context* c : g->ctxs) tdx_context_destroy(c);
+    delete g->bar;
+    delete g;
+}

@@ -201,9 +201,7 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
         if (rc != TDX_OK) return rc;
         if (!st.multi()) return TDX_OK;
         int64_t changed = 0;
-        rc = strip_exchange<int32_t>(ctx, st, field, -1, sc.flags, geom.tiles_x, &changed);
-        if (rc != TDX_OK) return rc;
-        rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+        rc = strip_exchange<int32_t>(ctx, st, field, -1, sc.flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
         if (rc != TDX_OK) return rc;
         if (changed == 0) return TDX_OK;
     }

@@ -209,9 +209,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
             outer++;
             if (!st.multi()) break;
             int64_t changed = 0;
-            rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA, flags, geom.tiles_x, &changed);
-            if (rc != TDX_OK) return rc;
-            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA, flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
             if (rc != TDX_OK) return rc;
             if (changed == 0) break;
         }

@@ -29,6 +29,12 @@ static inline Strip strip_from_comm(const tdx_comm* comm, int nx, int ny_local) 
 
 namespace stripk {
 template <class T>
+__device__ __forceinline__ bool same_bits(T a, T b) {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b);
+    else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(uint16_t, a) == __builtin_bit_cast(uint16_t, b);
+    else return a == b;
+}
+template <class T>
 __global__ void fill_row_kernel(T* row, T v, int nx) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x < nx) row[x] = v;
@@ -41,7 +47,7 @@ __global__ void merge_row_kernel(T* halo, const T* recv, int nx, unsigned long l
     bool ch = false;
     if (x < nx) {
         const T a = recv[x];
-        if (!(a == halo[x])) {
+        if (!same_bits(a, halo[x])) {   // bit patterns: a NaN boundary cell must not count as "changed" in every round
             halo[x] = a;
             ch = true;
             if (tile_flags) {
@@ -58,6 +64,33 @@ __global__ void merge_row_kernel(T* halo, const T* recv, int nx, unsigned long l
 }
 }  // namespace stripk
 
+// stream-ordered transport (RCCL): exchange() enqueues on the context's stream, no synchronisation around it
+static inline bool strip_ordered(const Strip& st) { return st.comm && (st.comm->flags & TDX_COMM_STREAM_ORDERED) != 0; }
+static inline int strip_pre_exchange_sync(tdx_context* ctx, const Strip& st) {
+    if (!strip_ordered(st)) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TDX_OK;
+}
+
+// Sum / max over the ranks of `count` int64 counters that live in DEVICE memory (d_v, written by work already enqueued on
+// the stream); the result lands in host_out.  With a transport that reduces device values in stream order (RCCL) this is
+// one collective and ONE synchronisation; otherwise device -> host, synchronise, host all-reduce.
+static inline int strip_allreduce_device(tdx_context* ctx, const Strip& st, unsigned long long* d_v, int count, int op, int64_t* host_out) {
+    hipStream_t s = ctx->stream;
+    if (st.multi() && st.comm->allreduce_dev) {
+        if (st.comm->allreduce_dev(st.comm->user, reinterpret_cast<int64_t*>(d_v), count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce_dev failed");
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 48, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+        TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[48 + i]);
+        return TDX_OK;
+    }
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 48, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[48 + i]);
+    if (!st.multi()) return TDX_OK;
+    if (st.comm->allreduce(st.comm->user, host_out, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed");
+    return TDX_OK;
+}
+
 static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v, int count, int op) {
     if (!st.multi()) return TDX_OK;
     if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed");
@@ -66,9 +99,11 @@ static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v,
 
 // Halo rows of `arr` <- the neighbours' boundary rows (or `outside` beyond the raster).  With
 // tile_flags != nullptr only differing cells are written, the tiles that see them are flagged, and
-// *nchanged (host) receives this rank's number of changed halo cells.
+// *nchanged (host) receives this rank's number of changed halo cells - or, with global_vote, the number summed over
+// all ranks (the termination vote of the caller's loop, fused into this exchange: one collective, one synchronisation).
 template <class T>
-static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, uint32_t* tile_flags = nullptr, int tiles_x = 0, int64_t* nchanged = nullptr) {
+static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, uint32_t* tile_flags = nullptr, int tiles_x = 0, int64_t* nchanged = nullptr,
+                          bool global_vote = false) {
     if (nchanged) *nchanged = 0;
     if (st.ny_arr == st.y1 - st.y0) return TDX_OK;   // single-strip array without halo rows
     hipStream_t s = ctx->stream;
@@ -81,7 +116,7 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
     if (bytes > c->capacity) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm buffers smaller than one raster row");
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, arr + size_t(st.y0) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, arr + size_t(st.y1 - 1) * nx, bytes, hipMemcpyDeviceToDevice, s));
-    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
     if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
     if (!tile_flags && !nchanged) {
         if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y0 - 1) * nx, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
@@ -100,6 +135,12 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
         hipLaunchKernelGGL(stripk::merge_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(yh) * nx, static_cast<const T*>(c->recv_down), st.nx, d_n,
                            tile_flags, tiles_x, (yh - 1) / 64, yh / 64);
     }
+    if (global_vote) {
+        int64_t total = 0;
+        if (int rcv = strip_allreduce_device(ctx, st, d_n, 1, TDX_OP_SUM, &total)) return rcv;
+        if (nchanged) *nchanged = total;
+        return TDX_OK;
+    }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 40, d_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     if (nchanged) *nchanged = int64_t(ctx->h_mail[40]);
@@ -117,7 +158,7 @@ static inline int strip_exchange_buffers(tdx_context* ctx, const Strip& st, cons
     if (bytes > c->capacity) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm buffers smaller than one exchange row");
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, up_src, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, down_src, bytes, hipMemcpyDeviceToDevice, s));
-    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
     if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
     if (st.up && up_dst != c->recv_up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(up_dst, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down && down_dst != c->recv_down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(down_dst, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));

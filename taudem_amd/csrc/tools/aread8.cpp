@@ -14,6 +14,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string pfile, afile, wfile, datasrc, lyrname;
     int useOutlets = 0, uselyrname = 0, usew = 0, contcheck = 1, lyrno = 0;
     if (argc < 2) { printf("Error: use either the simple form or the form with explicit file names\n"); usage(argv[0]); }

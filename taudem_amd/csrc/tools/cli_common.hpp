@@ -34,6 +34,19 @@ inline int finish(const char* label, int err) {
     return 0;
 }
 
+// "--gpus N" (anywhere on the command line; not a flag of the reference, whose place for it is `mpiexec -n N`): removed from
+// argv before the reference-style parsing, so that the "simple usage" test argc == 2 still works.
+inline void take_gpus(int& argc, char** argv) {
+    for (int i = 1; i < argc; i++) {
+        if (strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) {
+            tdx_tool_set_gpus(atoi(argv[i + 1]));
+            for (int j = i; j + 2 <= argc; j++) argv[j] = (j + 2 < argc) ? argv[j + 2] : nullptr;
+            argc -= 2;
+            i--;
+        }
+    }
+}
+
 struct Args {
     int argc; char** argv; int i;
     Args(int c, char** v) : argc(c), argv(v), i(c > 2 ? 1 : 2) {}

@@ -13,6 +13,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string demfile, pointfile, slopefile, flowfile;
     int useflowfile = 0;
     if (argc < 2) { printf("Error: use either the simple form or the form with explicit file names\n"); usage(argv[0]); }

@@ -14,6 +14,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string pfile, safile, ssafile, datasrc, lyrname;
     int useOutlets = 0, uselyrname = 0, lyrno = 0, usemax = 1, contcheck = 1;
     if (argc < 2) usage(argv[0]);

@@ -16,6 +16,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string pfile, plenfile, tlenfile, gordfile, maskfile, datasrc, lyrname;
     int useOutlets = 0, uselyrname = 0, lyrno = 0, useMask = 0, thresh = 0;
     if (argc < 2) { printf("Error: To run this program, use either the Simple Usage option or\nthe Usage with Specific file names option\n"); usage(argv[0]); }

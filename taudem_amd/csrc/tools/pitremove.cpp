@@ -15,6 +15,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string demfile, newfile, maskfile;
     bool verbose = false, is_4p = false, use_mask = false;
     if (argc < 2) { printf("Error: use either the simple form or the form with explicit file names\n"); usage(argv[0]); }

@@ -12,6 +12,7 @@ static void usage(const char* prog) {
 }
 
 int main(int argc, char** argv) {
+    cli::take_gpus(argc, argv);
     std::string ssafile, srcfile, maskfile, tval;
     int usemask = 0;
     float thresh = 100.f;

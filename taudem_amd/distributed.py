@@ -124,6 +124,55 @@ class StripComm:
             return 1
 
 
+class RcclStripComm:
+    """tdx_comm backed by the library's NATIVE RCCL transport (taudem_amd/csrc/comm.cpp): boundary rows travel as grouped
+    ncclSend/ncclRecv on the context's stream, termination votes as ncclAllReduce on device values - no Python, no host
+    staging and no extra synchronisation in the exchange path.  torch.distributed is only the bootstrap: rank 0's
+    ncclUniqueId is broadcast through the process group (any backend) once."""
+
+    def __init__(self, ctx, nx: int, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            check(self._lib.tdx_rccl_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(self._lib.tdx_rccl_comm_create(ctx._h, ident, self.rank, self.size, int(nx), C.byref(h)), ctx._h)
+        self._h = h
+        self._comm = C.c_void_p(self._lib.tdx_rccl_comm_handle(h))
+        self.backend = "rccl-native"
+        del torch
+
+    def ptr(self):
+        return self._comm
+
+    def _counters(self):
+        e, a = C.c_int64(), C.c_int64()
+        self._lib.tdx_rccl_comm_counters(self._h, C.byref(e), C.byref(a))
+        return e.value, a.value
+
+    @property
+    def exchanges(self):
+        return self._counters()[0]
+
+    @property
+    def allreduces(self):
+        return self._counters()[1]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tdx_rccl_comm_destroy(self._h)
+            self._h = None
+
+
 def _tptr(t, dtype, shape, name):
     import torch
 

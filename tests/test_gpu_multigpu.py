@@ -1,0 +1,137 @@
+"""Multi-GPU plumbing on the (one-GPU) test box: the native transports of taudem_amd/csrc/comm.cpp, `tool --gpus N` (row strips
+behind the command-line surface, N rank threads; ranks that share a GPU use the peer transport) against the reference's
+rasters, and bench.py's own launch of one process per rank."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import taudem_amd as T
+from conftest import bits_equal, describe_diff, load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "taudem_amd", "bin")
+
+
+def run(tool, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([os.path.join(BIN, tool), *args], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_rccl_transport_selftest(ctx):
+    """ncclCommInitRank + grouped ncclSend/ncclRecv + ncclAllReduce on the context's stream (one rank talking to itself)."""
+    rc = ctx._lib.tdx_rccl_selftest(ctx._h)
+    assert rc == 0, T._lib.last_error(ctx._h)
+
+
+def test_group_peer_transport_protocol():
+    """tdx_group with 3 ranks on one GPU (peer transport): exchange + all-reduce from three threads, checked like the gloo protocol test."""
+    import threading
+
+    lib = T.load()
+    size, nx = 3, 37
+    devs = (C.c_int32 * size)(0, 0, 0)
+    g = C.c_void_p()
+    assert lib.tdx_group_create(size, devs, nx, C.byref(g)) == 0, T._lib.last_error(None)
+    assert lib.tdx_group_transport(g) == b"peer"
+    errors = []
+
+    def rank_main(r):
+        try:
+            comm = C.cast(lib.tdx_group_comm(g, r), C.POINTER(T._lib.TdxComm)).contents
+            ctxh = C.c_void_p(lib.tdx_group_context(g, r))
+            assert comm.rank == r and comm.size == size and comm.capacity >= 16 * nx
+            for it in range(3):
+                n = nx * (it + 1)
+                up = (np.arange(n) + 100 * r + it).astype(np.uint8)
+                dn = (np.arange(n) + 100 * r + 50 + it).astype(np.uint8)
+                fill = np.full(n, 255, np.uint8)
+                for dst, src in ((comm.send_up, up), (comm.send_down, dn), (comm.recv_up, fill), (comm.recv_down, fill)):
+                    assert lib.tdx_copy_to_device(ctxh, dst, src.ctypes.data, n) == 0
+                assert comm.exchange(comm.user, n) == 0
+                got_up, got_dn = np.empty(n, np.uint8), np.empty(n, np.uint8)
+                assert lib.tdx_copy_to_host(ctxh, got_up.ctypes.data, comm.recv_up, n) == 0
+                assert lib.tdx_copy_to_host(ctxh, got_dn.ctypes.data, comm.recv_down, n) == 0
+                if r > 0:
+                    assert np.array_equal(got_up, (np.arange(n) + 100 * (r - 1) + 50 + it).astype(np.uint8)), "recv_up = the upper neighbour's send_down"
+                else:
+                    assert got_up.min() == 255
+                if r < size - 1:
+                    assert np.array_equal(got_dn, (np.arange(n) + 100 * (r + 1) + it).astype(np.uint8)), "recv_down = the lower neighbour's send_up"
+                else:
+                    assert got_dn.min() == 255
+            vals = (C.c_int64 * 3)(r + 1, 10 * (r + 1), -r)
+            assert comm.allreduce(comm.user, vals, 3, 0) == 0
+            assert list(vals) == [6, 60, -3]
+            vals = (C.c_int64 * 2)(r, 7 - r)
+            assert comm.allreduce(comm.user, vals, 2, 1) == 0
+            assert list(vals) == [2, 7]
+        except BaseException as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(size)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    lib.tdx_group_destroy(g)
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("case,ngpus", [("plain", 2), ("holes", 3), ("rect_dxdy", 4)])
+def test_cli_gpus_n_matches_reference_outputs(tmp_path, case, ngpus):
+    """pitremove / d8flowdir / aread8 (+ -wg, -o) / dinfflowdir / areadinf / dinfdecayaccum with --gpus N: pixels identical to the
+    rasters of the real reference tools (which are themselves rank-count independent)."""
+    g = load_golden(case)
+    ny, nx = g["dem"].shape
+    dx, dy = float(g["dx"]), float(g["dy"])
+    gt = (1000.0, dx, 0.0, 5000.0 + dy * ny, 0.0, -dy)
+    f = lambda s: str(tmp_path / s)  # noqa: E731
+    N = ["--gpus", str(ngpus)]
+    T.write_raster(f("dem.tif"), np.ascontiguousarray(g["dem"]), float(g["nodata"]), geotransform=gt)
+    T.write_raster(f("w.tif"), np.ascontiguousarray(g["w"]), -9999.0, geotransform=gt)
+    T.write_raster(f("dm.tif"), np.ascontiguousarray(g["dm"]), -9999.0, geotransform=gt)
+    with open(f("outlets.txt"), "w") as fh:
+        for x_, y_ in zip(*g["outlet_xy"]):
+            fh.write(f"{float(x_)!r} {float(y_)!r}\n")
+    out = run("pitremove", *N, "-z", f("dem.tif"), "-fel", f("fel.tif"), env={"TAUDEM_AMD_STATS": "1"})
+    assert f"Processes: {ngpus}" in out
+    run("d8flowdir", "-fel", f("fel.tif"), "-p", f("p.tif"), "-sd8", f("sd8.tif"), *N)
+    run("aread8", "-p", f("p.tif"), "-ad8", f("ad8.tif"), *N)
+    run("aread8", "-p", f("p.tif"), "-ad8", f("ad8w.tif"), "-wg", f("w.tif"), *N)
+    run("aread8", "-p", f("p.tif"), "-ad8", f("ad8o.tif"), "-o", f("outlets.txt"), env={"TAUDEM_AMD_GPUS": str(ngpus)})
+    run("dinfflowdir", *N, "-fel", f("fel.tif"), "-ang", f("ang.tif"), "-slp", f("slp.tif"))
+    run("areadinf", *N, "-ang", f("ang.tif"), "-sca", f("sca.tif"))
+    run("dinfdecayaccum", *N, "-ang", f("ang.tif"), "-dm", f("dm.tif"), "-dsca", f("dsca.tif"))
+    for name, key, dt in (("fel", "fel", np.float32), ("p", "p", np.int16), ("sd8", "sd8", np.float32), ("ad8", "ad8", np.float32), ("ad8w", "ad8_w", np.float32),
+                          ("ad8o", "ad8_outlets", np.float32), ("ang", "ang", np.float32), ("slp", "slp", np.float32), ("sca", "sca", np.float32),
+                          ("dsca", "dsca", np.float32)):
+        a, _ = T.read_raster(f(name + ".tif"), dt)
+        assert bits_equal(a, g[key]), describe_diff(a, g[key], f"{name} --gpus {ngpus}")
+
+
+def _bench(args, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, no RANK): one process per rank, here two ranks sharing the GPU over gloo."""
+    out = _bench(["--gpus", "2", "--nx", "640", "--ny", "512", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"], {"TDX_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["nx"] == 640 and out["config"]["ny"] == 512
+    assert out["comm"]["exchanges_per_step"]["pitremove"] > 0 and out["value"] > 0
+
+
+def test_bench_strip_path_with_native_rccl_comm():
+    """The strip path of bench.py on one rank with the native RCCL communicator (ncclCommInitRank on this GPU)."""
+    out = _bench(["--nx", "1024", "--ny", "512", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"], {"TDX_BENCH_FORCE_STRIPS": "1"})
+    assert out["comm"]["transport"] == "rccl-native" and out["value"] > 0
