@@ -15,6 +15,8 @@
 #include "flats.hpp"
 #include "strips.hpp"
 
+#include <type_traits>
+
 namespace {
 using namespace tdxk;
 
@@ -62,6 +64,13 @@ __device__ __forceinline__ double prop_dev(float a, int k, double a2) {
     return p;
 }
 
+__device__ __forceinline__ int dinf_sector(float ang, double a2) {   // number of aref[1..8] that are <= ang, at least 1
+    int sector = 0;
+#pragma unroll
+    for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
+    return sector < 1 ? 1 : sector;
+}
+
 // does neighbour k of (x,y) drain into (x,y)?  returns the proportion (>0) or a value <= 0
 __device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny, int x, int y,
                                               int k, float nodata, size_t* nidx, bool* missing) {
@@ -97,7 +106,17 @@ __global__ __launch_bounds__(256) void dinf_setup_kernel(const float* __restrict
         else if (p > 0.0f) { c++; inf |= 1u << (k - 1); }
     }
     if (c == 0) c = CNT_SOURCE;
-    if (is_nodata_f(ANG[idx], nodata) || ANG[idx] == ANG_OUTSIDE) c = CNT_NOT_PART;
+    const float ang = ANG[idx];
+    if (is_nodata_f(ang, nodata) || ang == ANG_OUTSIDE) c = CNT_NOT_PART;
+    else {
+        // where this cell sends flow: prop(ang, k) can be positive only for the two directions that bracket the angle
+        // (src/commonLib.cpp:83-88); kept with the cell so that the sweep needs no proportion to find its targets
+        const double a2 = rows[y].a2;
+        const int s1 = dinf_sector(ang, a2);
+        inf |= unsigned(s1 - 1) << 9;
+        if (prop_dev(ang, s1, a2) > 0.0) inf |= 1u << 12;
+        if (prop_dev(ang, s1 % 8 + 1, a2) > 0.0) inf |= 1u << 13;
+    }
     info[idx] = uint16_t(inf);
     if (cnt) cnt[idx] = c;
     OUT[idx] = (c == CNT_NOT_PART) ? out_nodata : __uint_as_float(DINF_PENDING_BITS);
@@ -116,13 +135,6 @@ __global__ void fill_f32_kernel(float* p, float v, size_t n) {
 // Outlets mode runs the ordinary sweep on re-coded angles: cells outside the closure keep "a valid angle" for the
 // contamination test but neither participate nor contribute (ANG_OUTSIDE, for which prop() is 0 in every direction);
 // an outlet on a cell without angle participates as a pure sink (ANG_SINK) - src/commonLib.cpp:165-233.
-
-__device__ __forceinline__ int dinf_sector(float ang, double a2) {   // number of aref[1..8] that are <= ang, at least 1
-    int sector = 0;
-#pragma unroll
-    for (int j = 1; j <= 8; j++) sector += (double(ang) >= aref_at(j, a2)) ? 1 : 0;
-    return sector < 1 ? 1 : sector;
-}
 
 // mask of the reachability relaxation: the (at most two) neighbours a cell sends flow to
 __global__ __launch_bounds__(256) void dinf_reach_mask_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata, const RowProp* __restrict__ rows,
@@ -359,6 +371,333 @@ __global__ __launch_bounds__(256) void dinf_halo_kernel(Alg alg, const float* __
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(nchanged, (unsigned long long)__popcll(m));
 }
 
+
+// =====================================================================================================================
+// Tile dependency sweep (default path).  The walk above pays two device-scope memory round trips (~2.5 us) per cell of the
+// LONGEST flow path.  A cell's value depends only on its contributors' values (the k-ordered fold of the reference), never
+// on the schedule, so the same bits come out of any evaluation order that respects the dependencies.  Here:
+//   * a 256-thread workgroup stages a 64 x 64 tile + one ring of result, angle (decay multiplier, weight) and the per-cell
+//     inflow / target bits in LDS; a cell is READY when none of its contributors still shows the "pending" pattern - counted
+//     from the staged values, no global counters at all;
+//   * lanes walk downstream from the ready cells inside LDS (evaluate by pulling contributors in k order, publish in LDS,
+//     decrement the packed byte counters of the <= 2 targets with one returning LDS atomic each, continue into a target
+//     that became ready; a second ready target goes to a small LDS queue that the workgroup drains in phases) - a hop costs
+//     LDS latency plus the fp64 proportions, not HBM round trips;
+//   * evaluated cells are written back; a tile whose finished cells drain into a neighbouring tile raises that tile's
+//     activation flag for the next ROUND (the schedule of tile_relax.hpp: lists, flags, device-chained launches), which
+//     re-counts its perimeter from the new ring values.  Rounds = tile crossings of the longest dependency chain.
+// Cells that can never be evaluated (cycles, downstream of cycles) stay pending and become nodata in dinf_finish_kernel,
+// like the reference's never-queued cells.
+// =====================================================================================================================
+namespace dsweep {
+constexpr int TS = tilek::TS, LH = TS + 2;
+constexpr int QCAP = 512;
+
+// Per cell, once (streaming, all rows of the array): everything the sweep needs to evaluate the cell and to find its targets
+// without a proportion of its own -
+//   info  [0:8) neighbour k drains into the cell (the test of initNeighborDinfup, src/commonLib.cpp:99-131: `float p > 0`)
+//         [8]   a neighbour is missing (outside the raster or nodata: the contamination test of src/areadinf.cpp:196-199)
+//         [9:12) s1 - 1, [12] / [13] the cell sends flow to neighbour s1 / s1 % 8 + 1 (prop() can be positive only for the two
+//                directions that bracket the angle, src/commonLib.cpp:83-88)
+//         [16:24) contributor k reaches this cell through ITS second target (selects which of its two proportions applies)
+//   P     the two proportions of the cell's own outflow as doubles (the fp64 divisions of prop() leave the serial path)
+// and the result array starts as "pending" on participating owned cells.
+__global__ __launch_bounds__(256) void setup_kernel(const float* __restrict__ ANG, int nx, int ny, int y_own0, int y_own1, float nodata,
+                                                    const RowProp* __restrict__ rows, uint32_t* __restrict__ info, double2* __restrict__ P,
+                                                    float* __restrict__ OUT, float out_nodata) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    unsigned inf = 0;
+    for (int k = 1; k <= 8; k++) {
+        const int xn = x + d1(k), yn = y + d2(k);
+        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { inf |= 0x100u; continue; }
+        const float an = ANG[size_t(yn) * size_t(nx) + size_t(xn)];
+        if (is_nodata_f(an, nodata)) { inf |= 0x100u; continue; }
+        const double a2n = rows[yn].a2;
+        const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
+        if ((float)prop_dev(an, kk, a2n) > 0.0f) {
+            inf |= 1u << (k - 1);
+            const int s1n = dinf_sector(an, a2n);
+            if ((kk == 0 ? 8 : kk) != s1n) inf |= 1u << (16 + k - 1);   // not its first target: its second
+        }
+    }
+    const float ang = ANG[idx];
+    double2 pp = make_double2(0., 0.);
+    const bool part = !(is_nodata_f(ang, nodata) || ang == ANG_OUTSIDE);
+    if (part) {
+        const double a2 = rows[y].a2;
+        const int s1 = dinf_sector(ang, a2);
+        inf |= unsigned(s1 - 1) << 9;
+        const double p1 = prop_dev(ang, s1, a2), p2 = prop_dev(ang, s1 % 8 + 1, a2);
+        if (p1 > 0.0) { inf |= 1u << 12; pp.x = p1; }
+        if (p2 > 0.0) { inf |= 1u << 13; pp.y = p2; }
+    }
+    info[idx] = inf;
+    P[idx] = pp;
+    if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
+}
+
+template <bool HAS_W, bool HAS_DM>
+struct Lds {
+    double2 p[LH * LH];            // outflow proportions of tile + ring
+    float out[LH * LH];
+    float dm[HAS_DM ? LH * LH : 1];
+    float w[HAS_W ? TS * TS : 1];
+    uint32_t info[TS * TS];
+    uint32_t cnt[TS * TS / 4];     // one byte per cell: contributors still pending (255: not a pending cell of this rank)
+    double dx[TS];                 // cell size of the tile's rows (the unweighted increment)
+    uint16_t q[2][QCAP];           // ready cells handed on to the next phase
+    unsigned nq[2];
+    int rim;                       // RES_* rim bits: neighbouring tiles that receive flow from cells finished in this activation
+    int over;                      // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
+};
+
+__device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == DINF_PENDING_BITS; }
+
+struct AreaEval {   // src/areadinf.cpp:187-217
+    template <class L>
+    __device__ __forceinline__ float eval(const L& S, int c, int cl, int ly, unsigned inf, int contcheck, bool has_w) const {
+        float areares = 0.f;
+        bool con = (inf & 0x100u) != 0u;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const int n = cl + d2(k) * LH + d1(k);
+            const double2 pp = S.p[n];
+            const double p = ((inf >> (16 + k - 1)) & 1u) ? pp.y : pp.x;
+            const float v = S.out[n];
+            if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
+            else areares = (float)(areares + p * v);
+        }
+        if (has_w) areares = areares + S.w[c];
+        else areares = (float)(areares + S.dx[ly]);
+        return (con && contcheck == 1) ? TDX_AREA_NODATA : areares;
+    }
+};
+struct DecayEval {   // src/dinfdecayaccum.cpp:213-245
+    float dm_nodata;
+    template <class L>
+    __device__ __forceinline__ float eval(const L& S, int c, int cl, int ly, unsigned inf, int contcheck, bool has_w) const {
+        float acc = has_w ? S.w[c] : (float)S.dx[ly];
+        bool con = (inf & 0x100u) != 0u;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            if (!((inf >> (k - 1)) & 1u)) continue;
+            const int n = cl + d2(k) * LH + d1(k);
+            const double2 pp = S.p[n];
+            const double p = ((inf >> (16 + k - 1)) & 1u) ? pp.y : pp.x;
+            const float area = S.out[n], dm = S.dm[n];
+            if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
+            else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
+        }
+        return (con && contcheck == 1) ? TDX_ANG_NODATA : acc;
+    }
+};
+
+constexpr int NT = 1024;            // threads per tile: lane (lx, wv) owns column lx, rows 4 wv .. 4 wv + 3
+constexpr int RPL = TS * TS / NT;   // cells per lane
+constexpr int NSTAGE = (LH * LH + NT - 1) / NT;
+constexpr int BULK_SWEEPS = 12;
+
+// targets of a finished cell that lie outside the tile: those tiles have to look again
+__device__ __forceinline__ int rim_bits(unsigned inf, int cx, int ly) {
+    int bits = 0;
+    const int s1 = int((inf >> 9) & 7u) + 1;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!((inf >> (12 + t)) & 1u)) continue;
+        const int k = t == 0 ? s1 : (s1 % 8 + 1);
+        const int nx2 = cx + d1(k), ny2 = ly + d2(k);
+        if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS)
+            bits |= ny2 < 0 ? (nx2 < 0 ? 16 : (nx2 >= TS ? 32 : 1)) : (ny2 >= TS ? (nx2 < 0 ? 64 : (nx2 >= TS ? 128 : 2)) : (nx2 < 0 ? 4 : 8));
+    }
+    return bits;
+}
+
+template <class Eval, bool HAS_W, bool HAS_DM>
+__device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom& g, int tile, bool full, Lds<HAS_W, HAS_DM>& S, const double2* __restrict__ P,
+                                          const float* __restrict__ W, const float* __restrict__ DM, const uint32_t* __restrict__ INFO,
+                                          const RowProp* __restrict__ rows, float* __restrict__ OUT, float out_nodata, int contcheck) {
+    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
+    // ---- stage: every load of a lane is issued before the first LDS store (ONE memory latency per activation); addresses
+    // are clamped into the raster and validity is applied afterwards (a load inside a divergent branch is waited for at once)
+    {
+        float so[NSTAGE], sd[HAS_DM ? NSTAGE : 1];
+        double2 sp[NSTAGE];
+        uint32_t si[RPL];
+        float sw[HAS_W ? RPL : 1];
+        unsigned ok = 0;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT, ec = e < LH * LH ? e : LH * LH - 1;
+            const int wy = ec / LH, wx = ec - wy * LH;
+            const int gx = x0 - 1 + wx, gy = y0 - 1 + wy;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) ok |= 1u << i;
+            const int gxc = gx < 0 ? 0 : (gx >= g.nx ? g.nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy);
+            const size_t idx = size_t(gyc) * size_t(g.nx) + size_t(gxc);
+            so[i] = OUT[idx];
+            sp[i] = P[idx];
+            if (HAS_DM) sd[i] = DM[idx];
+        }
+        unsigned oki = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            const int gx = x0 + lx, gy = y0 + ry0 + r;
+            if (gx < g.nx && gy < g.ny) oki |= 1u << r;
+            const size_t idx = size_t(gy >= g.ny ? g.ny - 1 : gy) * size_t(g.nx) + size_t(gx >= g.nx ? g.nx - 1 : gx);
+            si[r] = INFO[idx];
+            if (HAS_W) sw[r] = W[idx];
+        }
+        double dxrow = 0.;
+        if (tid < TS) dxrow = rows[y0 + tid >= g.ny ? g.ny - 1 : y0 + tid].dx;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT;
+            if (e < LH * LH) {
+                const bool in = (ok >> i) & 1u;
+                S.out[e] = in ? so[i] : out_nodata;
+                S.p[e] = in ? sp[i] : make_double2(0., 0.);
+                if (HAS_DM) S.dm[e] = in ? sd[i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            S.info[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? si[r] : 0u;
+            if (HAS_W) S.w[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? sw[r] : 0.f;
+        }
+        if (tid < TS) S.dx[tid] = dxrow;
+    }
+    __syncthreads();
+    unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet)
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int gx = x0 + lx, gy = y0 + ry0 + r;
+        if (gx < g.nx && gy >= g.y_own0 && gy < g.y_own1 && pending(S.out[(ry0 + r + 1) * LH + lx + 1])) pendmask |= 1u << r;
+    }
+    const unsigned pend0 = pendmask;
+    int rim = 0;
+    // ---- bulk: a fresh tile holds thousands of ready cells and short chains - evaluated in lockstep (every lane looks at its
+    // own pending cells: ready = no contributor pending), one dependency level or more per sweep, no atomics.  What is left
+    // after a few sweeps are the stream cells: long, thin chains for the walks below.
+    if (full) {
+        for (int sweep = 0; sweep < BULK_SWEEPS; sweep++) {
+            bool prog = false;
+#pragma unroll
+            for (int rr = 0; rr < RPL; rr++) {
+                const int r = (sweep & 1) ? RPL - 1 - rr : rr;
+                if (!((pendmask >> r) & 1u)) continue;
+                const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
+                const unsigned inf = S.info[c];
+                bool ready = true;
+#pragma unroll
+                for (int k = 1; k <= 8; k++)
+                    if (((inf >> (k - 1)) & 1u) && pending(S.out[cl + d2(k) * LH + d1(k)])) ready = false;
+                if (ready) {
+                    S.out[cl] = ev.eval(S, c, cl, ly, inf, contcheck, HAS_W);
+                    rim |= rim_bits(inf, lx, ly);
+                    pendmask &= ~(1u << r);
+                    prog = true;
+                }
+            }
+            if (!__syncthreads_or(prog ? 1 : 0)) break;
+        }
+    }
+    // ---- pending contributors of the cells that are left
+    unsigned readymask = 0;
+    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(S.cnt);
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
+        unsigned cn = 255u;
+        if ((pendmask >> r) & 1u) {
+            const unsigned inf = S.info[c];
+            cn = 0u;
+#pragma unroll
+            for (int k = 1; k <= 8; k++)
+                if (((inf >> (k - 1)) & 1u) && pending(S.out[cl + d2(k) * LH + d1(k)])) cn++;
+            if (cn == 0u) readymask |= 1u << r;
+        }
+        cnt8[c] = uint8_t(cn);
+    }
+    __syncthreads();
+    // ---- walks: a lane follows a chain downstream as long as it finishes the last pending contributor of a target
+    auto walk = [&](int c, int phase) {
+        unsigned inf = S.info[c];
+        for (;;) {
+            const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
+            S.out[cl] = ev.eval(S, c, cl, ly, inf, contcheck, HAS_W);
+            // the (at most two) targets: both decrements and the candidates' info words are in flight together
+            const int s1 = int((inf >> 9) & 7u) + 1;
+            int tc[2] = {-1, -1};
+            unsigned old[2] = {0u, 0u}, tinf[2] = {0u, 0u};
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (!((inf >> (12 + t)) & 1u)) continue;
+                const int k = t == 0 ? s1 : (s1 % 8 + 1);
+                const int nx2 = cx + d1(k), ny2 = ly + d2(k);
+                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) continue;
+                tc[t] = ny2 * TS + nx2;
+                old[t] = __hip_atomic_fetch_sub(&S.cnt[tc[t] >> 2], 1u << (8 * (tc[t] & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tinf[t] = S.info[tc[t]];
+            }
+            rim |= rim_bits(inf, cx, ly);
+            int next = -1;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (tc[t] < 0 || ((old[t] >> (8 * (tc[t] & 3))) & 255u) != 1u) continue;   // not its last pending contributor
+                if (next < 0) { next = tc[t]; inf = tinf[t]; }
+                else {
+                    const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
+                    if (slot < unsigned(QCAP)) S.q[phase ^ 1][slot] = uint16_t(tc[t]);
+                    else S.over = 1;
+                }
+            }
+            if (next < 0) break;
+            c = next;
+        }
+    };
+    for (unsigned m = readymask; m; m &= m - 1u) walk((ry0 + (__ffs(int(m)) - 1)) * TS + lx, 0);
+    for (int phase = 1;; phase ^= 1) {          // drain the hand-over queue: the walks of a phase fill the other buffer
+        __syncthreads();                        // every push into q[phase] has landed
+        const unsigned n = S.nq[phase] < unsigned(QCAP) ? S.nq[phase] : unsigned(QCAP);
+        if (n == 0u) break;
+        for (unsigned i = tid; i < n; i += unsigned(NT)) walk(int(S.q[phase][i]), phase);
+        __syncthreads();                        // q[phase] has been read by everybody
+        if (tid == 0) S.nq[phase] = 0u;         // (nobody pushes into it before the next barrier)
+    }
+    // ---- write back what this activation evaluated
+    bool wrote = false;
+    for (unsigned m = pend0; m; m &= m - 1u) {
+        const int r = __ffs(int(m)) - 1, ly = ry0 + r;
+        const float v = S.out[(ly + 1) * LH + lx + 1];
+        if (!pending(v)) { OUT[size_t(y0 + ly) * size_t(g.nx) + size_t(x0 + lx)] = v; wrote = true; }
+    }
+    if (rim) atomicOr(&S.rim, rim);
+    const int any = __syncthreads_or(wrote ? 1 : 0);
+    const int res = (any ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
+    __syncthreads();   // S is reused by the next tile
+    return res;
+}
+
+template <class Eval, bool HAS_W, bool HAS_DM>
+__global__ __launch_bounds__(NT) void sweep_kernel(Eval ev, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+                                                   uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
+                                                   unsigned pull_max, const double2* __restrict__ P, const float* __restrict__ W, const float* __restrict__ DM,
+                                                   const uint32_t* __restrict__ INFO, const RowProp* __restrict__ rows, float* __restrict__ OUT,
+                                                   float out_nodata, int contcheck) {
+    __shared__ Lds<HAS_W, HAS_DM> S;
+    __shared__ tilek::TileLds L;
+    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
+        return sweep_tile<Eval, HAS_W, HAS_DM>(ev, g, tile, full, S, P, W, DM, INFO, rows, OUT, out_nodata, contcheck);
+    });
+}
+}  // namespace dsweep
+
 template <class Alg>
 int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, float ang_nodata, const double* dxc, const double* dyc, int contcheck,
                    const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_out, float out_nodata, float* d_dm, float dm_nodata,
@@ -372,8 +711,9 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     rows.resize(size_t(iny));
     for (int j = 0; j < iny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
     RowProp* d_rows = static_cast<RowProp*>(ctx->scratch(TDX_S_J, rows.size() * sizeof(RowProp)));
-    int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-    uint16_t* info = static_cast<uint16_t*>(ctx->scratch(TDX_S_I, n * 2));
+    const bool use_walk = getenv("TDX_DINF_WALK") != nullptr;   // A/B hook: the atomic pull walk instead of the tile dependency sweep
+    int32_t* cnt = use_walk ? static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4)) : reinterpret_cast<int32_t*>(ctx->d_mail);
+    uint16_t* info = use_walk ? static_cast<uint16_t*>(ctx->scratch(TDX_S_I, n * 2)) : reinterpret_cast<uint16_t*>(ctx->d_mail);
     const unsigned long long ovf_cap = n / 4 + 1024;
     uint32_t* ovfa = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ovf_cap) * 4));
     uint32_t* ovfb = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ovf_cap) * 4));
@@ -419,17 +759,83 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         if (stats) stats->launches[TDX_K_BFS] += ll;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     }
+    uint32_t* info32 = nullptr;
+    double2* d_P = nullptr;
+    if (!use_walk) {
+        info32 = static_cast<uint32_t*>(ctx->scratch(TDX_S_I, n * 4));
+        d_P = static_cast<double2*>(ctx->scratch(TDX_S_A, n * 16));
+        if (!info32 || !d_P) return TDX_ERR_NOMEM;
+    }
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
+        if (use_walk)
+            hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
+        else
+            hipLaunchKernelGGL(dsweep::setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info32,
+                               d_P, d_out, out_nodata);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
-    // halo rows of the result and of the counters start as "not evaluated"
+    // halo rows of the result (and of the walk's counters) start as "not evaluated"
     rc = strip_exchange<float>(ctx, st, d_out, out_nodata);
     if (rc != TDX_OK) return rc;
+    int64_t rounds = 0, outer = 0;
+    if (!use_walk) {
+        TdxSpan sp(ctx, TDX_K_ACCUM);
+        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+        unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+        if (!flags || !counts) return TDX_ERR_NOMEM;
+        const tilek::Sched sched{flags, flags + ntiles, counts};
+        const float* d_w = alg.W;
+        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
+        int64_t launches = 0;
+        for (;;) {
+            RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, geom, sched, ctx->h_mail, nullptr);
+            run.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
+                                    unsigned pull_max) {
+                if constexpr (std::is_same<Alg, AreaAlg>::value) {
+                    if (d_w)
+                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, true, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
+                                           fcur, fnext, lnext, pull_max, d_P, d_w, nullptr, info32, d_rows, d_out, out_nodata, contcheck);
+                    else
+                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, false, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
+                                           fcur, fnext, lnext, pull_max, d_P, nullptr, nullptr, info32, d_rows, d_out, out_nodata, contcheck);
+                } else {
+                    if (d_w)
+                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, true, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
+                                           list, count, fcur, fnext, lnext, pull_max, d_P, d_w, alg.DM, info32, d_rows, d_out, out_nodata, contcheck);
+                    else
+                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, false, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
+                                           list, count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck);
+                }
+            };
+            static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
+            run.print_counts = dbg_rounds;
+            if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%zu tiles):", ntiles);
+            rc = run.start();
+            if (rc != TDX_OK) return rc;
+            while (!run.done) {
+                rc = run.enqueue();
+                if (rc != TDX_OK) return rc;
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                run.collect();
+            }
+            rounds += run.rounds;
+            launches += run.launches;
+            if (!st.multi()) break;
+            // the neighbours' boundary rows: cells finished there release the owned cells they drain into (addBorders() + queue
+            // refill of src/areadinf.cpp:241-262); tiles that see a changed halo cell run again
+            int64_t changed = 0;
+            rc = strip_exchange<float>(ctx, st, d_out, out_nodata, flags, geom.tiles_x, &changed, true);
+            if (rc != TDX_OK) return rc;
+            if (changed == 0) break;
+            outer++;
+        }
+        if (stats) stats->launches[TDX_K_ACCUM] += launches;
+    } else {
     rc = strip_exchange<int32_t>(ctx, st, cnt, CNT_NOT_PART);
     if (rc != TDX_OK) return rc;
-    int64_t rounds = 0, outer = 0;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
         uint32_t *lst = ovfa, *nxt = ovfb;
@@ -479,6 +885,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             rounds++;
         }
         if (stats) stats->launches[TDX_K_ACCUM] += rounds;
+    }
     }
     {
         const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);

@@ -24,6 +24,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <type_traits>
 
 #include "context.hpp"
@@ -651,14 +652,13 @@ __device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeo
 // activation flags in this round's flag half and activate tiles for the next round in the other half / the other list
 // (count[1] = the next round's size).  Flags raised in round r are only read in round r + 1, so everything a tile loads
 // was written before its launch started.
-template <class Op, bool REG>
-__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
-                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
-                                                    uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg) {
-    using T = typename Op::T;
-    static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
-    __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
-    __shared__ TileLds L;
+// The work distribution of one round, shared by every tile kernel that uses this schedule (the relaxation below, the
+// dependency sweeps of tile_dep.hpp): body(tile, full) processes one tile with the whole workgroup and returns its RES_* mask
+// (uniform); all threads must call it, and it must end with a barrier.
+template <class Body>
+__device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_cur,
+                                             uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next, unsigned pull_max, const TileGeom& g,
+                                             TileLds& L, Body body) {
     const unsigned nact = unsigned(count[0]);
     const uint32_t entry0 = list[blockIdx.x];          // for a small round (below); fetched together with the count: gridDim.x <= number of tiles
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
@@ -681,18 +681,31 @@ __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const
         __syncthreads();
         const unsigned first = L.next;
         const unsigned long long base = L.base;
-        for (unsigned i = threadIdx.x; i < npend; i += unsigned(NTHR)) list_next[base + i] = L.pend[i];
+        for (unsigned i = threadIdx.x; i < npend; i += blockDim.x) list_next[base + i] = L.pend[i];
         if (threadIdx.x == 0) L.npend = 0u;   // the next push comes after the first barrier of the next tile
         if (first >= nact) break;
         const unsigned last = first + pull < nact ? first + pull : nact;
         for (unsigned it = first; it < last; it++) {
             const int tile = fixed ? int(entry0) : int(list[it]);
             const bool full = flags_cur[tile] >= FLAG_FULL;
-            const int res = REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);   // (ends with a barrier: every lane has read the flag)
+            const int res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
             if (threadIdx.x == 0) flags_cur[tile] = 0u;
             if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, L);
         }
     }
+}
+
+template <class Op, bool REG>
+__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
+                                                    uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg) {
+    using T = typename Op::T;
+    static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
+    __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
+    __shared__ TileLds L;
+    round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
+        return REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);
+    });
 }
 
 // ---- schedule 2: asynchronous worklist.  ONE launch: resident workgroups pop tiles from a device queue, relax
@@ -913,6 +926,9 @@ struct RoundRunner {
     bool done = false;
     int64_t rounds = 0, launches = 0;
     unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
+    // another tile kernel on the same schedule (tile_dep.hpp): launches one round; empty = the relaxation kernel of `op`
+    std::function<void(unsigned grid, hipStream_t st, const uint32_t* list, unsigned long long* count, uint32_t* flags_cur, uint32_t* flags_next,
+                       uint32_t* list_next, unsigned pull_max)> custom_launch;
     RoundRunner(tdx_context* c, hipStream_t st, Op o, tilek::TileGeom geom, tilek::Sched sched, uint64_t* host_mail, unsigned long long* d)
         : ctx(c), s(st), op(o), g(geom), sc(sched), h(host_mail), dbg(d) {
         ntiles = g.tiles_x * g.tiles_y;
@@ -948,7 +964,9 @@ struct RoundRunner {
         for (int b = 0; b < batch; b++) {
             const int p = (parity + b) & 1;
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
-            if (lds_variant)
+            if (custom_launch)
+                custom_launch(grid, s, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1), list_of(p ^ 1), pull_max);
+            else if (lds_variant)
                 hipLaunchKernelGGL((relax_kernel<Op, false>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
                                    list_of(p ^ 1), pull_max, dbg);
             else
