@@ -456,39 +456,54 @@ struct Lds {
 
 __device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == DINF_PENDING_BITS; }
 
+// The neighbourhood of a cell as registers: all 8 result values and proportion pairs are requested unconditionally and
+// together (ONE LDS latency); a read inside a data-dependent branch gets its own basic block and its own wait - eight of
+// them per cell were most of a hop's time.
+struct Nbr8 { float v[9]; double2 p[9]; float dm[9]; };
+template <class L, bool HAS_DM>
+__device__ __forceinline__ void load_nbrs(const L& S, int cl, Nbr8& nb) {
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        const int n = cl + d2(k) * LH + d1(k);
+        nb.v[k] = S.out[n];
+        nb.p[k] = S.p[n];
+        if (HAS_DM) nb.dm[k] = S.dm[n];
+    }
+}
+__device__ __forceinline__ unsigned pending_bits(const Nbr8& nb) {
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 1; k <= 8; k++) b |= pending(nb.v[k]) ? 1u << (k - 1) : 0u;
+    return b;
+}
+
 struct AreaEval {   // src/areadinf.cpp:187-217
-    template <class L>
-    __device__ __forceinline__ float eval(const L& S, int c, int cl, int ly, unsigned inf, int contcheck, bool has_w) const {
+    __device__ __forceinline__ float eval(const Nbr8& nb, float w, double dx, unsigned inf, int contcheck, bool has_w) const {
         float areares = 0.f;
         bool con = (inf & 0x100u) != 0u;
 #pragma unroll
         for (int k = 1; k <= 8; k++) {
             if (!((inf >> (k - 1)) & 1u)) continue;
-            const int n = cl + d2(k) * LH + d1(k);
-            const double2 pp = S.p[n];
-            const double p = ((inf >> (16 + k - 1)) & 1u) ? pp.y : pp.x;
-            const float v = S.out[n];
+            const double p = ((inf >> (16 + k - 1)) & 1u) ? nb.p[k].y : nb.p[k].x;
+            const float v = nb.v[k];
             if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
             else areares = (float)(areares + p * v);
         }
-        if (has_w) areares = areares + S.w[c];
-        else areares = (float)(areares + S.dx[ly]);
+        if (has_w) areares = areares + w;
+        else areares = (float)(areares + dx);
         return (con && contcheck == 1) ? TDX_AREA_NODATA : areares;
     }
 };
 struct DecayEval {   // src/dinfdecayaccum.cpp:213-245
     float dm_nodata;
-    template <class L>
-    __device__ __forceinline__ float eval(const L& S, int c, int cl, int ly, unsigned inf, int contcheck, bool has_w) const {
-        float acc = has_w ? S.w[c] : (float)S.dx[ly];
+    __device__ __forceinline__ float eval(const Nbr8& nb, float w, double dx, unsigned inf, int contcheck, bool has_w) const {
+        float acc = has_w ? w : (float)dx;
         bool con = (inf & 0x100u) != 0u;
 #pragma unroll
         for (int k = 1; k <= 8; k++) {
             if (!((inf >> (k - 1)) & 1u)) continue;
-            const int n = cl + d2(k) * LH + d1(k);
-            const double2 pp = S.p[n];
-            const double p = ((inf >> (16 + k - 1)) & 1u) ? pp.y : pp.x;
-            const float area = S.out[n], dm = S.dm[n];
+            const double p = ((inf >> (16 + k - 1)) & 1u) ? nb.p[k].y : nb.p[k].x;
+            const float area = nb.v[k], dm = nb.dm[k];
             if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
             else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
         }
@@ -519,10 +534,13 @@ __device__ __forceinline__ int rim_bits(unsigned inf, int cx, int ly) {
 template <class Eval, bool HAS_W, bool HAS_DM>
 __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom& g, int tile, bool full, Lds<HAS_W, HAS_DM>& S, const double2* __restrict__ P,
                                           const float* __restrict__ W, const float* __restrict__ DM, const uint32_t* __restrict__ INFO,
-                                          const RowProp* __restrict__ rows, float* __restrict__ OUT, float out_nodata, int contcheck) {
+                                          const RowProp* __restrict__ rows, float* __restrict__ OUT, float out_nodata, int contcheck,
+                                          unsigned long long* __restrict__ dbg) {
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
+    const unsigned long long tc0 = dbg ? wall_clock64() : 0ull;
+    unsigned long long hops = 0, nphase = 0;
     if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
     // ---- stage: every load of a lane is issued before the first LDS store (ONE memory latency per activation); addresses
     // are clamped into the raster and validity is applied afterwards (a load inside a divergent branch is waited for at once)
@@ -573,6 +591,7 @@ __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom&
         if (tid < TS) S.dx[tid] = dxrow;
     }
     __syncthreads();
+    const unsigned long long tc1 = dbg ? wall_clock64() : 0ull;
     unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet)
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
@@ -593,12 +612,12 @@ __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom&
                 if (!((pendmask >> r) & 1u)) continue;
                 const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
                 const unsigned inf = S.info[c];
-                bool ready = true;
-#pragma unroll
-                for (int k = 1; k <= 8; k++)
-                    if (((inf >> (k - 1)) & 1u) && pending(S.out[cl + d2(k) * LH + d1(k)])) ready = false;
-                if (ready) {
-                    S.out[cl] = ev.eval(S, c, cl, ly, inf, contcheck, HAS_W);
+                Nbr8 nb;
+                load_nbrs<Lds<HAS_W, HAS_DM>, HAS_DM>(S, cl, nb);
+                const float wv = HAS_W ? S.w[c] : 0.f;
+                const double dxv = S.dx[ly];
+                if ((inf & 0xFFu & pending_bits(nb)) == 0u) {
+                    S.out[cl] = ev.eval(nb, wv, dxv, inf, contcheck, HAS_W);
                     rim |= rim_bits(inf, lx, ly);
                     pendmask &= ~(1u << r);
                     prog = true;
@@ -614,23 +633,32 @@ __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom&
     for (int r = 0; r < RPL; r++) {
         const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
         unsigned cn = 255u;
-        if ((pendmask >> r) & 1u) {
-            const unsigned inf = S.info[c];
-            cn = 0u;
+        const unsigned inf = S.info[c];
+        float nv[9];
 #pragma unroll
-            for (int k = 1; k <= 8; k++)
-                if (((inf >> (k - 1)) & 1u) && pending(S.out[cl + d2(k) * LH + d1(k)])) cn++;
+        for (int k = 1; k <= 8; k++) nv[k] = S.out[cl + d2(k) * LH + d1(k)];
+        if ((pendmask >> r) & 1u) {
+            unsigned pb = 0;
+#pragma unroll
+            for (int k = 1; k <= 8; k++) pb |= pending(nv[k]) ? 1u << (k - 1) : 0u;
+            cn = unsigned(__popc(inf & 0xFFu & pb));
             if (cn == 0u) readymask |= 1u << r;
         }
         cnt8[c] = uint8_t(cn);
     }
     __syncthreads();
+    const unsigned long long tc2 = dbg ? wall_clock64() : 0ull;
     // ---- walks: a lane follows a chain downstream as long as it finishes the last pending contributor of a target
     auto walk = [&](int c, int phase) {
         unsigned inf = S.info[c];
         for (;;) {
             const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
-            S.out[cl] = ev.eval(S, c, cl, ly, inf, contcheck, HAS_W);
+            Nbr8 nb;
+            load_nbrs<Lds<HAS_W, HAS_DM>, HAS_DM>(S, cl, nb);
+            const float wv = HAS_W ? S.w[c] : 0.f;
+            const double dxv = S.dx[ly];
+            S.out[cl] = ev.eval(nb, wv, dxv, inf, contcheck, HAS_W);
+            hops++;
             // the (at most two) targets: both decrements and the candidates' info words are in flight together
             const int s1 = int((inf >> 9) & 7u) + 1;
             int tc[2] = {-1, -1};
@@ -666,10 +694,12 @@ __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom&
         __syncthreads();                        // every push into q[phase] has landed
         const unsigned n = S.nq[phase] < unsigned(QCAP) ? S.nq[phase] : unsigned(QCAP);
         if (n == 0u) break;
+        nphase++;
         for (unsigned i = tid; i < n; i += unsigned(NT)) walk(int(S.q[phase][i]), phase);
         __syncthreads();                        // q[phase] has been read by everybody
         if (tid == 0) S.nq[phase] = 0u;         // (nobody pushes into it before the next barrier)
     }
+    const unsigned long long tc3 = dbg ? wall_clock64() : 0ull;
     // ---- write back what this activation evaluated
     bool wrote = false;
     for (unsigned m = pend0; m; m &= m - 1u) {
@@ -680,6 +710,16 @@ __device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom&
     if (rim) atomicOr(&S.rim, rim);
     const int any = __syncthreads_or(wrote ? 1 : 0);
     const int res = (any ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
+    if (dbg) {   // TDX_DEBUG_ROUNDS=1: 100 MHz ticks per phase, hops (total and of the busiest lane), hand-over phases
+        atomicAdd(dbg + 4, hops);
+        atomicMax(&S.nq[0], unsigned(hops));   // (the queue counters are idle here)
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long tc4 = wall_clock64();
+            atomicAdd(dbg + 0, tc1 - tc0); atomicAdd(dbg + 1, tc2 - tc1); atomicAdd(dbg + 2, tc3 - tc2); atomicAdd(dbg + 3, tc4 - tc3);
+            atomicAdd(dbg + 5, (unsigned long long)S.nq[0]); atomicAdd(dbg + 6, nphase); atomicAdd(dbg + 7, 1ull);
+        }
+    }
     __syncthreads();   // S is reused by the next tile
     return res;
 }
@@ -689,14 +729,15 @@ __global__ __launch_bounds__(NT) void sweep_kernel(Eval ev, tilek::TileGeom g, c
                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
                                                    unsigned pull_max, const double2* __restrict__ P, const float* __restrict__ W, const float* __restrict__ DM,
                                                    const uint32_t* __restrict__ INFO, const RowProp* __restrict__ rows, float* __restrict__ OUT,
-                                                   float out_nodata, int contcheck) {
+                                                   float out_nodata, int contcheck, unsigned long long* __restrict__ dbg) {
     __shared__ Lds<HAS_W, HAS_DM> S;
     __shared__ tilek::TileLds L;
     tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
-        return sweep_tile<Eval, HAS_W, HAS_DM>(ev, g, tile, full, S, P, W, DM, INFO, rows, OUT, out_nodata, contcheck);
+        return sweep_tile<Eval, HAS_W, HAS_DM>(ev, g, tile, full, S, P, W, DM, INFO, rows, OUT, out_nodata, contcheck, dbg);
     });
 }
 }  // namespace dsweep
+
 
 template <class Alg>
 int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, float ang_nodata, const double* dxc, const double* dyc, int contcheck,
@@ -711,7 +752,9 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     rows.resize(size_t(iny));
     for (int j = 0; j < iny; j++) { rows[size_t(j)].a2 = atan2(dyc[j], dxc[j]); rows[size_t(j)].dx = dxc[j]; }
     RowProp* d_rows = static_cast<RowProp*>(ctx->scratch(TDX_S_J, rows.size() * sizeof(RowProp)));
-    const bool use_walk = getenv("TDX_DINF_WALK") != nullptr;   // A/B hook: the atomic pull walk instead of the tile dependency sweep
+    // default: the tile dependency sweep (LDS tiles on the round schedule, no device-scope atomics).  TDX_DINF_WALK=1: the
+    // atomic pull walk instead (A/B hook; tests/test_gpu_dinf.py checks that both give the same bits)
+    const bool use_walk = getenv("TDX_DINF_WALK") != nullptr;
     int32_t* cnt = use_walk ? static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4)) : reinterpret_cast<int32_t*>(ctx->d_mail);
     uint16_t* info = use_walk ? static_cast<uint16_t*>(ctx->scratch(TDX_S_I, n * 2)) : reinterpret_cast<uint16_t*>(ctx->d_mail);
     const unsigned long long ovf_cap = n / 4 + 1024;
@@ -792,27 +835,31 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         int64_t launches = 0;
         for (;;) {
             RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, geom, sched, ctx->h_mail, nullptr);
+            static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
+            static const bool dbg_cycles = dbg_rounds && atoi(getenv("TDX_DEBUG_ROUNDS")) == 1;
+            unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + 64 : nullptr;
+            int last_printed = -1;
             run.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
                                     unsigned pull_max) {
                 if constexpr (std::is_same<Alg, AreaAlg>::value) {
                     if (d_w)
                         hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, true, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
-                                           fcur, fnext, lnext, pull_max, d_P, d_w, nullptr, info32, d_rows, d_out, out_nodata, contcheck);
+                                           fcur, fnext, lnext, pull_max, d_P, d_w, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);
                     else
                         hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, false, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
-                                           fcur, fnext, lnext, pull_max, d_P, nullptr, nullptr, info32, d_rows, d_out, out_nodata, contcheck);
+                                           fcur, fnext, lnext, pull_max, d_P, nullptr, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);
                 } else {
                     if (d_w)
                         hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, true, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
-                                           list, count, fcur, fnext, lnext, pull_max, d_P, d_w, alg.DM, info32, d_rows, d_out, out_nodata, contcheck);
+                                           list, count, fcur, fnext, lnext, pull_max, d_P, d_w, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);
                     else
                         hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, false, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
-                                           list, count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck);
+                                           list, count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);
                 }
             };
-            static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
             run.print_counts = dbg_rounds;
             if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%zu tiles):", ntiles);
+            if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
             rc = run.start();
             if (rc != TDX_OK) return rc;
             while (!run.done) {
@@ -820,6 +867,15 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 if (rc != TDX_OK) return rc;
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 run.collect();
+                if (dbg) {   // per batch of rounds: average phase times (us) and hops per activation
+                    TDX_HIP_CHECK(ctx, hipMemcpy(ctx->h_mail + 64, dbg, 64, hipMemcpyDeviceToHost));
+                    TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
+                    const double na = double(ctx->h_mail[71] ? ctx->h_mail[71] : 1);
+                    fprintf(stderr, "\n  [rounds %d..%lld] activations %.0f: stage %.1f scan+bulk %.1f walks %.1f writeback %.1f us; hops/act %.1f, busiest lane %.1f, phases %.2f\n",
+                            last_printed + 1, (long long)run.rounds - 1, na, ctx->h_mail[64] / na / 100.0, ctx->h_mail[65] / na / 100.0, ctx->h_mail[66] / na / 100.0,
+                            ctx->h_mail[67] / na / 100.0, ctx->h_mail[68] / na, ctx->h_mail[69] / na, ctx->h_mail[70] / na);
+                    last_printed = int(run.rounds) - 1;
+                }
             }
             rounds += run.rounds;
             launches += run.launches;

@@ -11,8 +11,11 @@ namespace tdxk {
 __device__ __constant__ const int kD1[9] = {0, 1, 1, 0, -1, -1, -1, 0, 1};
 __device__ __constant__ const int kD2[9] = {0, 0, -1, -1, -1, 0, 1, 1, 1};
 
-__device__ __forceinline__ int d1(int k) { return kD1[k]; }
-__device__ __forceinline__ int d2(int k) { return kD2[k]; }
+// As arithmetic on packed 2-bit fields, not table reads: a lookup in a __constant__ array with a RUN-TIME index compiles to a
+// global_load (0.3-1 us) - in the dependency walks that was two or three dependent loads on every hop of the critical path.
+// (With a compile-time k both forms fold to the constant.)
+__device__ __forceinline__ int d1(int k) { return int((0x24069u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ int d2(int k) { return int((0x2a405u >> (2 * k)) & 3u) - 1; }
 
 #define TDX_MINEPS 1E-5f   /* src/commonLib.h:81 */
 

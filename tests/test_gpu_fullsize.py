@@ -72,3 +72,56 @@ def test_properties_hold_where_the_oracle_confirms_them(ctx, oracle, monkeypatch
 def test_properties_at_16384(ctx, monkeypatch):
     amax = _props(ctx, 16384, 1234, monkeypatch)
     assert amax > 2 ** 24      # the exact re-evaluation path was exercised
+
+
+def _dinf_props(ctx, n, seed, monkeypatch):
+    """D-infinity at full size: angles in range, every interior cell resolved, the tile dependency sweep and the atomic pull walk
+    (two independent schedules) agree bit for bit on sca, and flow is conserved at the raster's rim within float32 rounding."""
+    import math
+
+    import torch
+
+    dem = ctx.synth_dem(n, seed=seed)
+    fel = ctx.pitremove(dem, -9999.0)
+    del dem
+    ang, slp, st = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    del fel
+    assert st["flats_left"] == 0
+    inner = ang[1:-1, 1:-1]
+    assert bool(((inner >= 0) & (inner <= 2 * math.pi + 1e-6)).all()), "an interior cell has no D-infinity angle"
+    assert bool((slp[1:-1, 1:-1] >= 0).all())
+    ring_nd = -3.402823466e38
+    assert bool((ang[0] == ring_nd).all() and (ang[-1] == ring_nd).all() and (ang[:, 0] == ring_nd).all() and (ang[:, -1] == ring_nd).all())
+    del slp
+    sca_t = ctx.areadinf(ang, dx=30.0, dy=30.0, contcheck=False)
+    monkeypatch.setenv("TDX_DINF_WALK", "1")
+    sca_w = ctx.areadinf(ang, dx=30.0, dy=30.0, contcheck=False)
+    monkeypatch.delenv("TDX_DINF_WALK")
+    assert torch.equal(sca_t.view(torch.int32), sca_w.view(torch.int32)), "tile dependency sweep and pull walk differ"
+    assert bool((sca_t[1:-1, 1:-1] >= 30.0).all()), "an interior cell was never evaluated"
+    # conservation: what leaves through the nodata ring = every interior cell's own dx (float32 sums along the trunks round)
+    k_d1 = [0, 1, 1, 0, -1, -1, -1, 0, 1]
+    k_d2 = [0, 0, -1, -1, -1, 0, 1, 1, 1]
+    total = 0.0
+    a64 = inner.double()
+    s64 = sca_t[1:-1, 1:-1].double()
+    q = math.pi / 4      # square cells: the facet directions are multiples of pi/4
+    for k in range(1, 9):
+        lo, mid, hi = (k - 2) * q, (k - 1) * q, k * q
+        aa = torch.where((k == 1) & (a64 > math.pi), a64 - 2 * math.pi, a64) if k == 1 else a64
+        p = torch.where((aa > lo) & (aa < hi), torch.where(aa > mid, (hi - aa) / (hi - mid), (aa - lo) / (mid - lo)), torch.zeros_like(aa))
+        p = torch.where(p < 1e-5, torch.zeros_like(p), p)
+        yy, xx = torch.nonzero(p > 0, as_tuple=True)
+        ty, tx = yy + 1 + k_d2[k], xx + 1 + k_d1[k]
+        on_ring = (ty == 0) | (ty == n - 1) | (tx == 0) | (tx == n - 1)
+        total += float((p[yy[on_ring], xx[on_ring]] * s64[yy[on_ring], xx[on_ring]]).sum())
+    want = 30.0 * (n - 2) * (n - 2)
+    assert abs(total - want) <= 2e-3 * want, (total, want)
+
+
+def test_dinf_properties_small(ctx, monkeypatch):
+    _dinf_props(ctx, 700, 3, monkeypatch)
+
+
+def test_dinf_properties_at_16384(ctx, monkeypatch):
+    _dinf_props(ctx, 16384, 1234, monkeypatch)
