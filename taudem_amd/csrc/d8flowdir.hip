@@ -29,31 +29,43 @@ using namespace tdxk;
 
 constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-thread block
 
-// One lane walks down a column segment keeping the 3x3 window in registers (3 loads per new row).
-// Besides p and sd8 it appends the flat cells to `qlist` with ONE atomic per block.
+// One lane walks down a column segment keeping the 3x3 window in registers.  A wave covers 62 output columns: lanes 0 and 63
+// only carry the columns beside them, so the west / east neighbours of a row are DPP lane shifts of the ONE value each lane
+// loads per row (v_mov_b32_dpp wave_shr:1 / wave_shl:1) - a third of the load instructions and of the L1 traffic of three
+// overlapping row loads per lane.  Besides p and sd8 it appends the flat cells to `qlist` with ONE atomic per block.
+constexpr int SLOPE_COLS = 62;
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
                                                        float* __restrict__ SD8, uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
-    const bool colok = x < nx;
-    const int xm = x > 0 ? x - 1 : x, xp = (x < nx - 1) ? x + 1 : (colok ? x : nx - 1);
-    const int xc = colok ? x : nx - 1;
-    auto ldrow = [&](int y, float& a, float& b, float& c) {
-        if (y >= 0 && y < ny) {
-            const float* r = Z + size_t(y) * size_t(nx);
-            a = r[xm]; b = r[xc]; c = r[xp];
-        } else { a = b = c = nodata; }
-    };
-    float n0, n1, n2, c0, c1, c2, s0, s1, s2;
-    ldrow(ybase - 1, n0, n1, n2);
-    ldrow(ybase, c0, c1, c2);
+    using tilek::lane_left;
+    using tilek::lane_right;
+    const int lx = threadIdx.x & 63;
+    const int x = blockIdx.x * SLOPE_COLS - 1 + lx;
+    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
+    const bool mine = lx >= 1 && lx <= SLOPE_COLS && x < nx;
+    const bool inx = x >= 0 && x < nx;
+    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+    // all 18 row loads of the lane are issued back to back (rows clamped into the array; validity applied afterwards)
+    float z[SLOPE_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        z[j] = Z[size_t(yc) * size_t(nx) + size_t(xc)];
+    }
+#pragma unroll
+    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+        const int y = ybase - 1 + j;
+        if (!inx || y < 0 || y >= ny) z[j] = nodata;   // outside the raster reads as nodata (src/linearpart.h:470-483)
+    }
     unsigned flatmask = 0;
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
-        ldrow(y + 1, s0, s1, s2);
-        if (colok && y < y_own1) {
+        const float n1 = z[r], c1 = z[r + 1], s1 = z[r + 2];
+        const float n0 = lane_left(n1, nodata), n2 = lane_right(n1, nodata);
+        const float c0 = lane_left(c1, nodata), c2 = lane_right(c1, nodata);
+        const float s0 = lane_left(s1, nodata), s2 = lane_right(s1, nodata);
+        if (mine && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
             int16_t p = TDX_P_NODATA;
             float sd = -1.0f;
@@ -86,8 +98,6 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
             P[idx] = p;
             if (SD8) SD8[idx] = sd;
         }
-        n0 = c0; n1 = c1; n2 = c2;
-        c0 = s0; c1 = s1; c2 = s2;
     }
     unsigned long long pos = block_reserve(unsigned(__popc(flatmask)), nflat);
 #pragma unroll
@@ -382,7 +392,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+        dim3 grid((inx + SLOPE_COLS - 1) / SLOPE_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
         hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, qlist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }

@@ -23,14 +23,18 @@ using namespace tdxk;
 
 #define TDX_PI 3.14159265359   /* src/commonLib.h:76 */
 
-// facet tables (src/dinf.cpp:328-335)
-__device__ __constant__ const int kID1[9] = {0, 1, 2, 2, 1, 1, 2, 2, 1};
-__device__ __constant__ const int kI1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0};
-__device__ __constant__ const int kI2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1};
-__device__ __constant__ const int kJ1[9] = {0, 1, 0, 0, -1, -1, 0, 0, 1};
-__device__ __constant__ const int kJ2[9] = {0, 1, 1, -1, -1, -1, -1, 1, 1};
-__device__ __constant__ const float kANGC[9] = {0, 0.f, 1.f, 1.f, 2.f, 2.f, 3.f, 3.f, 4.f};
-__device__ __constant__ const float kANGF[9] = {0, 1.f, -1.f, 1.f, -1.f, 1.f, -1.f, 1.f, -1.f};
+// facet tables (src/dinf.cpp:328-335) as arithmetic on packed 2-bit fields: a lookup in a __constant__ array with a
+// run-time index is a global load (device_common.hpp, d1/d2)
+//   ID1 {1,2,2,1,1,2,2,1}  I1 {0,-1,-1,0,0,1,1,0}  I2 {-1,-1,-1,-1,1,1,1,1}  J1 {1,0,0,-1,-1,0,0,1}  J2 {1,1,-1,-1,-1,-1,1,1}
+//   ANGC {0,1,1,2,2,3,3,4} = K / 2      ANGF {1,-1,1,-1,1,-1,1,-1}
+__host__ __device__ constexpr int fI1(int K) { return int((0x1a505u >> (2 * K)) & 3u) - 1; }
+__host__ __device__ constexpr int fI2(int K) { return int((0x2a801u >> (2 * K)) & 3u) - 1; }
+__host__ __device__ constexpr int fJ1(int K) { return int((0x25059u >> (2 * K)) & 3u) - 1; }
+__host__ __device__ constexpr int fJ2(int K) { return int((0x28029u >> (2 * K)) & 3u) - 1; }
+__host__ __device__ constexpr bool fID1_is1(int K) { return ((0x132u >> K) & 1u) != 0u; }
+__host__ __device__ constexpr double fANGC(int K) { return double(K / 2); }
+__host__ __device__ constexpr double fANGF(int K) { return (K & 1) ? 1.0 : -1.0; }
+static_assert(fI1(3) == -1 && fI2(5) == 1 && fJ1(4) == -1 && fJ2(8) == 1 && fID1_is1(1) && !fID1_is1(2) && fID1_is1(8), "facet tables");
 
 // per-row geometry: DXX[1]=dx, DXX[2]=dy, DD, AD12 = atan2(dy,dx) [D1=dx,D2=dy], AD21 = atan2(dx,dy)
 struct RowGeom { double dx, dy, dd, ad12, ad21; };
@@ -48,51 +52,105 @@ __device__ __forceinline__ void vslope(double E0, double E1, double E2, double D
 }
 
 __device__ __forceinline__ void facet_geom(const RowGeom& g, int K, double& D1, double& D2, double& AD) {
-    const bool one = (kID1[K] == 1);
+    const bool one = fID1_is1(K);
     D1 = one ? g.dx : g.dy;
     D2 = one ? g.dy : g.dx;
     AD = one ? g.ad12 : g.ad21;
 }
 
+// VSLOPE's slope without its atan2.  Which of the three branches a facet takes is a question about the SIGN of S2 and about
+// atan2(S2, S1) > atan2(D2, D1), i.e. S2 * D1 > S1 * D2 for positive S1 - decided exactly by that product unless the two sides
+// agree to nine digits, where the rounded atan2 values themselves decide as in the reference.  The angle is needed for the
+// WINNING facet only: 8 fp64 atan2 per cell become at most one.
+//   returns S; *kind = 0: A = 0, 1: A = AD, 2: A = atan2(S2, S1) (interior)
+__device__ __forceinline__ double vslope_s(double E0, double E1, double E2, double D1, double D2, double DD, double AD, int* kind, double* s1o, double* s2o) {
+    const double S1 = (E0 - E1) / D1, S2 = (E1 - E2) / D2;   // cell sizes are never 0
+    *s1o = S1; *s2o = S2;
+    int kd;
+    if (S2 == 0 && S1 == 0) kd = 2;                       // A = 0 through the else-branch: S = sqrt(0) = 0 (kind 2 with atan2 skipped: A = 0)
+    else if (S2 < 0) kd = 0;                              // atan2 < 0
+    else if (S2 == 0) kd = S1 > 0 ? 2 : 1;                // atan2(+0, S1): 0 for S1 > 0 (not < 0, not > AD), pi for S1 < 0
+    else if (S1 <= 0) kd = 1;                             // angle >= pi/2 > AD
+    else {
+        const double l = S2 * D1, r = S1 * D2;
+        if (fabs(l - r) > 1e-9 * (l + r)) kd = l > r ? 1 : 2;
+        else kd = atan2(S2, S1) > AD ? 1 : 2;
+    }
+    *kind = kd;
+    if (kd == 0) return S1;
+    if (kd == 1) return (E0 - E2) / DD;
+    return sqrt(S1 * S1 + S2 * S2);
+}
+
+// setPosDirDinf + SET2 + VSLOPE as a streaming 3x3 stencil: a 256-thread block covers 64 x 64 cells, a lane walks a 16-row
+// column segment with the window in registers (3 coalesced row loads per output row).  Facets whose two corners are both not
+// lower than the centre cannot exceed SMAX = 0 and are skipped before any division.
+constexpr int DSLOPE_ROWS = 16;
 __global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                          const RowGeom* __restrict__ geom, float* __restrict__ ANG,
                                                          float* __restrict__ SLP, unsigned long long* __restrict__ nflat) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool flat = false;
-    if (x < nx && y < y_own1) {
-        const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-        float ang = TDX_ANG_NODATA, slp = -1.0f;
-        const float z0 = Z[idx];
-        const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
-        if (!edge && !is_nodata_f(z0, nodata)) {
-            bool con = false;
+    const int ybase = y_own0 + blockIdx.y * (4 * DSLOPE_ROWS) + (threadIdx.x >> 6) * DSLOPE_ROWS;
+    const bool colok = x < nx;
+    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
+    auto ldrow = [&](int y, float& a, float& b, float& c) {
+        if (y >= 0 && y < ny) {
+            const float* r = Z + size_t(y) * size_t(nx);
+            a = r[xm]; b = r[xc]; c = r[xp];
+        } else { a = b = c = nodata; }
+    };
+    // window w[dy + 1][dx + 1]
+    float n0, n1, n2, c0, c1, c2, s0, s1, s2;
+    ldrow(ybase - 1, n0, n1, n2);
+    ldrow(ybase, c0, c1, c2);
+    unsigned nfl = 0;
 #pragma unroll
-            for (int k = 1; k <= 8; k++) con = con || is_nodata_f(Z[size_t(y + d2(k)) * size_t(nx) + size_t(x + d1(k))], nodata);
-            if (!con) {
-                const RowGeom g = geom[y];
-                double SMAX = 0., AMAX = 0.;
-                int KD = 0;
-                for (int K = 1; K <= 8; K++) {
-                    // SET2(I=row, J=col): E1 at (row+I1, col+J1), E2 at (row+I2, col+J2)
+    for (int r = 0; r < DSLOPE_ROWS; r++) {
+        const int y = ybase + r;
+        ldrow(y + 1, s0, s1, s2);
+        if (colok && y < y_own1) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            float ang = TDX_ANG_NODATA, slp = -1.0f;
+            const float z0 = c1;
+            const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
+            if (!edge && !is_nodata_f(z0, nodata)) {
+                const bool con = is_nodata_f(n0, nodata) || is_nodata_f(n1, nodata) || is_nodata_f(n2, nodata) || is_nodata_f(c0, nodata) ||
+                                 is_nodata_f(c2, nodata) || is_nodata_f(s0, nodata) || is_nodata_f(s1, nodata) || is_nodata_f(s2, nodata);
+                if (!con) {
+                    const RowGeom g = geom[y];
+                    const float w[3][3] = {{n0, n1, n2}, {c0, c1, c2}, {s0, s1, s2}};
+                    double SMAX = 0., S1W = 0., S2W = 0.;
+                    int KD = 0, KINDW = 0;
                     const double a = (double)z0;
-                    const double b = (double)Z[size_t(y + kI1[K]) * size_t(nx) + size_t(x + kJ1[K])];
-                    const double c = (double)Z[size_t(y + kI2[K]) * size_t(nx) + size_t(x + kJ2[K])];
-                    double D1, D2, AD, S, A;
-                    facet_geom(g, K, D1, D2, AD);
-                    vslope(a, b, c, D1, D2, g.dd, AD, S, A);
-                    if (S > SMAX) { SMAX = S; KD = K; AMAX = A; }
+#pragma unroll
+                    for (int K = 1; K <= 8; K++) {
+                        // SET2(I=row, J=col): E1 at (row+I1, col+J1), E2 at (row+I2, col+J2)
+                        const float e1 = w[1 + fI1(K)][1 + fJ1(K)], e2 = w[1 + fI2(K)][1 + fJ2(K)];
+                        if (!(e1 < z0 || e2 < z0)) continue;   // S1 <= 0 and (E0 - E2) <= 0: every branch of VSLOPE gives S <= 0
+                        double D1, D2, AD, sa, sb;
+                        facet_geom(g, K, D1, D2, AD);
+                        int kind;
+                        const double S = vslope_s(a, (double)e1, (double)e2, D1, D2, g.dd, AD, &kind, &sa, &sb);
+                        if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
+                    }
+                    ang = -1.f;
+                    if (KD > 0) {
+                        double AD, D1, D2;
+                        facet_geom(g, KD, D1, D2, AD);
+                        const double AMAX = KINDW == 0 ? 0. : (KINDW == 1 ? AD : ((S2W == 0 && S1W == 0) ? 0. : atan2(S2W, S1W)));
+                        ang = (float)(fANGC(KD) * (TDX_PI / 2) + fANGF(KD) * AMAX);
+                    }
+                    slp = (float)SMAX;
+                    if (ang == -1.f) nfl++;
                 }
-                ang = -1.f;
-                if (KD > 0) ang = (float)(kANGC[KD] * (TDX_PI / 2) + kANGF[KD] * AMAX);
-                slp = (float)SMAX;
-                flat = (ang == -1.f);
             }
+            ANG[idx] = ang;
+            SLP[idx] = slp;
         }
-        ANG[idx] = ang;
-        SLP[idx] = slp;
+        n0 = c0; n1 = c1; n2 = c2;
+        c0 = s0; c1 = s1; c2 = s2;
     }
-    (void)block_reserve(flat ? 1u : 0u, nflat);   // one atomic per block
+    (void)block_reserve(nfl, nflat);   // one atomic per block
 }
 
 struct DinfTraits {
@@ -158,8 +216,8 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
     const double a = (double)Z[c0];
     const int16_t a1 = flat_elev2(lvl[c0], rq[c0], fl);
     for (int K = 1; K <= 8; K++) {
-        const size_t n1 = size_t(ptrdiff_t(c0) + ptrdiff_t(kI1[K]) * nx + kJ1[K]);
-        const size_t n2 = size_t(ptrdiff_t(c0) + ptrdiff_t(kI2[K]) * nx + kJ2[K]);
+        const size_t n1 = size_t(ptrdiff_t(c0) + ptrdiff_t(fI1(K)) * nx + fJ1(K));
+        const size_t n2 = size_t(ptrdiff_t(c0) + ptrdiff_t(fI2(K)) * nx + fJ2(K));
         const bool in1 = rq[n1] > 0, in2 = rq[n2] > 0;   // dn > 0
         double D1, D2, AD, S = 0, A = 0;
         facet_geom(g, K, D1, D2, AD);
@@ -197,7 +255,7 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
     float ang = ANG[c0];
     if (!is_nodata_f(ang, TDX_ANG_NODATA)) ang = -1.f;
     if (KD > 0) {
-        const float t = (float)(kANGC[KD] * (TDX_PI / 2) + kANGF[KD] * AKD);
+        const float t = (float)(fANGC(KD) * (TDX_PI / 2) + fANGF(KD) * AKD);
         if (t >= 0.0f) ang = t;
     }
     ANG[c0] = ang;
@@ -253,7 +311,7 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
+        dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 4 * DSLOPE_ROWS - 1) / (4 * DSLOPE_ROWS));
         hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geom, d_ang, d_slp, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
