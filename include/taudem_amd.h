@@ -301,6 +301,14 @@ int tdx_raster_write(const char* path, int dtype, const void* data, int64_t nx, 
 int tdx_raster_write_geo(const char* path, int dtype, const void* data, int64_t nx, int64_t ny, double nodata,
                          const double* geotransform, int geographic, int lzw);
 
+/* ---- outlet points (replaces readoutlets(), src/ReadOutlets.cpp:49-198, without OGR) -------------------------------- */
+/* Reads point features from an ESRI shapefile (.shp: Point / PointZ / PointM), a GeoJSON file (.json / .geojson: Point
+ * geometries) or a text file ("x y [id]" per line).  x / y / id: caller arrays of `capacity` entries (may be NULL to count);
+ * *count = number of points in the file.  Returns 0, or TDX_ERR_OUTLETS (5, the code of src/aread8.cpp:125). */
+int tdx_outlets_read(const char* path, double* x, double* y, int32_t* id, int64_t capacity, int64_t* count);
+/* tiffIO::geoToGlobalXY (src/tiffIO.cpp:580-588) for the raster `rasterpath`: (int) truncation, no bounds check */
+int tdx_outlets_to_cells(const char* rasterpath, const double* x, const double* y, int64_t n, int32_t* col, int32_t* row);
+
 /* ---- file-level tool functions (argument lists of the reference's tool functions) ---------- */
 /* int flood(char*,char*,char*,int,bool,bool,bool,char*)            src/flood.h:1-2 */
 int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* sfdrfile, int usesfdr,

@@ -150,6 +150,8 @@ _SIGNATURES = {
     "tdx_tool_gridnet": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_d8flowpathextremeup": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_tool_threshold": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int]),
+    "tdx_outlets_read": (C.c_int, [C.c_char_p, _P, _P, _P, _I64, C.POINTER(_I64)]),
+    "tdx_outlets_to_cells": (C.c_int, [C.c_char_p, _P, _P, _I64, _P, _P]),
     "tdx_tool_set_device": (C.c_int, [C.c_int]),
     "tdx_tool_set_gpus": (C.c_int, [C.c_int]),
     "tdx_rccl_unique_id": (C.c_int, [_P]),

@@ -5,6 +5,7 @@
 
 #include "../../include/taudem_amd.h"
 #include "geotiff.hpp"
+#include "outlets.hpp"
 
 extern thread_local std::string g_tdx_thread_error;
 
@@ -84,6 +85,34 @@ int tdx_raster_write_geo(const char* path, int dtype, const void* data, int64_t 
     if (geographic) ri.geo.geokeys = {1, 1, 0, 2, 1024, 0, 1, 2, 1025, 0, 1, 1};
     ri.geographic = geographic != 0;
     return write_common(path, dtype, data, nx, ny, nodata, &ri, lzw);
+}
+
+int tdx_outlets_read(const char* path, double* x, double* y, int32_t* id, int64_t capacity, int64_t* count) {
+    if (!path || !count) return TDX_ERR_ARG;
+    std::vector<double> vx, vy;
+    std::vector<int> vid;
+    std::string err;
+    if (!tdx::read_outlets(path, vx, vy, vid, err)) { g_tdx_thread_error = err; return TDX_ERR_OUTLETS; }
+    *count = int64_t(vx.size());
+    for (int64_t i = 0; i < int64_t(vx.size()) && i < capacity; i++) {
+        if (x) x[i] = vx[size_t(i)];
+        if (y) y[i] = vy[size_t(i)];
+        if (id) id[i] = vid[size_t(i)];
+    }
+    return TDX_OK;
+}
+
+int tdx_outlets_to_cells(const char* rasterpath, const double* x, const double* y, int64_t n, int32_t* col, int32_t* row) {
+    if (!rasterpath || !x || !y || !col || !row || n < 0) return TDX_ERR_ARG;
+    tdx::TiffReader rd;
+    if (!rd.open(rasterpath)) { g_tdx_thread_error = rd.error(); return TDX_ERR_FILE; }
+    const tdx::RasterInfo ri = rd.info();
+    for (int64_t i = 0; i < n; i++) {
+        int gx, gy;
+        tdx::geo_to_global_xy(x[i], y[i], ri.xleftedge, ri.ytopedge, ri.dlon, ri.dlat, gx, gy);
+        col[i] = gx; row[i] = gy;
+    }
+    return TDX_OK;
 }
 
 }  // extern "C"
