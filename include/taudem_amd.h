@@ -129,14 +129,18 @@ int tdx_aread8(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16
                float* ad8, tdx_stats* stats);
 
 /* ---- GridNet / Threshold (the step after AreaD8) ------------------------- */
-/* gridnet() src/gridnet.cpp:54-514 without outlets: plen / tlen = longest / total upstream path length (float, -1 nodata),
- * gord = Strahler order (int16, -1 nodata).  mask: optional int32 grid, only cells with mask >= thresh are evaluated
- * (NULL = all cells).  dxc / dyc: per-row cell sizes (ny doubles, HOST). */
+/* gridnet() src/gridnet.cpp:54-514: plen / tlen = longest / total upstream path length (float, -1 nodata), gord = Strahler order
+ * (int16, -1 nodata).  mask: optional int32 grid, only cells with mask >= thresh are evaluated (NULL = all cells).  dxc / dyc: per-row
+ * cell sizes (ny doubles, HOST).  Outlets (src/gridnet.cpp:269-369): n_outlets < 0 = none; otherwise HOST arrays of global column / row
+ * indices - only the outlets' upstream closure is evaluated, other cells get gord 0.  Strips: as tdx_aread8_strip (mask strip halo rows
+ * are filled by the library; outlet rows in strip-array coordinates). */
 int tdx_gridnet_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata,
                     const double* dxc, const double* dyc, const int32_t* d_mask, int32_t thresh,
+                    const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
                     float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats);
 int tdx_gridnet(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata,
                 const double* dxc, const double* dyc, const int32_t* mask, int32_t thresh,
+                const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
                 float* plen, float* tlen, int16_t* gord, tdx_stats* stats);
 /* threshold() src/Threshold.cpp:49-162: src = 1 where ssa >= thresh (and mask >= 0), else 0; -32768 where ssa is nodata */
 int tdx_threshold_dev(tdx_context* ctx, const float* d_ssa, int64_t nx, int64_t ny, float ssa_nodata,
@@ -271,6 +275,11 @@ int tdx_d8flowpathextremeup_strip(tdx_context* ctx, const tdx_comm* comm, int16_
                                   int16_t p_nodata, const float* d_sa, int usemax, int contcheck,
                                   const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
                                   float* d_ssa, tdx_stats* stats);
+/* GridNet on a strip (d_mask: optional int32 strip array whose halo rows the library fills) */
+int tdx_gridnet_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
+                      const double* dxc, const double* dyc, int32_t* d_mask, int32_t thresh,
+                      const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
+                      float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats);
 
 /* ---- synthetic benchmark input (not in the reference) -------------------------------------- */
 /* Fills d_out (nx*ny float32) with the seeded fractal surface of taudem_amd/csrc/synth_dem.h for
@@ -329,8 +338,7 @@ int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* data
 int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const char* dmfile, const char* datasrc,
                             const char* lyrname, int uselyrname, int lyrno, const char* wfile,
                             int useOutlets, int usew, int contcheck);
-/* int gridnet(char*,char*,char*,char*,char*,char*,char*,int,int,int,int,int)  src/gridnet.cpp:54-55
- * (useOutlets = 1 is not built yet: returns TDX_ERR_ARG) */
+/* int gridnet(char*,char*,char*,char*,char*,char*,char*,int,int,int,int,int)  src/gridnet.cpp:54-55 */
 int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile,
                      const char* maskfile, const char* datasrc, const char* lyrname, int uselyrname, int lyrno,
                      int useMask, int useOutlets, int thresh);

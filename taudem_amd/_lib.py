@@ -120,8 +120,9 @@ _SIGNATURES = {
     "tdx_d8flowpathextremeup_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_d8flowpathextremeup": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_d8flowpathextremeup_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, _P, C.c_int, C.c_int, _P, _P, _I64, _P, _P]),
-    "tdx_gridnet_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
-    "tdx_gridnet": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "tdx_gridnet_dev": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _I64, _P, _P, _P, _P]),
+    "tdx_gridnet": (C.c_int, [_P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _I64, _P, _P, _P, _P]),
+    "tdx_gridnet_strip": (C.c_int, [_P, _P, _P, _I64, _I64, C.c_int16, _P, _P, _P, C.c_int32, _P, _P, _I64, _P, _P, _P, _P]),
     "tdx_threshold_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _F, _P, _P]),
     "tdx_threshold": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _F, _P, _P]),
     "tdx_dinfflowdir_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),

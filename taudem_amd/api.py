@@ -176,8 +176,9 @@ class Context:
         del keep
         return (ssa, st.as_dict()) if stats else ssa
 
-    def gridnet(self, p, nodata=int(P_NODATA), dx=1.0, dy=1.0, mask=None, thresh=0, stats=False):
-        """plen, tlen, gord = gridnet(p)  (src/gridnet.cpp:54, no outlets).  mask: int32 raster, cells with mask >= thresh are evaluated."""
+    def gridnet(self, p, nodata=int(P_NODATA), dx=1.0, dy=1.0, mask=None, thresh=0, outlets=None, stats=False):
+        """plen, tlen, gord = gridnet(p)  (src/gridnet.cpp:54).  mask: int32 raster, cells with mask >= thresh are evaluated;
+        outlets: (columns, rows) - only their upstream closure is evaluated."""
         ny, nx = p.shape
         dxc, dyc = _f64(dx, ny), _f64(dy, ny)
         plen = self._out(p, np.float32, (ny, nx))
@@ -191,9 +192,11 @@ class Context:
         if mask is not None and mdev != dev:
             raise ValueError("all rasters must be on the same side (host or device)")
         st = TdxStats()
+        ox, oy, no, keep = self._outlets(outlets)
         self._sync_torch(p, mask)
         check(self._pick(dev, "tdx_gridnet")(self._h, pp, nx, ny, int(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pm, int(thresh),
-                                              ppl, ptl, pgo, C.byref(st)), self._h)
+                                              ox, oy, no, ppl, ptl, pgo, C.byref(st)), self._h)
+        del keep
         return (plen, tlen, gord, st.as_dict()) if stats else (plen, tlen, gord)
 
     def threshold(self, ssa, thresh, nodata=-1.0, mask=None, stats=False):

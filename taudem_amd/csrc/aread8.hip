@@ -17,6 +17,7 @@
 //   outlets            reverse BFS from the outlet cells marks the upstream closure (frontier sweeps)
 #include "context.hpp"
 #include "device_common.hpp"
+#include "d8_sweep.hpp"
 #include "flats.hpp"
 #include "strips.hpp"
 
@@ -983,9 +984,47 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
         hipLaunchKernelGGL(d8_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, reach, n, p_nodata, pprime);
         p_use = pprime;
     }
-    if (tiled) return aread8_tiled(ctx, st, p_use, p_nodata, contcheck, d_ad8, stats);
+    if (tiled && getenv("TDX_AD8_SWEEP") == nullptr) return aread8_tiled(ctx, st, p_use, p_nodata, contcheck, d_ad8, stats);
 
-    // ---- exact pull walk (weights / TDX_AD8_WALK) ----
+    if (!force_walk) {
+        // ---- tile dependency sweep (weights, extremes, rasters beyond the 32-bit counts; TDX_AD8_SWEEP=1: always) ----
+        uint32_t* info = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, n * 4));
+        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+        unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+        if (!info || !flags || !counts) return TDX_ERR_NOMEM;
+        ctx->begin_call(stats);
+        rc = strip_exchange<int16_t>(ctx, st, p_use, p_nodata);
+        if (rc != TDX_OK) return rc;
+        {
+            TdxSpan sp(ctx, TDX_K_STENCIL);
+            hipLaunchKernelGGL(d8sweep::setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, p_use, inx, iny, p_nodata, 0, nullptr, 0, nullptr, info);
+            const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);
+            hipLaunchKernelGGL(d8sweep::init_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, info, d_ad8, first, nown, ex.out_nodata);
+            if (stats) stats->launches[TDX_K_STENCIL] += 2;
+        }
+        rc = strip_exchange<float>(ctx, st, d_ad8, ex.out_nodata);
+        if (rc != TDX_OK) return rc;
+        int64_t rounds = 0, launches = 0, outer = 1;
+        {
+            TdxSpan sp(ctx, TDX_K_ACCUM);
+            d8sweep::SumMaxMin alg{ex.mode, ex.out_nodata, w_nodata, contcheck, d_w != nullptr};
+            d8sweep::Arrays<d8sweep::SumMaxMin> A{d_ad8, d_w, nullptr, info};
+            rc = d8sweep::run(ctx, st, alg, A, flags, counts, &rounds, &launches, &outer);
+            if (rc != TDX_OK) return rc;
+            const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);
+            hipLaunchKernelGGL(d8sweep::finish_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, d_ad8, first, nown, ex.out_nodata);   // never evaluated: nodata
+            if (stats) stats->launches[TDX_K_ACCUM] += launches;
+        }
+        TDX_HIP_CHECK(ctx, hipGetLastError());
+        tdx_stats* stt = stats;
+        ctx->end_call();
+        if (stt) { stt->rounds = outer; stt->cells_evaluated = rounds; }
+        return TDX_OK;
+    }
+
+    // ---- exact pull walk (TDX_AD8_WALK: A/B hook) ----
     int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
     float* recvbuf = static_cast<float*>(ctx->scratch(TDX_S_K, size_t(inx) * 4 * 4));
     if (!cnt || !recvbuf) return TDX_ERR_NOMEM;

@@ -159,34 +159,51 @@ void print_gpu_stats(const char* tool, const tdx_stats& st, int64_t cells) {
 
 extern "C" {
 
-int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile, const char* maskfile, const char* /*datasrc*/,
+int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfile, const char* gordfile, const char* maskfile, const char* datasrc,
                      const char* /*lyrname*/, int /*uselyrname*/, int /*lyrno*/, int useMask, int useOutlets, int thresh) {
     printf("GridNet version %s\n", TDVERSION);
     fflush(stdout);
-    if (useOutlets == 1) {
-        g_tdx_thread_error = "gridnet: the outlets branch (-o) is not built yet";
-        fprintf(stderr, "taudem_amd: %s\n", g_tdx_thread_error.c_str());
-        return TDX_ERR_ARG;
-    }
     const double begint = now_s();
     Raster p, mask;
     int rc = load_raster(pfile, tdx::DType::I16, p);
     if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, p.info, ox, oy); if (rc != TDX_OK) return rc; }   // src/gridnet.cpp:78-120
     if (useMask == 1) {
         rc = load_raster(maskfile, tdx::DType::I32, mask);
         if (rc != TDX_OK) return rc;
         if (!compare_rasters(p.info, pfile, mask.info, maskfile)) { printf("File sizes do not match\n%s\n", maskfile); fflush(stdout); return TDX_ERR_OUTLETS; }   // src/gridnet.cpp:147-152
     }
     const double readt = now_s();
-    CtxGuard g;
-    if (g.rc != TDX_OK) return g.rc;
     const size_t n = p.s.size();
     std::vector<float> plen(n), tlen(n);
     std::vector<int16_t> gord(n);
     tdx_stats st;
-    rc = tdx_gridnet(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, p.info.dxc.data(), p.info.dyc.data(),
-                     useMask ? mask.l.data() : nullptr, thresh, plen.data(), tlen.data(), gord.data(), &st);
-    if (rc != TDX_OK) { fprintf(stderr, "taudem_amd: %s\n", tdx_last_error(g.c)); return rc; }
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            int16_t* d_p = j.strip<int16_t>(p.s.data());
+            int32_t* d_m = useMask ? j.strip<int32_t>(mask.l.data()) : nullptr;
+            float* d_pl = j.strip<float>(nullptr);
+            float* d_tl = j.strip<float>(nullptr);
+            int16_t* d_go = j.strip<int16_t>(nullptr);
+            if (!d_p || !d_pl || !d_tl || !d_go || (useMask && !d_m)) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(p.info.dxc), dys = j.rows_of(p.info.dyc);
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_gridnet_strip(j.ctx, j.comm, d_p, j.nx, j.nyl, (int16_t)p.info.nodata, dxs.data(), dys.data(), d_m, thresh, useOutlets ? ox.data() : nullptr,
+                                            useOutlets ? lrow.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, d_pl, d_tl, d_go, s);
+            if (e != TDX_OK) return e;
+            return (j.fetch(plen.data(), d_pl) && j.fetch(tlen.data(), d_tl) && j.fetch(gord.data(), d_go)) ? TDX_OK : TDX_ERR_HIP;
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_gridnet(g.c, p.s.data(), p.info.nx, p.info.ny, (int16_t)p.info.nodata, p.info.dxc.data(), p.info.dyc.data(), useMask ? mask.l.data() : nullptr, thresh,
+                         useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, plen.data(), tlen.data(),
+                         gord.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
     const double computet = now_s();
     rc = save_raster(gordfile, tdx::DType::I16, gord.data(), p.info, -1.0);   // src/gridnet.cpp:474-481
     if (rc != TDX_OK) return rc;
@@ -195,7 +212,7 @@ int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfi
     rc = save_raster(tlenfile, tdx::DType::F32, tlen.data(), p.info, -1.0);
     if (rc != TDX_OK) return rc;
     const double writet = now_s();
-    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", 1, readt - begint, computet - readt,
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt,
            writet - computet, writet - begint);
     print_gpu_stats("gridnet", st, p.info.nx * p.info.ny);
     return 0;

@@ -1,0 +1,416 @@
+// Tile dependency sweep for the D8 flow algebra: weighted AreaD8, D8FlowPathExtremeUp (aread8.hip) and GridNet (gridnet.hip).
+//
+// Same idea as the D-infinity sweep of areadinf.hip (dsweep): a cell's value depends only on the values of the cells that
+// drain into it (the reference folds them in k = 1..8 order: src/aread8.cpp:231-256, src/D8flowpathextremeup.cpp:167-199,
+// src/gridnet.cpp:380-426), never on the schedule.  The atomic pull walks pay two device-scope memory round trips per cell of
+// the longest flow path and one device-scope atomic per flow link; here a 1024-thread workgroup stages a 64 x 64 tile + ring of
+// the result(s) and the per-cell info word in LDS, counts the pending contributors of every pending cell FROM THE STAGED VALUES
+// (no global counters), evaluates ready cells in lockstep sweeps while the tile is fresh, then lets lanes walk chains
+// downstream inside LDS (one returning LDS atomic per hop; D8 has one target per cell, so a chain never forks).  Finished
+// cells are written back; a tile whose cells drain into a neighbouring tile raises that tile's flag for the next ROUND
+// (the schedule of tile_relax.hpp).  Rounds = tile crossings of the longest flow path; strips exchange the boundary rows of
+// the result between runs of rounds and re-activate the tiles that see a changed halo cell.
+//
+// Per-cell info word (d8sweep::setup_kernel, one streaming pass over the direction grid):
+//   [0:8)   neighbour k is a contributor for the DEPENDENCY count (in-degree of initNeighborD8up, src/commonLib.cpp:251-282:
+//           its direction code is 0..8 and code - k == +-4 - which includes a p == 0 cell at k == 4, the reference's quirk)
+//   [8]     a neighbour is missing (off the raster or nodata): edge contamination (src/aread8.cpp:241-242)
+//   [9:13)  the cell's own direction code (0..8; 15: none / sink)
+//   [13]    the cell participates      [14] the cell can never become ready (a p == 0 contributor is counted but never drains)
+//   [16:24) neighbour k contributes to the VALUE (GridNet: its code is > 0, its mask value passes and it drains into the cell;
+//           the AreaD8 family: same as [0:8))
+//   [24]    the cell's own mask value passes (GridNet: an unmasked cell completes without being evaluated)
+#pragma once
+#include "context.hpp"
+#include "device_common.hpp"
+#include "flats.hpp"
+#include "strips.hpp"
+#include "tile_relax.hpp"
+
+#include <cstring>
+
+namespace d8sweep {
+using namespace tdxk;
+constexpr int TS = tilek::TS, LH = TS + 2;
+constexpr int NT = 1024, RPL = TS * TS / NT, NSTAGE = (LH * LH + NT - 1) / NT;
+constexpr int BULK_SWEEPS = 12;
+constexpr uint32_t PENDING_BITS = 0x7FC0DEADu;   // a quiet NaN no arithmetic produces: "participating, not evaluated yet"
+constexpr unsigned INFO_CON = 1u << 8, INFO_PART = 1u << 13, INFO_DEAD = 1u << 14, INFO_OWNMASK = 1u << 24;
+constexpr int16_t P_OUTSIDE = 16, P_SINK = 32;   // re-coded directions of outlets mode (aread8.hip)
+
+__device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == PENDING_BITS; }
+
+// gn_mask: GridNet's mask grid (cells with mask >= thresh are evaluated), nullptr otherwise; gridnet != 0 selects GridNet's
+// value-contributor rule.  participates(p): code 0..8 or P_SINK (AreaD8 family) / any non-nodata code inside `reach` (GridNet).
+static __global__ __launch_bounds__(256) void setup_kernel(const int16_t* __restrict__ P, int nx, int ny, int16_t nodata, int gridnet,
+                                                    const int32_t* __restrict__ gn_mask, int thresh, const int32_t* __restrict__ reach,
+                                                    uint32_t* __restrict__ info) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    const int16_t p = P[idx];
+    unsigned inf = 0;
+    bool part;
+    if (gridnet) part = !is_nodata_s(p, nodata) && (!reach || reach[idx] == 1);
+    else part = !is_nodata_s(p, nodata) && ((p >= 0 && p <= 8) || p == P_SINK);
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        const int xn = x + d1(k), yn = y + d2(k);
+        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { inf |= INFO_CON; continue; }
+        const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+        const int16_t pn = P[n];
+        if (is_nodata_s(pn, nodata)) { inf |= INFO_CON; continue; }
+        const bool drains = (pn - k == 4 || pn - k == -4);
+        if (!drains) continue;
+        if (gridnet) {
+            // in-degree: every non-nodata neighbour that drains into the cell (src/gridnet.cpp:238-267; with outlets: :285-300)
+            inf |= 1u << (k - 1);
+            if (pn == 0) inf |= INFO_DEAD;
+            if (pn > 0 && (!gn_mask || gn_mask[n] >= thresh)) inf |= 1u << (16 + k - 1);
+        } else if (pn >= 0 && pn <= 8) {
+            inf |= (1u << (k - 1)) | (1u << (16 + k - 1));
+            if (pn == 0) inf |= INFO_DEAD;   // counted in the in-degree, never decremented (src/aread8.cpp:262)
+        }
+    }
+    const unsigned code = (p >= 0 && p <= 8) ? unsigned(p) : 15u;
+    inf |= code << 9;
+    if (part) inf |= INFO_PART;
+    if (!gn_mask || gn_mask[idx] >= thresh) inf |= INFO_OWNMASK;
+    info[idx] = inf;
+}
+
+// rim bit (tilek::RES_* numbering) of the neighbouring tile that holds the cell (nx2, ny2), which lies outside this tile
+__device__ __forceinline__ int rim_bit(int nx2, int ny2) {
+    return ny2 < 0 ? (nx2 < 0 ? 16 : (nx2 >= TS ? 32 : 1)) : (ny2 >= TS ? (nx2 < 0 ? 64 : (nx2 >= TS ? 128 : 2)) : (nx2 < 0 ? 4 : 8));
+}
+
+// ---- value policies -------------------------------------------------------------------------------------------------------
+// A policy defines the per-cell record (`Cell`) that lives in the work array and, tile + ring, in LDS.  Its first 32 bits carry
+// the pending pattern.  A record is read and written with ONE load / store instruction, so a tile that stages its ring while the
+// neighbouring tile writes back (same round) sees either the old record (pending) or the complete new one - never a mixture;
+// that is why GridNet's three results travel as one 16-byte record and are split into the three rasters afterwards.
+struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8Expr)
+    using Cell = float;
+    static constexpr bool HAS_AUX = true;       // weight grid / the grid whose extreme is sought (may be absent for unit weights)
+    static constexpr bool HAS_DIST = false;
+    int mode;            // 0 sum, 1 max, 2 min
+    float out_nodata;
+    float w_nodata;
+    int contcheck;
+    bool has_aux;
+    static __device__ __forceinline__ float head(float c) { return c; }
+    static __host__ __device__ __forceinline__ float outside() { return -1.0f; }
+    template <class L>
+    __device__ __forceinline__ void eval(L& S, int c, int cl, int ly, unsigned inf, const Cell (&nb)[9]) const {
+        float a;
+        const float aux = has_aux ? S.aux[c] : 1.0f;
+        if (mode != 0) a = aux;                                                     // src/D8flowpathextremeup.cpp:170
+        else if (has_aux) a = is_nodata_f(aux, w_nodata) ? TDX_AREA_NODATA : aux;   // a nodata weight keeps the initial -1
+        else a = 1.0f;
+        bool con = (inf & INFO_CON) != 0u;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            if (!((inf >> (16 + k - 1)) & 1u)) continue;
+            const float v = nb[k];
+            if (is_nodata_f(v, out_nodata)) con = true;
+            else if (mode == 0) a = a + v;
+            else if (mode == 1) { if (v > a) a = v; }
+            else { if (v < a) a = v; }
+        }
+        if (con && contcheck == 1) a = out_nodata;
+        S.v[cl] = a;
+    }
+};
+
+struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (int bits), -}
+    using Cell = float4;
+    static constexpr bool HAS_AUX = false;
+    static constexpr bool HAS_DIST = true;
+    static __device__ __forceinline__ float head(const float4& c) { return c.x; }
+    static __host__ __device__ __forceinline__ float4 outside() { const int m1 = -1; float z; memcpy(&z, &m1, 4); return make_float4(-1.0f, -1.0f, z, 0.f); }
+    template <class L>
+    __device__ __forceinline__ void eval(L& S, int c, int cl, int ly, unsigned inf, const Cell (&nb)[9]) const {
+        float4 me = S.v[cl];
+        if (!(inf & INFO_OWNMASK)) { me.x = -1.0f; S.v[cl] = me; return; }   // completes without a value: tlen / gord keep what they had
+        float tl = 0.0f, pl = 0.0f;
+        int a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            if (!((inf >> (16 + k - 1)) & 1u)) continue;
+            const int g = __float_as_int(nb[k].z);        // Strahler order (src/gridnet.cpp:404-411)
+            if (g >= a1) { a2 = a1; a1 = g; }
+            else if (g > a2) a2 = g;
+            const float dd = S.dist[ly * 9 + ((k + 3) % 8 + 1)];   // dist[j][sdir]: the row of the evaluated cell, the CODE of the neighbour (= k +- 4)
+            const float ld = nb[k].x + dd;
+            tl = tl + (float)(nb[k].y + dd);
+            if (ld > pl) pl = ld;
+        }
+        S.v[cl] = make_float4(pl, tl, __int_as_float((a2 + 1 > a1) ? a2 + 1 : a1), 0.f);
+    }
+};
+
+template <class Alg>
+struct Lds {
+    typename Alg::Cell v[LH * LH];
+    float aux[Alg::HAS_AUX ? TS * TS : 1];
+    float dist[Alg::HAS_DIST ? TS * 9 : 1];
+    uint32_t info[TS * TS];
+    uint32_t cnt[TS * TS / 4];   // one byte per cell: contributors still pending (255: not a pending cell of this rank)
+    int rim;
+};
+
+template <class Alg>
+struct Arrays {   // global arrays of one sweep
+    typename Alg::Cell* v;                  // the work array (AreaD8 family: the result raster itself)
+    const float* aux;                       // weights / input grid (may be null)
+    const float* dist;                      // GridNet: [row][9]
+    const uint32_t* info;
+};
+
+template <class Alg>
+__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg>& S, const Arrays<Alg>& A) {
+    using Cell = typename Alg::Cell;
+    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    if (tid == 0) S.rim = 0;
+    // ---- stage: every load is issued before the first LDS store (addresses clamped, validity applied afterwards)
+    {
+        Cell s0[NSTAGE];
+        uint32_t si[RPL];
+        float sa[Alg::HAS_AUX ? RPL : 1];
+        unsigned ok = 0;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT, ec = e < LH * LH ? e : LH * LH - 1;
+            const int wy = ec / LH, wx = ec - wy * LH;
+            const int gx = x0 - 1 + wx, gy = y0 - 1 + wy;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) ok |= 1u << i;
+            const int gxc = gx < 0 ? 0 : (gx >= g.nx ? g.nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy);
+            s0[i] = A.v[size_t(gyc) * size_t(g.nx) + size_t(gxc)];
+        }
+        unsigned oki = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            const int gx = x0 + lx, gy = y0 + ry0 + r;
+            if (gx < g.nx && gy < g.ny) oki |= 1u << r;
+            const size_t idx = size_t(gy >= g.ny ? g.ny - 1 : gy) * size_t(g.nx) + size_t(gx >= g.nx ? g.nx - 1 : gx);
+            si[r] = A.info[idx];
+            if (Alg::HAS_AUX) sa[r] = A.aux ? A.aux[idx] : 0.f;
+        }
+        float sdist = 0.f;
+        if (Alg::HAS_DIST && tid < TS * 9) { const int gy = y0 + tid / 9; sdist = A.dist[size_t(gy >= g.ny ? g.ny - 1 : gy) * 9 + size_t(tid % 9)]; }
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT;
+            if (e < LH * LH) S.v[e] = ((ok >> i) & 1u) ? s0[i] : Alg::outside();   // (never read: cells outside the raster are nobody's contributor)
+        }
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            S.info[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? si[r] : 0u;
+            if (Alg::HAS_AUX) S.aux[(ry0 + r) * TS + lx] = sa[r];
+        }
+        if (Alg::HAS_DIST && tid < TS * 9) S.dist[tid] = sdist;
+    }
+    __syncthreads();
+    unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet) and can become ready
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int gx = x0 + lx, gy = y0 + ry0 + r;
+        if (gx < g.nx && gy >= g.y_own0 && gy < g.y_own1 && pending(Alg::head(S.v[(ry0 + r + 1) * LH + lx + 1])) && !(S.info[(ry0 + r) * TS + lx] & INFO_DEAD))
+            pendmask |= 1u << r;
+    }
+    const unsigned pend0 = pendmask;
+    int rim = 0;
+    auto out_of_tile = [&](unsigned inf, int cx, int ly) {   // the tile a finished cell drains into has to look again
+        const int code = int((inf >> 9) & 15u);
+        if (code >= 1 && code <= 8) {
+            const int nx2 = cx + d1(code), ny2 = ly + d2(code);
+            if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rim |= rim_bit(nx2, ny2);
+        }
+    };
+    auto load_nbrs = [&](int cl, Cell (&nb)[9]) {   // unconditional and together: one LDS latency for the whole neighbourhood
+#pragma unroll
+        for (int k = 1; k <= 8; k++) nb[k] = S.v[cl + d2(k) * LH + d1(k)];
+    };
+    auto pending_bits = [&](const Cell (&nb)[9]) {
+        unsigned pb = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) pb |= pending(Alg::head(nb[k])) ? 1u << (k - 1) : 0u;
+        return pb;
+    };
+    // ---- bulk: lockstep sweeps over the lane's own cells (ready = no contributor pending), no atomics
+    if (full) {
+        for (int sweep = 0; sweep < BULK_SWEEPS; sweep++) {
+            bool prog = false;
+#pragma unroll
+            for (int rr = 0; rr < RPL; rr++) {
+                const int r = (sweep & 1) ? RPL - 1 - rr : rr;
+                if (!((pendmask >> r) & 1u)) continue;
+                const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
+                const unsigned inf = S.info[c];
+                Cell nb[9];
+                load_nbrs(cl, nb);
+                if ((inf & 0xFFu & pending_bits(nb)) == 0u) {
+                    alg.eval(S, c, cl, ly, inf, nb);
+                    out_of_tile(inf, lx, ly);
+                    pendmask &= ~(1u << r);
+                    prog = true;
+                }
+            }
+            if (!__syncthreads_or(prog ? 1 : 0)) break;
+        }
+    }
+    // ---- pending contributors of the cells that are left
+    unsigned readymask = 0;
+    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(S.cnt);
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
+        unsigned cn = 255u;
+        const unsigned inf = S.info[c];
+        Cell nb[9];
+        load_nbrs(cl, nb);
+        if ((pendmask >> r) & 1u) {
+            cn = unsigned(__popc(inf & 0xFFu & pending_bits(nb)));
+            if (cn == 0u) readymask |= 1u << r;
+        }
+        cnt8[c] = uint8_t(cn);
+    }
+    __syncthreads();
+    // ---- walks: a lane follows the flow path downstream as long as it finishes the last pending contributor of the next cell
+    for (unsigned m = readymask; m; m &= m - 1u) {
+        int c = (ry0 + (__ffs(int(m)) - 1)) * TS + lx;
+        unsigned inf = S.info[c];
+        for (;;) {
+            const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
+            Cell nb[9];
+            load_nbrs(cl, nb);
+            alg.eval(S, c, cl, ly, inf, nb);
+            const int code = int((inf >> 9) & 15u);
+            if (code < 1 || code > 8) break;
+            const int nx2 = cx + d1(code), ny2 = ly + d2(code);
+            if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit(nx2, ny2); break; }
+            const int tc = ny2 * TS + nx2, sh = 8 * (tc & 3);
+            const unsigned old = __hip_atomic_fetch_sub(&S.cnt[tc >> 2], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned tinf = S.info[tc];
+            if (((old >> sh) & 255u) != 1u) break;   // somebody else finishes its last contributor
+            c = tc; inf = tinf;
+        }
+    }
+    __syncthreads();
+    // ---- write back what this activation evaluated (one store per record)
+    bool wrote = false;
+    for (unsigned m = pend0; m; m &= m - 1u) {
+        const int r = __ffs(int(m)) - 1, ly = ry0 + r, cl = (ly + 1) * LH + lx + 1;
+        const Cell v = S.v[cl];
+        if (!pending(Alg::head(v))) { A.v[size_t(y0 + ly) * size_t(g.nx) + size_t(x0 + lx)] = v; wrote = true; }
+    }
+    if (rim) atomicOr(&S.rim, rim);
+    const int any = __syncthreads_or(wrote ? 1 : 0);
+    const int res = any ? (tilek::RES_CHANGED | S.rim) : 0;
+    __syncthreads();   // S is reused by the next tile
+    return res;
+}
+
+template <class Alg>
+__global__ __launch_bounds__(NT) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+                                                   uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
+                                                   unsigned pull_max, Arrays<Alg> A) {
+    __shared__ Lds<Alg> S;
+    __shared__ tilek::TileLds L;
+    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg>(alg, g, tile, full, S, A); });
+}
+
+// the pending pattern that is left (cells on or below a cycle, cells fed by the p == 0 quirk) becomes `value`
+static __global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ v0, size_t first, size_t n, float value) {
+    const size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < first + n && pending(v0[i])) v0[i] = value;
+}
+
+// initial state of the primary result array on the owned rows: pending where the cell participates, `other` elsewhere
+static __global__ __launch_bounds__(256) void init_kernel(const uint32_t* __restrict__ info, float* __restrict__ v0, size_t first, size_t n, float other) {
+    const size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < first + n) v0[i] = (info[i] & INFO_PART) ? __uint_as_float(PENDING_BITS) : other;
+}
+
+// ---- upstream closure of outlet cells (outlets mode) through the tile relaxation engine (flats.hpp: reach_closure) ----
+// mask of the reachability relaxation: the neighbour a cell drains to; a p == 0 cell counts as draining to its south-east
+// neighbour, because the in-degree counts it there (src/commonLib.cpp:257-266, src/gridnet.cpp:285-300)
+static __global__ __launch_bounds__(256) void reach_mask_kernel(const int16_t* __restrict__ P, size_t n, int16_t nodata, uint8_t* __restrict__ mask) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int16_t p = P[i];
+    unsigned m = 0;
+    if (!is_nodata_s(p, nodata)) {
+        if (p >= 1 && p <= 8) m = 1u << (p - 1);
+        else if (p == 0) m = 1u << 7;
+    }
+    mask[i] = uint8_t(m);
+}
+// outlet cells (array coordinates; only those in the owned rows, and with skip_nodata only those on a cell with a direction
+// value): reach = 1 and their tile is activated
+static __global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int y_own0,
+                                                                int y_own1, int tiles_x, const int16_t* __restrict__ P, int16_t nodata, int skip_nodata,
+                                                                int32_t* __restrict__ reach, uint32_t* __restrict__ tile_flags) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    const int x = ox[o], y = oy[o];
+    if (x < 0 || x >= nx || y < y_own0 || y >= y_own1) return;   // globalToLocal + isInPartition (src/commonLib.cpp:289-291)
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    if (skip_nodata && is_nodata_s(P[idx], nodata)) return;
+    reach[idx] = 1;
+    tile_flags[(y / tilek::TS) * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+}
+
+template <int BYTES> struct BitsOf;
+template <> struct BitsOf<4> { using type = uint32_t; };
+template <> struct BitsOf<16> { using type = uint4; };
+
+// Runs the sweep to the global fixed point.  `flags` holds (1 + SCHED_LIST_WORDS) * ntiles words, `counts` 2 * COUNT_RING.
+// The work array must be initialised (pending pattern on participating owned cells) and its halo rows exchanged; cells still
+// pending on return (on or below a cycle, fed by the p == 0 quirk) are the caller's to finish.
+template <class Alg>
+static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32_t* flags, unsigned long long* counts, int64_t* rounds_out, int64_t* launches_out,
+               int64_t* outer_out) {
+    using Bits = typename BitsOf<sizeof(typename Alg::Cell)>::type;
+    hipStream_t s = ctx->stream;
+    const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
+    const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+    const tilek::Sched sched{flags, flags + ntiles, counts};
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
+    int rc;
+    for (;;) {
+        RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, geom, sched, ctx->h_mail, nullptr);
+        runner.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
+                                   unsigned pull_max) {
+            hipLaunchKernelGGL((sweep_kernel<Alg>), dim3(grid), dim3(NT), 0, ls, alg, geom, list, count, fcur, fnext, lnext, pull_max, A);
+        };
+        rc = runner.start();
+        if (rc != TDX_OK) return rc;
+        while (!runner.done) {
+            rc = runner.enqueue();
+            if (rc != TDX_OK) return rc;
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            runner.collect();
+        }
+        if (rounds_out) *rounds_out += runner.rounds;
+        if (launches_out) *launches_out += runner.launches;
+        if (!st.multi()) break;
+        // the neighbours' boundary rows (as bit patterns: a pending record must compare equal to itself): cells finished there
+        // release the owned cells they drain into (addBorders() + queue refill of src/aread8.cpp:282-303); tiles that see a changed
+        // halo cell run again
+        int64_t changed = 0;
+        Bits outside_bits;
+        const typename Alg::Cell oc = Alg::outside();
+        memcpy(&outside_bits, &oc, sizeof(Bits));
+        rc = strip_exchange<Bits>(ctx, st, reinterpret_cast<Bits*>(A.v), outside_bits, flags, geom.tiles_x, &changed, true);
+        if (rc != TDX_OK) return rc;
+        if (changed == 0) break;
+        if (outer_out) (*outer_out)++;
+    }
+    return TDX_OK;
+}
+
+}  // namespace d8sweep

@@ -9,14 +9,18 @@
 // contributor.  The 3x3 window of directions / mask flags of the next cell is prefetched with the decrement, and all
 // contributor values are requested before the first one is used (a hop is a chain of memory round trips).
 //
-// Not built yet: the outlets branch (src/gridnet.cpp:269-369) and row strips.
+// Default path: the tile dependency sweep of d8_sweep.hpp (LDS tiles on the round schedule; outlets through the upstream
+// closure of flats.hpp: reach_closure, src/gridnet.cpp:269-369; row strips).  The pull walk below is kept as an A/B hook
+// (TDX_GN_WALK=1: single raster, no outlets).
 // Deliberate restriction (same as oracle/taudem_oracle.c: orc_gridnet): a neighbour whose COLUMN lies outside the raster
 // is skipped; the reference reads it through linearpart::getData, which returns a stale temporary for an out-of-range x
 // (src/linearpart.h:501-512).  It only concerns ring cells, which carry nodata in every D8FlowDir output.
 #include "context.hpp"
+#include "d8_sweep.hpp"
 #include "device_common.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -171,14 +175,38 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int tdx_gridnet_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata, const double* dxc, const double* dyc,
-                               const int32_t* d_mask, int32_t thresh, float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats) {
-    if (!ctx || !d_p || !dxc || !dyc || !d_plen || !d_tlen || !d_gord || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet_dev: bad argument");
-    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
-        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells");
+namespace {
+// initial records on the owned rows (src/gridnet.cpp:176-178, 228-235; with outlets :271-283): plen pending on participating cells
+// (-1 elsewhere), tlen -1; gord 1 on cells that will be evaluated (non-nodata cells whose mask value passes / the outlets' upstream
+// closure), 0 on non-nodata cells outside the closure, -1 on nodata
+__global__ __launch_bounds__(256) void gn_init_kernel(const uint32_t* __restrict__ info, const int16_t* __restrict__ P, int16_t nodata, int use_outlets, size_t first,
+                                                      size_t n, float4* __restrict__ rec) {
+    const size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= first + n) return;
+    const unsigned inf = info[i];
+    const bool valid = !is_nodata_s(P[i], nodata);
+    int g;
+    if (use_outlets) g = (inf & d8sweep::INFO_PART) ? 1 : (valid ? 0 : -1);
+    else g = (valid && (inf & d8sweep::INFO_OWNMASK)) ? 1 : -1;
+    rec[i] = make_float4((inf & d8sweep::INFO_PART) ? __uint_as_float(d8sweep::PENDING_BITS) : -1.0f, -1.0f, __int_as_float(g), 0.f);
+}
+// records -> the three rasters; a cell that never became ready (cycle, p == 0 quirk) keeps plen -1 like the reference's never-queued cells
+__global__ __launch_bounds__(256) void gn_unpack_kernel(const float4* __restrict__ rec, size_t first, size_t n, float* __restrict__ plen, float* __restrict__ tlen,
+                                                        int16_t* __restrict__ gord) {
+    const size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= first + n) return;
+    const float4 r = rec[i];
+    plen[i] = d8sweep::pending(r.x) ? -1.0f : r.x;
+    tlen[i] = r.y;
+    gord[i] = int16_t(__float_as_int(r.z));
+}
+
+// One strip of gridnet() (src/gridnet.cpp:54-514).  dxc / dyc: cell sizes of the rows of the strip array.
+int gridnet_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_nodata, const double* dxc, const double* dyc, const int32_t* d_mask, int32_t thresh,
+                 const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int inx = int(nx), iny = int(ny);
+    const int inx = st.nx, iny = st.ny_arr;
     const size_t n = size_t(inx) * size_t(iny);
     if (!d_mask) thresh = 0;   // src/gridnet.cpp:155-159
     // dist[row][k] = sqrt((dx d1)^2 + (dy d2)^2) in double, stored as float (src/gridnet.cpp:196-209)
@@ -188,36 +216,135 @@ extern "C" int tdx_gridnet_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx,
     for (int m = 0; m < iny; m++)
         for (int k = 1; k <= 8; k++)
             dist[size_t(m) * 9 + size_t(k)] = (float)sqrt(dxc[m] * dxc[m] * hd1[k] * hd1[k] + dyc[m] * dyc[m] * hd2[k] * hd2[k]);
-    int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-    int32_t* gord32 = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
     float* d_dist = static_cast<float*>(ctx->scratch(TDX_S_J, dist.size() * sizeof(float)));
-    if (!cnt || !gord32 || !d_dist) return TDX_ERR_NOMEM;
+    if (!d_dist) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, dist.data(), dist.size() * sizeof(float), hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));   // `dist` is a local
-    ctx->begin_call(stats);
     const dim3 grid2d((inx + 63) / 64, (iny + 3) / 4);
+    const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);
+
+    if (getenv("TDX_GN_WALK") && !st.multi() && n_outlets < 0) {   // A/B hook: the atomic pull walk
+        int32_t* cnt = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
+        int32_t* gord32 = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+        if (!cnt || !gord32) return TDX_ERR_NOMEM;
+        ctx->begin_call(stats);
+        {
+            TdxSpan sp(ctx, TDX_K_STENCIL);
+            hipLaunchKernelGGL(gn_setup_kernel, grid2d, dim3(256), 0, s, d_p, inx, iny, p_nodata, d_mask, int(thresh), cnt, d_plen, d_tlen, gord32);
+            if (stats) stats->launches[TDX_K_STENCIL]++;
+        }
+        {
+            TdxSpan sp(ctx, TDX_K_ACCUM);
+            hipLaunchKernelGGL(gn_walk_kernel, grid2d, dim3(256), 0, s, d_p, d_mask, int(thresh), d_dist, inx, iny, p_nodata, cnt, d_plen, d_tlen, gord32);
+            if (stats) stats->launches[TDX_K_ACCUM]++;
+        }
+        {
+            TdxSpan sp(ctx, TDX_K_MISC);
+            hipLaunchKernelGGL(gn_narrow_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, gord32, n, d_gord);
+            if (stats) stats->launches[TDX_K_MISC]++;
+        }
+        TDX_HIP_CHECK(ctx, hipGetLastError());
+        ctx->end_call();
+        return TDX_OK;
+    }
+
+    const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+    const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+    uint32_t* info = static_cast<uint32_t*>(ctx->scratch(TDX_S_A, n * 4));
+    uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+    unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+    if (!info || !flags || !counts) return TDX_ERR_NOMEM;
+    ctx->begin_call(stats);
+    int rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);   // directions of the neighbours' boundary rows
+    if (rc != TDX_OK) return rc;
+    if (d_mask) {   // ... and their mask values (the value-contributor rule looks at the neighbour's mask)
+        rc = strip_exchange<int32_t>(ctx, st, const_cast<int32_t*>(d_mask), int32_t(thresh) - 1);
+        if (rc != TDX_OK) return rc;
+    }
+    int32_t* reach = nullptr;
+    if (n_outlets >= 0) {
+        // upstream closure of the outlets (src/gridnet.cpp:285-340: level by level, one MPI round per level; here one more fixed
+        // point of the tile engine, across strips)
+        TdxSpan sp(ctx, TDX_K_BFS);
+        reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
+        uint8_t* rmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
+        int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
+        if (!reach || !rmask || !d_oxy) return TDX_ERR_NOMEM;
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(reach, 0, n * 4, s));
+        TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+        hipLaunchKernelGGL(d8sweep::reach_mask_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, n, p_nodata, rmask);
+        if (n_outlets > 0) {
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(d8sweep::reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets), inx,
+                               st.y0, st.y1, geom.tiles_x, d_p, p_nodata, 1, reach, flags);
+        }
+        int64_t rr = 0, ll = 0;
+        rc = reach_closure(ctx, st, reach, rmask, flags, flags + ntiles, counts, &rr, &ll);
+        if (rc != TDX_OK) return rc;
+        if (stats) stats->launches[TDX_K_BFS] += ll;
+    }
+    float4* rec = static_cast<float4*>(ctx->scratch(TDX_S_C, n * 16));   // {plen, tlen, gord, -} per cell: one record, one store (d8_sweep.hpp)
+    if (!rec) return TDX_ERR_NOMEM;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(gn_setup_kernel, grid2d, dim3(256), 0, s, d_p, inx, iny, p_nodata, d_mask, int(thresh), cnt, d_plen, d_tlen, gord32);
-        if (stats) stats->launches[TDX_K_STENCIL]++;
+        hipLaunchKernelGGL(d8sweep::setup_kernel, grid2d, dim3(256), 0, s, d_p, inx, iny, p_nodata, 1, d_mask, int(thresh), reach, info);
+        hipLaunchKernelGGL(gn_init_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, info, d_p, p_nodata, n_outlets >= 0 ? 1 : 0, first, nown, rec);
+        if (stats) stats->launches[TDX_K_STENCIL] += 2;
     }
     {
+        const float4 oc = d8sweep::GridNetAlg::outside();
+        uint4 ob;
+        memcpy(&ob, &oc, sizeof(ob));
+        rc = strip_exchange<uint4>(ctx, st, reinterpret_cast<uint4*>(rec), ob);
+        if (rc != TDX_OK) return rc;
+    }
+    int64_t rounds = 0, launches = 0, outer = 1;
+    {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        hipLaunchKernelGGL(gn_walk_kernel, grid2d, dim3(256), 0, s, d_p, d_mask, int(thresh), d_dist, inx, iny, p_nodata, cnt, d_plen, d_tlen, gord32);
-        if (stats) stats->launches[TDX_K_ACCUM]++;
+        d8sweep::Arrays<d8sweep::GridNetAlg> A{rec, nullptr, d_dist, info};
+        rc = d8sweep::run(ctx, st, d8sweep::GridNetAlg{}, A, flags, counts, &rounds, &launches, &outer);
+        if (rc != TDX_OK) return rc;
+        if (stats) stats->launches[TDX_K_ACCUM] += launches;
     }
     {
         TdxSpan sp(ctx, TDX_K_MISC);
-        hipLaunchKernelGGL(gn_narrow_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, gord32, n, d_gord);
+        hipLaunchKernelGGL(gn_unpack_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, rec, first, nown, d_plen, d_tlen, d_gord);
         if (stats) stats->launches[TDX_K_MISC]++;
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
+    tdx_stats* stt = stats;
     ctx->end_call();
+    if (stt) { stt->rounds = outer; stt->cells_evaluated = rounds; }
     return TDX_OK;
+}
+}  // namespace
+
+extern "C" int tdx_gridnet_dev(tdx_context* ctx, const int16_t* d_p, int64_t nx, int64_t ny, int16_t p_nodata, const double* dxc, const double* dyc,
+                               const int32_t* d_mask, int32_t thresh, const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_plen,
+                               float* d_tlen, int16_t* d_gord, tdx_stats* stats) {
+    if (!ctx || !d_p || !dxc || !dyc || !d_plen || !d_tlen || !d_gord || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet_dev: bad argument");
+    if (nx > 0x7fffffff || ny > 0x7fffffff || uint64_t(nx) * uint64_t(ny) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells");
+    if (n_outlets > 0 && (!outlet_x || !outlet_y)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet_dev: outlets missing");
+    return gridnet_impl(ctx, strip_single(int(nx), int(ny)), const_cast<int16_t*>(d_p), p_nodata, dxc, dyc, d_mask, thresh, outlet_x, outlet_y, n_outlets, d_plen,
+                        d_tlen, d_gord, stats);
+}
+
+extern "C" int tdx_gridnet_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata, const double* dxc,
+                                 const double* dyc, int32_t* d_mask, int32_t thresh, const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
+                                 float* d_plen, float* d_tlen, int16_t* d_gord, tdx_stats* stats) {
+    if (!ctx || !d_p || !dxc || !dyc || !d_plen || !d_tlen || !d_gord || nx <= 0 || ny_local <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet_strip: bad argument");
+    if (nx > 0x7fffffff || ny_local > 0x7ffffff0 || uint64_t(nx) * uint64_t(ny_local + 2) > 0xffffffffull)
+        return tdx_fail(ctx, TDX_ERR_ARG, "raster larger than 2^32 cells per device strip");
+    if (n_outlets > 0 && (!outlet_x || !outlet_row)) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet_strip: outlets missing");
+    return gridnet_impl(ctx, strip_from_comm(comm, int(nx), int(ny_local)), d_p, p_nodata, dxc, dyc, d_mask, thresh, outlet_x, outlet_row, n_outlets, d_plen, d_tlen,
+                        d_gord, stats);
 }
 
 extern "C" int tdx_gridnet(tdx_context* ctx, const int16_t* p, int64_t nx, int64_t ny, int16_t p_nodata, const double* dxc, const double* dyc,
-                           const int32_t* mask, int32_t thresh, float* plen, float* tlen, int16_t* gord, tdx_stats* stats) {
+                           const int32_t* mask, int32_t thresh, const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* plen, float* tlen,
+                           int16_t* gord, tdx_stats* stats) {
     if (!ctx || !p || !plen || !tlen || !gord || nx <= 0 || ny <= 0) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_gridnet: bad argument");
     const size_t n = size_t(nx) * size_t(ny);
     int16_t* d_p = static_cast<int16_t*>(ctx->scratch(TDX_S_IO0, n * 2));
@@ -228,7 +355,7 @@ extern "C" int tdx_gridnet(tdx_context* ctx, const int16_t* p, int64_t nx, int64
     if (!d_p || !d_pl || !d_tl || !d_go || (mask && !d_m)) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_p, p, n * 2, hipMemcpyHostToDevice, ctx->stream));
     if (mask) TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_m, mask, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    const int rc = tdx_gridnet_dev(ctx, d_p, nx, ny, p_nodata, dxc, dyc, d_m, thresh, d_pl, d_tl, d_go, stats);
+    const int rc = tdx_gridnet_dev(ctx, d_p, nx, ny, p_nodata, dxc, dyc, d_m, thresh, outlet_x, outlet_y, n_outlets, d_pl, d_tl, d_go, stats);
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(plen, d_pl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(tlen, d_tl, n * 4, hipMemcpyDeviceToHost, ctx->stream));

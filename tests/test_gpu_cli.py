@@ -127,7 +127,10 @@ def test_reference_mains_on_the_shim(tmp_path):
     for name, key, dt in (("fel", "fel", np.float32), ("p", "p", np.int16), ("sd8", "sd8", np.float32), ("ad8", "ad8_nc", np.float32), ("slp", "slp", np.float32),
                           ("sca", "sca", np.float32)):
         a, _ = T.read_raster(f("dem" + name + ".tif"), dt)
-        assert bits_equal(a, g[key]), describe_diff(a, g[key], name)
+        if name == "sca":   # end to end from OUR angles: the stated gate (1e-6 relative)
+            assert (np.isclose(a, g[key], rtol=1e-6, atol=0) | (a == g[key])).all()
+        else:
+            assert bits_equal(a, g[key]), describe_diff(a, g[key], name)
 
 
 @pytest.mark.slow

@@ -129,3 +129,57 @@ def test_cli_gridnet_threshold(tmp_path, ctx):
     assert "Threshold version 5.4.0" in out
     a, _ = T.read_raster(f("src.tif"), np.int16)
     assert bits_equal(a, h["src"]), describe_diff(a, h["src"], "src")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_gridnet_outlets(name, ctx):
+    """gridnet -o (src/gridnet.cpp:269-369): only the outlets' upstream closure is evaluated, every other cell with a direction gets order 0."""
+    g, h = load_golden(name), load_golden_gridnet(name)
+    if "gord_o" not in h:
+        pytest.skip("no -o rasters in this golden file")
+    p = np.ascontiguousarray(g["p"])
+    plen, tlen, gord = ctx.gridnet(p, -32768, g["dxc"], g["dyc"], outlets=outlets_to_indices(g))
+    assert bits_equal(gord, h["gord_o"]), describe_diff(gord, h["gord_o"], "gord -o")
+    assert bits_equal(plen, h["plen_o"]), describe_diff(plen, h["plen_o"], "plen -o")
+    assert bits_equal(tlen, h["tlen_o"]), describe_diff(tlen, h["tlen_o"], "tlen -o")
+
+
+def test_gridnet_outlets_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(8)
+    dem = oracle.synth_dem((700, 900), 17)
+    dem[300:330, 100:180] = -9999.0
+    p, _, _ = oracle.d8flowdir(oracle.pitremove(dem, -9999.0), -3.0e38, 30.0, 30.0)
+    ox = rng.integers(1, 899, size=12).astype(np.int32); oy = rng.integers(1, 699, size=12).astype(np.int32)
+    ox[0], oy[0] = 120, 310          # an outlet on a nodata cell: ignored
+    mask = (rng.random(p.shape) * 10).astype(np.int32)
+    for m, t in ((None, 0), (mask, 2)):
+        o = oracle.gridnet(p, -32768, 30.0, 30.0, mask=m, thresh=t, outlets=(ox, oy))
+        a = ctx.gridnet(p, -32768, 30.0, 30.0, mask=m, thresh=t, outlets=(ox, oy))
+        for x, y, nm in zip(a, o, ("plen", "tlen", "gord")):
+            assert bits_equal(x, y), describe_diff(x, y, f"{nm} -o mask={m is not None}")
+
+
+def test_sweep_and_walk_agree(ctx, oracle, monkeypatch):
+    """Two independent schedules of the same dependency sweeps (LDS tiles on the round schedule vs the atomic pull walk): GridNet,
+    weighted AreaD8 and D8FlowPathExtremeUp give the same bits; unweighted AreaD8 agrees across tile contraction, sweep and walk."""
+    rng = np.random.default_rng(2)
+    dem = oracle.synth_dem((1500, 1300), 5)
+    p, _, _ = oracle.d8flowdir(oracle.pitremove(dem, -9999.0), -3.0e38, 30.0, 30.0)
+    w = (rng.random(p.shape, dtype=np.float32) * 1.0e3).astype(np.float32)
+    res = {}
+    for mode in ("sweep", "walk"):
+        if mode == "walk":
+            monkeypatch.setenv("TDX_GN_WALK", "1"); monkeypatch.setenv("TDX_AD8_WALK", "1")
+        res[mode] = (ctx.gridnet(p, -32768, 30.0, 30.0), ctx.aread8(p, -32768, weights=w, contcheck=False), ctx.d8flowpathextremeup(p, w, -32768, usemax=False),
+                     ctx.aread8(p, -32768))
+    monkeypatch.delenv("TDX_GN_WALK"); monkeypatch.delenv("TDX_AD8_WALK")
+    gn_o = oracle.gridnet(p, -32768, 30.0, 30.0)
+    for a, b, o, nm in zip(res["sweep"][0], res["walk"][0], gn_o, ("plen", "tlen", "gord")):
+        assert bits_equal(a, o), describe_diff(a, o, f"gridnet sweep vs oracle: {nm}")
+        assert bits_equal(b, o), describe_diff(b, o, f"gridnet walk vs oracle: {nm}")
+    for i in (1, 2, 3):
+        assert bits_equal(res["sweep"][i], res["walk"][i])
+    monkeypatch.setenv("TDX_AD8_SWEEP", "1")
+    assert bits_equal(ctx.aread8(p, -32768), res["walk"][3]), "unweighted AreaD8: sweep vs walk"
+    monkeypatch.delenv("TDX_AD8_SWEEP")
+    assert bits_equal(res["walk"][1], oracle.aread8(p, -32768, weights=w, contcheck=False))

@@ -109,6 +109,17 @@ def test_cli_gpus_n_matches_reference_outputs(tmp_path, case, ngpus):
     run("dinfflowdir", *N, "-fel", f("fel.tif"), "-ang", f("ang.tif"), "-slp", f("slp.tif"))
     run("areadinf", *N, "-ang", f("ang.tif"), "-sca", f("sca.tif"))
     run("dinfdecayaccum", *N, "-ang", f("ang.tif"), "-dm", f("dm.tif"), "-dsca", f("dsca.tif"))
+    from conftest import load_golden_gridnet
+    h = load_golden_gridnet(case)
+    T.write_raster(f("gmask.tif"), np.ascontiguousarray(h["mask_i32"]), -1, geotransform=gt)
+    run("gridnet", "-p", f("p.tif"), "-plen", f("plen.tif"), "-tlen", f("tlen.tif"), "-gord", f("gord.tif"), *N)
+    run("gridnet", *N, "-p", f("p.tif"), "-plen", f("plenm.tif"), "-tlen", f("tlenm.tif"), "-gord", f("gordm.tif"), "-mask", f("gmask.tif"), "-thresh", str(int(h["gn_thresh"])))
+    run("gridnet", *N, "-p", f("p.tif"), "-plen", f("pleno.tif"), "-tlen", f("tleno.tif"), "-gord", f("gordo.tif"), "-o", f("outlets.txt"))
+    for name, key, dt in (("plen", "plen", np.float32), ("tlen", "tlen", np.float32), ("gord", "gord", np.int16), ("plenm", "plen_m", np.float32),
+                          ("tlenm", "tlen_m", np.float32), ("gordm", "gord_m", np.int16), ("pleno", "plen_o", np.float32), ("tleno", "tlen_o", np.float32),
+                          ("gordo", "gord_o", np.int16)):
+        a, _ = T.read_raster(f(name + ".tif"), dt)
+        assert bits_equal(a, h[key]), describe_diff(a, h[key], f"gridnet {name} --gpus {ngpus}")
     for name, key, dt in (("fel", "fel", np.float32), ("p", "p", np.int16), ("sd8", "sd8", np.float32), ("ad8", "ad8", np.float32), ("ad8w", "ad8_w", np.float32),
                           ("ad8o", "ad8_outlets", np.float32), ("ang", "ang", np.float32), ("slp", "slp", np.float32), ("sca", "sca", np.float32),
                           ("dsca", "dsca", np.float32)):

@@ -105,4 +105,4 @@ def test_new_tools_report_missing_files(tmp_path):
     assert tools.gridnet(nope, nope, nope, nope) == _lib.TDX_ERR_FILE
     assert tools.threshold(nope, nope) == _lib.TDX_ERR_FILE
     assert tools.d8flowpathextremeup(nope, nope, nope) == _lib.TDX_ERR_FILE
-    assert tools.gridnet(nope, nope, nope, nope, useOutlets=1) == _lib.TDX_ERR_ARG   # the -o branch of GridNet is not built yet
+    assert tools.gridnet(nope, nope, nope, nope, useOutlets=1) == _lib.TDX_ERR_FILE
