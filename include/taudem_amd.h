@@ -186,6 +186,22 @@ int tdx_dinfdecayaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t n
                        float* dsca, tdx_stats* stats);
 
 
+/* ---- D-infinity flow algebra in reverse --------------------------------------------------------- */
+/* depgrd() src/DinfUpDependence.cpp:52-272: dep = fraction of the flow of each cell that reaches the cells with dg >= 1 (the
+ * "disturbance" grid, int32); float, nodata -1.  dxc / dyc: per-row cell sizes (HOST). */
+int tdx_dinfupdependence_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                             const double* dxc, const double* dyc, const int32_t* d_dg, float* d_dep, tdx_stats* stats);
+int tdx_dinfupdependence(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                         const double* dxc, const double* dyc, const int32_t* dg, float* dep, tdx_stats* stats);
+/* dsaccum() src/DinfRevAccum.cpp:51-290: racc = weight accumulated over everything DOWNSTREAM of a cell (proportioned like the
+ * flow), dmax = the maximum weight downstream; both float, nodata -FLT_MAX. */
+int tdx_dinfrevaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                         const double* dxc, const double* dyc, const float* d_w, float w_nodata,
+                         float* d_racc, float* d_dmax, tdx_stats* stats);
+int tdx_dinfrevaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                     const double* dxc, const double* dyc, const float* w, float w_nodata,
+                     float* racc, float* dmax, tdx_stats* stats);
+
 /* ---- row strips across GPUs (replaces linearpart<T>, src/linearpart.h:55-565) ---------------------- */
 /* One process per GPU holds one horizontal strip of the raster plus ONE halo row above and below it,
  * exactly like linearpart (rows r*(Y/P) .. , remainder to the last rank, src/linearpart.h:133-134; halo =
@@ -275,6 +291,11 @@ int tdx_d8flowpathextremeup_strip(tdx_context* ctx, const tdx_comm* comm, int16_
                                   int16_t p_nodata, const float* d_sa, int usemax, int contcheck,
                                   const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
                                   float* d_ssa, tdx_stats* stats);
+/* the reverse D-infinity tools on strips (dxc / dyc: per-row cell sizes of the ny_local + 2 strip rows) */
+int tdx_dinfupdependence_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                               const double* dxc, const double* dyc, int32_t* d_dg, float* d_dep, tdx_stats* stats);
+int tdx_dinfrevaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                           const double* dxc, const double* dyc, float* d_w, float w_nodata, float* d_racc, float* d_dmax, tdx_stats* stats);
 /* GridNet on a strip (d_mask: optional int32 strip array whose halo rows the library fills) */
 int tdx_gridnet_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                       const double* dxc, const double* dyc, int32_t* d_mask, int32_t thresh,
@@ -345,6 +366,10 @@ int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfi
 /* int d8flowpathextremeup(char*,char*,char*,int,char*,char*,int,int,int,int)   src/D8flowpathextremeup.cpp:58 */
 int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const char* ssafile, int usemax, const char* datasrc,
                                  const char* lyrname, int uselyrname, int lyrno, int useOutlets, int contcheck);
+/* int depgrd(char* angfile, char* dgfile, char* depfile)           src/DinfUpDependence.cpp:52 */
+int tdx_tool_dinfupdependence(const char* angfile, const char* dgfile, const char* depfile);
+/* int dsaccum(char* angfile, char* wgfile, char* raccfile, char* dmaxfile)   src/DinfRevAccum.cpp:51 */
+int tdx_tool_dinfrevaccum(const char* angfile, const char* wgfile, const char* raccfile, const char* dmaxfile);
 /* int threshold(char*,char*,char*,float,int)                       src/Threshold.cpp:49 */
 int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask);
 /* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */

@@ -180,6 +180,29 @@ def dinfdecayaccum(ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, d
     return out
 
 
+def dinfupdependence(ang, dg, nodata=-3.402823466e38, dx=1.0, dy=1.0):
+    """dep of src/DinfUpDependence.cpp (nodata -1)."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    dg = np.ascontiguousarray(dg, dtype=np.int32)
+    ny, nx = ang.shape
+    dep = np.empty((ny, nx), dtype=np.float32)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinfupdependence(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(dg), _p(dep))
+    return dep
+
+
+def dinfrevaccum(ang, w, nodata=-3.402823466e38, w_nodata=-9999.0, dx=1.0, dy=1.0):
+    """(racc, dmax) of src/DinfRevAccum.cpp (nodata -FLT_MAX)."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    ny, nx = ang.shape
+    racc = np.empty((ny, nx), dtype=np.float32)
+    dmax = np.empty((ny, nx), dtype=np.float32)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinfrevaccum(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(w), C.c_float(w_nodata), _p(racc), _p(dmax))
+    return racc, dmax
+
+
 def prop(a, k, dx, dy):
     return lib().orc_prop(C.c_float(a), C.c_int(k), C.c_double(dx), C.c_double(dy))
 

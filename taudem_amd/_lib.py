@@ -137,6 +137,14 @@ _SIGNATURES = {
     "tdx_dinfflowdir_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
     "tdx_areadinf_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, C.c_int, _P, _P, _I64, _P, _P]),
     "tdx_dinfdecayaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfupdependence_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_dinfupdependence": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_dinfupdependence_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tdx_dinfrevaccum_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _P]),
+    "tdx_dinfrevaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _P]),
+    "tdx_dinfrevaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _P]),
+    "tdx_tool_dinfupdependence": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p]),
+    "tdx_tool_dinfrevaccum": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "tdx_synth_dem_dev": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _I64, _I64, _P]),
     "tdx_raster_info_read": (C.c_int, [C.c_char_p, C.POINTER(TdxRasterInfo)]),
     "tdx_raster_read": (C.c_int, [C.c_char_p, C.c_int, _P, _P, _P]),

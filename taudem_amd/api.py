@@ -86,7 +86,7 @@ class Context:
         if _is_torch(like):
             import torch
 
-            td = {np.float32: torch.float32, np.int16: torch.int16}[dtype]
+            td = {np.float32: torch.float32, np.int16: torch.int16, np.int32: torch.int32}[dtype]
             return torch.empty(shape, dtype=td, device=like.device)
         return np.empty(shape, dtype=dtype)
 
@@ -267,6 +267,40 @@ class Context:
                                                      pd, float(dm_nodata), pw, int(bool(contcheck)), ox, oy, no, ps, C.byref(st)), self._h)
         del keep
         return (dsca, st.as_dict()) if stats else dsca
+
+    def dinfupdependence(self, ang, dg, nodata=float(ANG_NODATA), dx=1.0, dy=1.0, stats=False):
+        """dep = depgrd(ang, dg)  (src/DinfUpDependence.cpp:52): dg int32, dep float32 (nodata -1)."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        dep = self._out(ang, np.float32, (ny, nx))
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        pg, gdev = self._ptr(dg, np.int32, (ny, nx), "dg")
+        po, _ = self._ptr(dep, np.float32, (ny, nx), "dep")
+        if gdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(ang, dg)
+        check(self._pick(dev, "tdx_dinfupdependence")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pg, po,
+                                                       C.byref(st)), self._h)
+        return (dep, st.as_dict()) if stats else dep
+
+    def dinfrevaccum(self, ang, w, nodata=float(ANG_NODATA), w_nodata=-9999.0, dx=1.0, dy=1.0, stats=False):
+        """racc, dmax = dsaccum(ang, w)  (src/DinfRevAccum.cpp:51): float32, nodata -FLT_MAX."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        racc = self._out(ang, np.float32, (ny, nx))
+        dmax = self._out(ang, np.float32, (ny, nx))
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        pw, wdev = self._ptr(w, np.float32, (ny, nx), "w")
+        pr, _ = self._ptr(racc, np.float32, (ny, nx), "racc")
+        pm, _ = self._ptr(dmax, np.float32, (ny, nx), "dmax")
+        if wdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        st = TdxStats()
+        self._sync_torch(ang, w)
+        check(self._pick(dev, "tdx_dinfrevaccum")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pw,
+                                                   float(w_nodata), pr, pm, C.byref(st)), self._h)
+        return (racc, dmax, st.as_dict()) if stats else (racc, dmax)
 
     def synth_dem(self, n_or_shape, seed=1234, x0=0, y0=0, base_wavelength=None, out=None):
         """Seeded fractal DEM generated on the device (torch tensor on cuda:<device>)."""

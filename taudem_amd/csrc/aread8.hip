@@ -1010,7 +1010,7 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
         {
             TdxSpan sp(ctx, TDX_K_ACCUM);
             d8sweep::SumMaxMin alg{ex.mode, ex.out_nodata, w_nodata, contcheck, d_w != nullptr};
-            d8sweep::Arrays<d8sweep::SumMaxMin> A{d_ad8, d_w, nullptr, info};
+            d8sweep::Arrays<d8sweep::SumMaxMin> A{d_ad8, d_w, nullptr, nullptr, info};
             rc = d8sweep::run(ctx, st, alg, A, flags, counts, &rounds, &launches, &outer);
             if (rc != TDX_OK) return rc;
             const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);

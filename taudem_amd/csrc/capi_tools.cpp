@@ -292,6 +292,94 @@ int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* mas
     return 0;
 }
 
+int tdx_tool_dinfupdependence(const char* angfile, const char* dgfile, const char* depfile) {
+    printf("DinfUpDependence version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster ang, dg;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    rc = load_raster(dgfile, tdx::DType::I32, dg);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, dg.info, dgfile)) return TDX_ERR_MISMATCH;   // src/DinfUpDependence.cpp:103
+    const double readt = now_s();
+    std::vector<float> dep(ang.f.size());
+    tdx_stats st;
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            int32_t* d_dg = j.strip<int32_t>(dg.l.data());
+            float* d_dep = j.strip<float>(nullptr);
+            if (!d_ang || !d_dg || !d_dep) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const int e = tdx_dinfupdependence_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_dg, d_dep, s);
+            return e != TDX_OK ? e : (j.fetch(dep.data(), d_dep) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinfupdependence(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(), dg.l.data(), dep.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
+    const double computet = now_s();
+    rc = save_raster(depfile, tdx::DType::F32, dep.data(), ang.info, -1.0);   // depNodata = -1 (src/DinfUpDependence.cpp:113)
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt, writet - computet,
+           writet - begint);
+    print_gpu_stats("dinfupdependence", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
+int tdx_tool_dinfrevaccum(const char* angfile, const char* wgfile, const char* raccfile, const char* dmaxfile) {
+    printf("DinfRevAccum version %s\n", TDVERSION);
+    fflush(stdout);
+    const double begint = now_s();
+    Raster ang, w;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    rc = load_raster(wgfile, tdx::DType::F32, w);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, w.info, wgfile)) { printf("File sizes do not match\n%s\n", wgfile); fflush(stdout); return TDX_ERR_OUTLETS; }   // src/DinfRevAccum.cpp:94-99
+    const double readt = now_s();
+    const size_t n = ang.f.size();
+    std::vector<float> racc(n), dmax(n);
+    tdx_stats st;
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            float* d_w = j.strip<float>(w.f.data());
+            float* d_r = j.strip<float>(nullptr);
+            float* d_m = j.strip<float>(nullptr);
+            if (!d_ang || !d_w || !d_r || !d_m) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const int e = tdx_dinfrevaccum_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_w, (float)w.info.nodata, d_r, d_m, s);
+            if (e != TDX_OK) return e;
+            return (j.fetch(racc.data(), d_r) && j.fetch(dmax.data(), d_m)) ? TDX_OK : TDX_ERR_HIP;
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinfrevaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(), w.f.data(),
+                              (float)w.info.nodata, racc.data(), dmax.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
+    const double computet = now_s();
+    rc = save_raster(raccfile, tdx::DType::F32, racc.data(), ang.info, (double)TDX_ANG_NODATA);   // MISSINGFLOAT (src/DinfRevAccum.cpp:253-258)
+    if (rc != TDX_OK) return rc;
+    rc = save_raster(dmaxfile, tdx::DType::F32, dmax.data(), ang.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt, writet - computet,
+           writet - begint);
+    print_gpu_stats("dinfrevaccum", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
 int tdx_tool_set_device(int device) { g_tool_device = device; return TDX_OK; }
 int tdx_tool_set_gpus(int ngpus) { g_tool_gpus = ngpus; return TDX_OK; }
 

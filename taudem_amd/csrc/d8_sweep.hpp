@@ -92,8 +92,12 @@ __device__ __forceinline__ int rim_bit(int nx2, int ny2) {
 // that is why GridNet's three results travel as one 16-byte record and are split into the three rasters afterwards.
 struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8Expr)
     using Cell = float;
-    static constexpr bool HAS_AUX = true;       // weight grid / the grid whose extreme is sought (may be absent for unit weights)
+    using Aux = float;                          // weight grid / the grid whose extreme is sought (may be absent for unit weights)
+    static constexpr bool HAS_AUX = true;
     static constexpr bool HAS_DIST = false;
+    static constexpr bool HAS_ROWS = false;
+    // cells whose pending count includes this one: the cell it drains to
+    static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     int mode;            // 0 sum, 1 max, 2 min
     float out_nodata;
     float w_nodata;
@@ -125,8 +129,11 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
 
 struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (int bits), -}
     using Cell = float4;
+    using Aux = float;
     static constexpr bool HAS_AUX = false;
     static constexpr bool HAS_DIST = true;
+    static constexpr bool HAS_ROWS = false;
+    static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
     static __host__ __device__ __forceinline__ float4 outside() { const int m1 = -1; float z; memcpy(&z, &m1, 4); return make_float4(-1.0f, -1.0f, z, 0.f); }
     template <class L>
@@ -150,21 +157,27 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     }
 };
 
+constexpr int QCAP = 512;
 template <class Alg>
 struct Lds {
     typename Alg::Cell v[LH * LH];
-    float aux[Alg::HAS_AUX ? TS * TS : 1];
+    typename Alg::Aux aux[Alg::HAS_AUX ? TS * TS : 1];
     float dist[Alg::HAS_DIST ? TS * 9 : 1];
+    double rows[Alg::HAS_ROWS ? TS : 1];   // per-row value of the tile's rows (D-infinity: a2 = atan2(dy, dx))
     uint32_t info[TS * TS];
     uint32_t cnt[TS * TS / 4];   // one byte per cell: contributors still pending (255: not a pending cell of this rank)
+    uint16_t q[2][QCAP];         // ready cells handed on to the next phase (a finished cell may release several)
+    unsigned nq[2];
     int rim;
+    int over;                    // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
 };
 
 template <class Alg>
 struct Arrays {   // global arrays of one sweep
     typename Alg::Cell* v;                  // the work array (AreaD8 family: the result raster itself)
-    const float* aux;                       // weights / input grid (may be null)
+    const typename Alg::Aux* aux;           // per-cell input record (weights, angle ...; may be null)
     const float* dist;                      // GridNet: [row][9]
+    const double* rows;                     // per array row (may be null)
     const uint32_t* info;
 };
 
@@ -174,12 +187,12 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
-    if (tid == 0) S.rim = 0;
+    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
     // ---- stage: every load is issued before the first LDS store (addresses clamped, validity applied afterwards)
     {
         Cell s0[NSTAGE];
         uint32_t si[RPL];
-        float sa[Alg::HAS_AUX ? RPL : 1];
+        typename Alg::Aux sa[Alg::HAS_AUX ? RPL : 1];
         unsigned ok = 0;
 #pragma unroll
         for (int i = 0; i < NSTAGE; i++) {
@@ -197,8 +210,10 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             if (gx < g.nx && gy < g.ny) oki |= 1u << r;
             const size_t idx = size_t(gy >= g.ny ? g.ny - 1 : gy) * size_t(g.nx) + size_t(gx >= g.nx ? g.nx - 1 : gx);
             si[r] = A.info[idx];
-            if (Alg::HAS_AUX) sa[r] = A.aux ? A.aux[idx] : 0.f;
+            if (Alg::HAS_AUX) { if (A.aux) sa[r] = A.aux[idx]; else sa[r] = typename Alg::Aux{}; }
         }
+        double srow = 0.;
+        if (Alg::HAS_ROWS && tid < TS) srow = A.rows[y0 + tid >= g.ny ? g.ny - 1 : y0 + tid];
         float sdist = 0.f;
         if (Alg::HAS_DIST && tid < TS * 9) { const int gy = y0 + tid / 9; sdist = A.dist[size_t(gy >= g.ny ? g.ny - 1 : gy) * 9 + size_t(tid % 9)]; }
 #pragma unroll
@@ -212,6 +227,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             if (Alg::HAS_AUX) S.aux[(ry0 + r) * TS + lx] = sa[r];
         }
         if (Alg::HAS_DIST && tid < TS * 9) S.dist[tid] = sdist;
+        if (Alg::HAS_ROWS && tid < TS) S.rows[tid] = srow;
     }
     __syncthreads();
     unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet) and can become ready
@@ -223,10 +239,10 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     }
     const unsigned pend0 = pendmask;
     int rim = 0;
-    auto out_of_tile = [&](unsigned inf, int cx, int ly) {   // the tile a finished cell drains into has to look again
-        const int code = int((inf >> 9) & 15u);
-        if (code >= 1 && code <= 8) {
-            const int nx2 = cx + d1(code), ny2 = ly + d2(code);
+    auto out_of_tile = [&](unsigned inf, int cx, int ly) {   // the tiles a finished cell releases cells in have to look again
+        for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
+            const int k = __ffs(int(m));
+            const int nx2 = cx + d1(k), ny2 = ly + d2(k);
             if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rim |= rim_bit(nx2, ny2);
         }
     };
@@ -279,27 +295,45 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         cnt8[c] = uint8_t(cn);
     }
     __syncthreads();
-    // ---- walks: a lane follows the flow path downstream as long as it finishes the last pending contributor of the next cell
-    for (unsigned m = readymask; m; m &= m - 1u) {
-        int c = (ry0 + (__ffs(int(m)) - 1)) * TS + lx;
+    // ---- walks: a lane follows a chain as long as it finishes the last pending contributor of a released cell; further cells
+    // released by the same step go to the hand-over queue, which the workgroup drains in phases
+    auto walk = [&](int c, int phase) {
         unsigned inf = S.info[c];
         for (;;) {
             const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
             Cell nb[9];
             load_nbrs(cl, nb);
             alg.eval(S, c, cl, ly, inf, nb);
-            const int code = int((inf >> 9) & 15u);
-            if (code < 1 || code > 8) break;
-            const int nx2 = cx + d1(code), ny2 = ly + d2(code);
-            if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit(nx2, ny2); break; }
-            const int tc = ny2 * TS + nx2, sh = 8 * (tc & 3);
-            const unsigned old = __hip_atomic_fetch_sub(&S.cnt[tc >> 2], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned tinf = S.info[tc];
-            if (((old >> sh) & 255u) != 1u) break;   // somebody else finishes its last contributor
-            c = tc; inf = tinf;
+            int next = -1;
+            unsigned ninf = 0;
+            for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
+                const int k = __ffs(int(m));
+                const int nx2 = cx + d1(k), ny2 = ly + d2(k);
+                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit(nx2, ny2); continue; }
+                const int tc = ny2 * TS + nx2, sh = 8 * (tc & 3);
+                const unsigned old = __hip_atomic_fetch_sub(&S.cnt[tc >> 2], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned tinf = S.info[tc];
+                if (((old >> sh) & 255u) != 1u) continue;   // somebody else finishes its last contributor
+                if (next < 0) { next = tc; ninf = tinf; }
+                else {
+                    const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
+                    if (slot < unsigned(QCAP)) S.q[phase ^ 1][slot] = uint16_t(tc);
+                    else S.over = 1;
+                }
+            }
+            if (next < 0) break;
+            c = next; inf = ninf;
         }
+    };
+    for (unsigned m = readymask; m; m &= m - 1u) walk((ry0 + (__ffs(int(m)) - 1)) * TS + lx, 0);
+    for (int phase = 1;; phase ^= 1) {
+        __syncthreads();                        // every push into q[phase] has landed
+        const unsigned n = S.nq[phase] < unsigned(QCAP) ? S.nq[phase] : unsigned(QCAP);
+        if (n == 0u) break;
+        for (unsigned i = tid; i < n; i += unsigned(NT)) walk(int(S.q[phase][i]), phase);
+        __syncthreads();                        // q[phase] has been read by everybody
+        if (tid == 0) S.nq[phase] = 0u;         // (nobody pushes into it before the next barrier)
     }
-    __syncthreads();
     // ---- write back what this activation evaluated (one store per record)
     bool wrote = false;
     for (unsigned m = pend0; m; m &= m - 1u) {
@@ -309,7 +343,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     }
     if (rim) atomicOr(&S.rim, rim);
     const int any = __syncthreads_or(wrote ? 1 : 0);
-    const int res = any ? (tilek::RES_CHANGED | S.rim) : 0;
+    const int res = (any ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
     __syncthreads();   // S is reused by the next tile
     return res;
 }
@@ -366,6 +400,7 @@ static __global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* _
 
 template <int BYTES> struct BitsOf;
 template <> struct BitsOf<4> { using type = uint32_t; };
+template <> struct BitsOf<8> { using type = uint2; };
 template <> struct BitsOf<16> { using type = uint4; };
 
 // Runs the sweep to the global fixed point.  `flags` holds (1 + SCHED_LIST_WORDS) * ntiles words, `counts` 2 * COUNT_RING.

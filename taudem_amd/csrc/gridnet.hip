@@ -302,7 +302,7 @@ int gridnet_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_noda
     int64_t rounds = 0, launches = 0, outer = 1;
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
-        d8sweep::Arrays<d8sweep::GridNetAlg> A{rec, nullptr, d_dist, info};
+        d8sweep::Arrays<d8sweep::GridNetAlg> A{rec, nullptr, d_dist, nullptr, info};
         rc = d8sweep::run(ctx, st, d8sweep::GridNetAlg{}, A, flags, counts, &rounds, &launches, &outer);
         if (rc != TDX_OK) return rc;
         if (stats) stats->launches[TDX_K_ACCUM] += launches;

@@ -4,7 +4,8 @@
 // src/areadinfmn.cpp, src/DinfDecayAccummn.cpp, src/gridnetmn.cpp, src/Thresholdmn.cpp, src/D8FlowPathExtremeUpmn.cpp) against
 // this file and -ltaudem_amd instead of flood.cpp / d8.cpp / aread8.cpp / ... + commonLib.cpp + tiffIO.cpp: every tool function the
 // mains call (prototypes: src/flood.h:1-2, src/d8.h:5, src/aread8.h:3, src/tardemlib.h:70, src/areadinf.h:2,
-// src/dinfdecayaccum.cpp:61-62, src/gridnet.cpp:54-55, src/Threshold.cpp:49, src/D8flowpathextremeup.cpp:58) forwards to the
+// src/dinfdecayaccum.cpp:61-62, src/gridnet.cpp:54-55, src/Threshold.cpp:49, src/D8flowpathextremeup.cpp:58,
+// src/DinfUpDependence.cpp:52, src/DinfRevAccum.cpp:51) forwards to the
 // file-level C ABI, and nameadd() (src/commonLib.cpp:53-73, the only other symbol the mains use) is provided here.  No MPI and
 // no GDAL at link time (their headers are only needed to COMPILE the mains, which include commonLib.h).
 // oracle/Makefile builds oracle/_ref/shim_<tool> this way; tests/test_gpu_cli.py runs them against the reference's rasters.
@@ -28,6 +29,10 @@ int gridnet(char* pfile, char* plenfile, char* tlenfile, char* gordfile, char* m
 { return tdx_tool_gridnet(pfile, plenfile, tlenfile, gordfile, maskfile, datasrc, lyrname, uselyrname, lyrno, useMask, useOutlets, thresh); }
 int d8flowpathextremeup(char* pfile, char* safile, char* ssafile, int usemax, char* datasrc, char* lyrname, int uselyrname, int lyrno, int useOutlets, int contcheck)
 { return tdx_tool_d8flowpathextremeup(pfile, safile, ssafile, usemax, datasrc, lyrname, uselyrname, lyrno, useOutlets, contcheck); }
+int depgrd(char* angfile, char* dgfile, char* depfile)
+{ return tdx_tool_dinfupdependence(angfile, dgfile, depfile); }
+int dsaccum(char* angfile, char* wgfile, char* raccfile, char* dmaxfile)
+{ return tdx_tool_dinfrevaccum(angfile, wgfile, raccfile, dmaxfile); }
 int threshold(char* ssafile, char* srcfile, char* maskfile, float thresh, int usemask)
 { return tdx_tool_threshold(ssafile, srcfile, maskfile, thresh, usemask); }
 

@@ -68,3 +68,13 @@ def nameadd(arg: str, suff: str) -> str:
         return arg + suff
     ext = arg[dot:]
     return arg[:dot] + suff + ("" if "." in suff else ext)
+
+
+def depgrd(angfile, dgfile, depfile):
+    """src/DinfUpDependence.cpp:52"""
+    return _lib.load().tdx_tool_dinfupdependence(_b(angfile), _b(dgfile), _b(depfile))
+
+
+def dsaccum(angfile, wgfile, raccfile, dmaxfile):
+    """src/DinfRevAccum.cpp:51"""
+    return _lib.load().tdx_tool_dinfrevaccum(_b(angfile), _b(wgfile), _b(raccfile), _b(dmaxfile))

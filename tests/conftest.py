@@ -18,12 +18,18 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(n for n in (os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "case_*.npz"))) if not n.endswith("_gridnet"))
+    return sorted(n for n in (os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "case_*.npz"))) if not n.endswith("_gridnet") and not n.endswith("_flowalg"))
 
 
 def load_golden_gridnet(name):
     """GridNet / Threshold rasters of the reference for the D8 rasters of case `name` (tests/golden/make_golden_gridnet.py)."""
     g = np.load(os.path.join(GOLDEN_DIR, f"case_{name}_gridnet.npz"), allow_pickle=False)
+    return {k: g[k] for k in g.files}
+
+
+def load_golden_flowalg(name):
+    """DinfUpDependence / DinfRevAccum rasters of the reference for the angles of case `name` (tests/golden/make_golden_flowalg.py)."""
+    g = np.load(os.path.join(GOLDEN_DIR, f"case_{name}_flowalg.npz"), allow_pickle=False)
     return {k: g[k] for k in g.files}
 
 
