@@ -184,7 +184,7 @@ __device__ __forceinline__ void ad8_walk_from(size_t idx, const int16_t* __restr
         if (xn < 0 || xn >= nx || yn < y_own0 || yn >= y_own1) return;   // off the raster, or a neighbour rank's row (released there)
         const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
         drain_stores();                 // value must be at the coherence point before the counter moves
-        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         D8Window wn;                    // the next hop's window travels with the atomic, not after it
         ad8_load_window(P, nx, ny, xn, yn, n, wn);
         if (old != 1) return;           // somebody else is the last contributor
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict
                 if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
                     const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
                     drain_stores();
-                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                     if (old == 1) ad8_walk_from(n, P, Wt, w_nodata, nx, ny, y_own0, y_own1, nodata, contcheck, cnt, A, ex);
                 }
             }

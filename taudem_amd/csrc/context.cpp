@@ -78,6 +78,8 @@ void tdx_context::end_call() {
 
 extern "C" {
 
+void tdx_context_destroy(tdx_context* c);
+
 const char* tdx_version(void) { return "taudem_amd 0.1.0 (TauDEM 5.4.0 hot path, gfx950)"; }
 
 int tdx_context_set_option(tdx_context* c, const char* name, int64_t value) {
@@ -92,6 +94,19 @@ int tdx_device_count(void) {
     return n;
 }
 
+static int context_init(tdx_context* c, int device) {
+    c->device = device;
+    TDX_HIP_CHECK(c, hipSetDevice(device));
+    TDX_HIP_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 256 * sizeof(uint64_t), hipHostMallocDefault));
+    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 256 * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 256 * sizeof(uint64_t)));
+    c->slots.resize(size_t(TDX_S_COUNT));
+    return TDX_OK;
+}
+
 int tdx_context_create(int device, tdx_context** out) {
     if (!out) return TDX_ERR_ARG;
     *out = nullptr;
@@ -102,15 +117,13 @@ int tdx_context_create(int device, tdx_context** out) {
     }
     if (device < 0 || device >= n) { g_tdx_thread_error = "bad device index"; return TDX_ERR_ARG; }
     tdx_context* c = new tdx_context;
-    c->device = device;
-    TDX_HIP_CHECK(c, hipSetDevice(device));
-    TDX_HIP_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 256 * sizeof(uint64_t), hipHostMallocDefault));
-    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 256 * sizeof(uint64_t)));
-    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 256 * sizeof(uint64_t)));
-    c->slots.resize(size_t(TDX_S_COUNT));
+    const int rc = context_init(c, device);
+    if (rc != TDX_OK) {   // nothing of a half-built context survives (the error text stays in the calling thread's slot)
+        const std::string keep = g_tdx_thread_error;
+        tdx_context_destroy(c);
+        g_tdx_thread_error = keep;
+        return rc;
+    }
     *out = c;
     return TDX_OK;
 }
@@ -118,7 +131,7 @@ int tdx_context_create(int device, tdx_context** out) {
 void tdx_context_destroy(tdx_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->slots) if (s.p) (void)hipFree(s.p);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_mail) (void)hipHostFree(c->h_mail);

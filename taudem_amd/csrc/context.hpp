@@ -42,6 +42,7 @@ struct tdx_context {
     hipEvent_t get_event();
     void begin_call(tdx_stats* st);
     void end_call();                          // synchronises, fills stats
+    void abort_call() { timing = false; cur_stats = nullptr; }   // an entry point leaves early: nothing may point at the caller's stats any more
     int span_begin(int kclass);              // returns the span's index (-1 when timing is off); spans may nest
     void span_end(int index);
 };
@@ -54,6 +55,7 @@ extern thread_local std::string g_tdx_thread_error;
         if (_e != hipSuccess) {                                                                    \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
             g_tdx_thread_error = (ctx)->err;                                                       \
+            (ctx)->abort_call();                                                                   \
             return TDX_ERR_HIP;                                                                    \
         }                                                                                          \
     } while (0)
@@ -73,7 +75,7 @@ enum {
 };
 
 static inline int tdx_fail(tdx_context* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) { ctx->err = msg; ctx->abort_call(); }
     g_tdx_thread_error = msg;
     return code;
 }

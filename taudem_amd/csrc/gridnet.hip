@@ -136,7 +136,7 @@ __device__ __forceinline__ void gn_walk_from(size_t idx, const int16_t* __restri
         const int xn = x + d1(k), yn = y + d2(k);
         const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
         drain_stores();                             // the values must be at the coherence point before the counter moves
-        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         GnWindow wn;                                // the next hop's window travels with the atomic, not after it
         gn_load_window(P, mask, thresh, nx, ny, xn, yn, n, wn);
         if (old != 1) return;                       // somebody else is the last contributor
