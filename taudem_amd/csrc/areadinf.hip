@@ -351,7 +351,6 @@ __global__ __launch_bounds__(256) void dinf_halo_kernel(Alg alg, const float* __
 // like the reference's never-queued cells.
 // =====================================================================================================================
 namespace dsweep {
-constexpr int TS = tilek::TS, LH = TS + 2;
 constexpr int QCAP = 512;
 
 // Per cell, once (streaming, all rows of the array): everything the sweep needs to evaluate the cell and to find its targets
@@ -400,28 +399,13 @@ __global__ __launch_bounds__(256) void setup_kernel(const float* __restrict__ AN
     if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
 }
 
-template <bool HAS_W, bool HAS_DM>
-struct Lds {
-    double2 p[LH * LH];            // outflow proportions of tile + ring
-    float out[LH * LH];
-    float dm[HAS_DM ? LH * LH : 1];
-    float w[HAS_W ? TS * TS : 1];
-    uint32_t info[TS * TS];
-    uint32_t cnt[TS * TS / 4];     // one byte per cell: contributors still pending (255: not a pending cell of this rank)
-    double dx[TS];                 // cell size of the tile's rows (the unweighted increment)
-    uint16_t q[2][QCAP];           // ready cells handed on to the next phase
-    unsigned nq[2];
-    int rim;                       // RES_* rim bits: neighbouring tiles that receive flow from cells finished in this activation
-    int over;                      // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
-};
-
 __device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == DINF_PENDING_BITS; }
 
 // The neighbourhood of a cell as registers: all 8 result values and proportion pairs are requested unconditionally and
 // together (ONE LDS latency); a read inside a data-dependent branch gets its own basic block and its own wait - eight of
 // them per cell were most of a hop's time.
 struct Nbr8 { float v[9]; double2 p[9]; float dm[9]; };
-template <class L, bool HAS_DM>
+template <class L, bool HAS_DM, int LH>
 __device__ __forceinline__ void load_nbrs(const L& S, int cl, Nbr8& nb) {
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
@@ -472,232 +456,40 @@ struct DecayEval {   // src/dinfdecayaccum.cpp:213-245
     }
 };
 
-constexpr int NT = 1024;            // threads per tile: lane (lx, wv) owns column lx, rows 4 wv .. 4 wv + 3
-constexpr int RPL = TS * TS / NT;   // cells per lane
-constexpr int NSTAGE = (LH * LH + NT - 1) / NT;
-constexpr int BULK_SWEEPS = 12;
-
-// targets of a finished cell that lie outside the tile: those tiles have to look again
-__device__ __forceinline__ int rim_bits(unsigned inf, int cx, int ly) {
-    int bits = 0;
-    const int s1 = int((inf >> 9) & 7u) + 1;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        if (!((inf >> (12 + t)) & 1u)) continue;
-        const int k = t == 0 ? s1 : (s1 % 8 + 1);
-        const int nx2 = cx + d1(k), ny2 = ly + d2(k);
-        if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS)
-            bits |= ny2 < 0 ? (nx2 < 0 ? 16 : (nx2 >= TS ? 32 : 1)) : (ny2 >= TS ? (nx2 < 0 ? 64 : (nx2 >= TS ? 128 : 2)) : (nx2 < 0 ? 4 : 8));
-    }
-    return bits;
+// activation flags between the two tile geometries (a 64 x 64 tile = 2 x 2 tiles of 32 x 32)
+static __global__ __launch_bounds__(256) void flags_down_kernel(const uint32_t* __restrict__ f64, int tiles_x64, uint32_t* __restrict__ f32, int tiles_x32,
+                                                                int tiles_y32) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles_x32 * tiles_y32) return;
+    const int tx = t % tiles_x32, ty = t / tiles_x32;
+    f32[t] = f64[(ty >> 1) * tiles_x64 + (tx >> 1)] ? tilek::FLAG_FULL : 0u;
 }
-
-template <class Eval, bool HAS_W, bool HAS_DM>
-__device__ __forceinline__ int sweep_tile(const Eval& ev, const tilek::TileGeom& g, int tile, bool full, Lds<HAS_W, HAS_DM>& S, const double2* __restrict__ P,
-                                          const float* __restrict__ W, const float* __restrict__ DM, const uint32_t* __restrict__ INFO,
-                                          const RowProp* __restrict__ rows, float* __restrict__ OUT, float out_nodata, int contcheck,
-                                          unsigned long long* __restrict__ dbg) {
-    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
-    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-    const int x0 = tx * TS, y0 = ty * TS;
-    const unsigned long long tc0 = dbg ? wall_clock64() : 0ull;
-    unsigned long long hops = 0, nphase = 0;
-    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
-    // ---- stage: every load of a lane is issued before the first LDS store (ONE memory latency per activation); addresses
-    // are clamped into the raster and validity is applied afterwards (a load inside a divergent branch is waited for at once)
-    {
-        float so[NSTAGE], sd[HAS_DM ? NSTAGE : 1];
-        double2 sp[NSTAGE];
-        uint32_t si[RPL];
-        float sw[HAS_W ? RPL : 1];
-        unsigned ok = 0;
-#pragma unroll
-        for (int i = 0; i < NSTAGE; i++) {
-            const int e = tid + i * NT, ec = e < LH * LH ? e : LH * LH - 1;
-            const int wy = ec / LH, wx = ec - wy * LH;
-            const int gx = x0 - 1 + wx, gy = y0 - 1 + wy;
-            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) ok |= 1u << i;
-            const int gxc = gx < 0 ? 0 : (gx >= g.nx ? g.nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy);
-            const size_t idx = size_t(gyc) * size_t(g.nx) + size_t(gxc);
-            so[i] = OUT[idx];
-            sp[i] = P[idx];
-            if (HAS_DM) sd[i] = DM[idx];
-        }
-        unsigned oki = 0;
-#pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            const int gx = x0 + lx, gy = y0 + ry0 + r;
-            if (gx < g.nx && gy < g.ny) oki |= 1u << r;
-            const size_t idx = size_t(gy >= g.ny ? g.ny - 1 : gy) * size_t(g.nx) + size_t(gx >= g.nx ? g.nx - 1 : gx);
-            si[r] = INFO[idx];
-            if (HAS_W) sw[r] = W[idx];
-        }
-        double dxrow = 0.;
-        if (tid < TS) dxrow = rows[y0 + tid >= g.ny ? g.ny - 1 : y0 + tid].dx;
-#pragma unroll
-        for (int i = 0; i < NSTAGE; i++) {
-            const int e = tid + i * NT;
-            if (e < LH * LH) {
-                const bool in = (ok >> i) & 1u;
-                S.out[e] = in ? so[i] : out_nodata;
-                S.p[e] = in ? sp[i] : make_double2(0., 0.);
-                if (HAS_DM) S.dm[e] = in ? sd[i] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            S.info[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? si[r] : 0u;
-            if (HAS_W) S.w[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? sw[r] : 0.f;
-        }
-        if (tid < TS) S.dx[tid] = dxrow;
+static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restrict__ f32, int tiles_x32, int tiles_y32, uint32_t* __restrict__ f64, int tiles_x64) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles_x32 * tiles_y32) return;
+    if (f32[t]) {
+        f32[t] = 0u;
+        const int tx = t % tiles_x32, ty = t / tiles_x32;
+        f64[(ty >> 1) * tiles_x64 + (tx >> 1)] = tilek::FLAG_HALO;   // walks only: the bulk sweeps have run
     }
-    __syncthreads();
-    const unsigned long long tc1 = dbg ? wall_clock64() : 0ull;
-    unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet)
-#pragma unroll
-    for (int r = 0; r < RPL; r++) {
-        const int gx = x0 + lx, gy = y0 + ry0 + r;
-        if (gx < g.nx && gy >= g.y_own0 && gy < g.y_own1 && pending(S.out[(ry0 + r + 1) * LH + lx + 1])) pendmask |= 1u << r;
-    }
-    const unsigned pend0 = pendmask;
-    int rim = 0;
-    // ---- bulk: a fresh tile holds thousands of ready cells and short chains - evaluated in lockstep (every lane looks at its
-    // own pending cells: ready = no contributor pending), one dependency level or more per sweep, no atomics.  What is left
-    // after a few sweeps are the stream cells: long, thin chains for the walks below.
-    if (full) {
-        for (int sweep = 0; sweep < BULK_SWEEPS; sweep++) {
-            bool prog = false;
-#pragma unroll
-            for (int rr = 0; rr < RPL; rr++) {
-                const int r = (sweep & 1) ? RPL - 1 - rr : rr;
-                if (!((pendmask >> r) & 1u)) continue;
-                const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
-                const unsigned inf = S.info[c];
-                Nbr8 nb;
-                load_nbrs<Lds<HAS_W, HAS_DM>, HAS_DM>(S, cl, nb);
-                const float wv = HAS_W ? S.w[c] : 0.f;
-                const double dxv = S.dx[ly];
-                if ((inf & 0xFFu & pending_bits(nb)) == 0u) {
-                    S.out[cl] = ev.eval(nb, wv, dxv, inf, contcheck, HAS_W);
-                    rim |= rim_bits(inf, lx, ly);
-                    pendmask &= ~(1u << r);
-                    prog = true;
-                }
-            }
-            if (!__syncthreads_or(prog ? 1 : 0)) break;
-        }
-    }
-    // ---- pending contributors of the cells that are left
-    unsigned readymask = 0;
-    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(S.cnt);
-#pragma unroll
-    for (int r = 0; r < RPL; r++) {
-        const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
-        unsigned cn = 255u;
-        const unsigned inf = S.info[c];
-        float nv[9];
-#pragma unroll
-        for (int k = 1; k <= 8; k++) nv[k] = S.out[cl + d2(k) * LH + d1(k)];
-        if ((pendmask >> r) & 1u) {
-            unsigned pb = 0;
-#pragma unroll
-            for (int k = 1; k <= 8; k++) pb |= pending(nv[k]) ? 1u << (k - 1) : 0u;
-            cn = unsigned(__popc(inf & 0xFFu & pb));
-            if (cn == 0u) readymask |= 1u << r;
-        }
-        cnt8[c] = uint8_t(cn);
-    }
-    __syncthreads();
-    const unsigned long long tc2 = dbg ? wall_clock64() : 0ull;
-    // ---- walks: a lane follows a chain downstream as long as it finishes the last pending contributor of a target
-    auto walk = [&](int c, int phase) {
-        unsigned inf = S.info[c];
-        for (;;) {
-            const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
-            Nbr8 nb;
-            load_nbrs<Lds<HAS_W, HAS_DM>, HAS_DM>(S, cl, nb);
-            const float wv = HAS_W ? S.w[c] : 0.f;
-            const double dxv = S.dx[ly];
-            S.out[cl] = ev.eval(nb, wv, dxv, inf, contcheck, HAS_W);
-            hops++;
-            // the (at most two) targets: both decrements and the candidates' info words are in flight together
-            const int s1 = int((inf >> 9) & 7u) + 1;
-            int tc[2] = {-1, -1};
-            unsigned old[2] = {0u, 0u}, tinf[2] = {0u, 0u};
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                if (!((inf >> (12 + t)) & 1u)) continue;
-                const int k = t == 0 ? s1 : (s1 % 8 + 1);
-                const int nx2 = cx + d1(k), ny2 = ly + d2(k);
-                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) continue;
-                tc[t] = ny2 * TS + nx2;
-                old[t] = __hip_atomic_fetch_sub(&S.cnt[tc[t] >> 2], 1u << (8 * (tc[t] & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                tinf[t] = S.info[tc[t]];
-            }
-            rim |= rim_bits(inf, cx, ly);
-            int next = -1;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                if (tc[t] < 0 || ((old[t] >> (8 * (tc[t] & 3))) & 255u) != 1u) continue;   // not its last pending contributor
-                if (next < 0) { next = tc[t]; inf = tinf[t]; }
-                else {
-                    const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
-                    if (slot < unsigned(QCAP)) S.q[phase ^ 1][slot] = uint16_t(tc[t]);
-                    else S.over = 1;
-                }
-            }
-            if (next < 0) break;
-            c = next;
-        }
-    };
-    for (unsigned m = readymask; m; m &= m - 1u) walk((ry0 + (__ffs(int(m)) - 1)) * TS + lx, 0);
-    for (int phase = 1;; phase ^= 1) {          // drain the hand-over queue: the walks of a phase fill the other buffer
-        __syncthreads();                        // every push into q[phase] has landed
-        const unsigned n = S.nq[phase] < unsigned(QCAP) ? S.nq[phase] : unsigned(QCAP);
-        if (n == 0u) break;
-        nphase++;
-        for (unsigned i = tid; i < n; i += unsigned(NT)) walk(int(S.q[phase][i]), phase);
-        __syncthreads();                        // q[phase] has been read by everybody
-        if (tid == 0) S.nq[phase] = 0u;         // (nobody pushes into it before the next barrier)
-    }
-    const unsigned long long tc3 = dbg ? wall_clock64() : 0ull;
-    // ---- write back what this activation evaluated
-    bool wrote = false;
-    for (unsigned m = pend0; m; m &= m - 1u) {
-        const int r = __ffs(int(m)) - 1, ly = ry0 + r;
-        const float v = S.out[(ly + 1) * LH + lx + 1];
-        if (!pending(v)) { OUT[size_t(y0 + ly) * size_t(g.nx) + size_t(x0 + lx)] = v; wrote = true; }
-    }
-    if (rim) atomicOr(&S.rim, rim);
-    const int any = __syncthreads_or(wrote ? 1 : 0);
-    const int res = (any ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
-    if (dbg) {   // TDX_DEBUG_ROUNDS=1: 100 MHz ticks per phase, hops (total and of the busiest lane), hand-over phases
-        atomicAdd(dbg + 4, hops);
-        atomicMax(&S.nq[0], unsigned(hops));   // (the queue counters are idle here)
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long tc4 = wall_clock64();
-            atomicAdd(dbg + 0, tc1 - tc0); atomicAdd(dbg + 1, tc2 - tc1); atomicAdd(dbg + 2, tc3 - tc2); atomicAdd(dbg + 3, tc4 - tc3);
-            atomicAdd(dbg + 5, (unsigned long long)S.nq[0]); atomicAdd(dbg + 6, nphase); atomicAdd(dbg + 7, 1ull);
-        }
-    }
-    __syncthreads();   // S is reused by the next tile
-    return res;
-}
-
-template <class Eval, bool HAS_W, bool HAS_DM>
-__global__ __launch_bounds__(NT) void sweep_kernel(Eval ev, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
-                                                   uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
-                                                   unsigned pull_max, const double2* __restrict__ P, const float* __restrict__ W, const float* __restrict__ DM,
-                                                   const uint32_t* __restrict__ INFO, const RowProp* __restrict__ rows, float* __restrict__ OUT,
-                                                   float out_nodata, int contcheck, unsigned long long* __restrict__ dbg) {
-    __shared__ Lds<HAS_W, HAS_DM> S;
-    __shared__ tilek::TileLds L;
-    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
-        return sweep_tile<Eval, HAS_W, HAS_DM>(ev, g, tile, full, S, P, W, DM, INFO, rows, OUT, out_nodata, contcheck, dbg);
-    });
 }
 }  // namespace dsweep
+
+#define DSWEEP_NS dsweep64
+#define DSWEEP_TS 64
+#define DSWEEP_NT 1024
+#include "dinf_sweep_tile.inc"
+#undef DSWEEP_NS
+#undef DSWEEP_TS
+#undef DSWEEP_NT
+#define DSWEEP_NS dsweep32
+#define DSWEEP_TS 32
+#define DSWEEP_NT 256
+#include "dinf_sweep_tile.inc"
+#undef DSWEEP_NS
+#undef DSWEEP_TS
+#undef DSWEEP_NT
+
 
 
 template <class Alg>
@@ -785,47 +577,62 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     int64_t rounds = 0, outer = 0;
     if (!use_walk) {
         TdxSpan sp(ctx, TDX_K_ACCUM);
+        // two tile geometries over the same arrays (the state of the sweep is the result raster alone): 32 x 32 tiles for the bulk
+        // rounds, 64 x 64 tiles for the tail (dinf_sweep_tile.inc)
         const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
-        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+        tilek::TileGeom geom32 = geom;
+        geom32.tiles_x = (inx + 31) / 32; geom32.tiles_y = (iny + 31) / 32;
+        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y), ntiles32 = size_t(geom32.tiles_x) * size_t(geom32.tiles_y);
         uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+        uint32_t* flags32 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, ntiles32 * 4 * (1 + tilek::SCHED_LIST_WORDS)));
         unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
-        if (!flags || !counts) return TDX_ERR_NOMEM;
-        const tilek::Sched sched{flags, flags + ntiles, counts};
+        if (!flags || !flags32 || !counts) return TDX_ERR_NOMEM;
+        const tilek::Sched sched{flags, flags + ntiles, counts}, sched32{flags32, flags32 + ntiles32, counts};
         const float* d_w = alg.W;
-        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
+        static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
+        static const bool dbg_cycles = dbg_rounds && atoi(getenv("TDX_DEBUG_ROUNDS")) == 1;
+        // the bulk phase ends when a round has at most this many active 32 x 32 tiles (0: no bulk phase)
+        static const unsigned long long bulk_until = getenv("TDX_DINF_BULK_UNTIL") ? strtoull(getenv("TDX_DINF_BULK_UNTIL"), nullptr, 10) : 6000ull;
+        unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + 64 : nullptr;
+        auto launch = [&](bool small, const tilek::TileGeom& gg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur,
+                          uint32_t* fnext, uint32_t* lnext, unsigned pull_max) {
+#define TDX_DSWEEP_LAUNCH(NS)                                                                                                                                   \
+    if constexpr (std::is_same<Alg, AreaAlg>::value) {                                                                                                          \
+        if (d_w)                                                                                                                                                \
+            hipLaunchKernelGGL((NS::sweep_kernel<dsweep::AreaEval, true, false>), dim3(grid), dim3(NS::NT), 0, ls, dsweep::AreaEval{}, gg, list, count, fcur,  \
+                               fnext, lnext, pull_max, d_P, d_w, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);                                   \
+        else                                                                                                                                                    \
+            hipLaunchKernelGGL((NS::sweep_kernel<dsweep::AreaEval, false, false>), dim3(grid), dim3(NS::NT), 0, ls, dsweep::AreaEval{}, gg, list, count, fcur, \
+                               fnext, lnext, pull_max, d_P, nullptr, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);                               \
+    } else {                                                                                                                                                    \
+        if (d_w)                                                                                                                                                \
+            hipLaunchKernelGGL((NS::sweep_kernel<dsweep::DecayEval, true, true>), dim3(grid), dim3(NS::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, gg, list, \
+                               count, fcur, fnext, lnext, pull_max, d_P, d_w, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);                       \
+        else                                                                                                                                                    \
+            hipLaunchKernelGGL((NS::sweep_kernel<dsweep::DecayEval, false, true>), dim3(grid), dim3(NS::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, gg, list, \
+                               count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);                   \
+    }
+            if (small) { TDX_DSWEEP_LAUNCH(dsweep32) } else { TDX_DSWEEP_LAUNCH(dsweep64) }
+#undef TDX_DSWEEP_LAUNCH
+        };
         int64_t launches = 0;
-        for (;;) {
-            RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, geom, sched, ctx->h_mail, nullptr);
-            static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
-            static const bool dbg_cycles = dbg_rounds && atoi(getenv("TDX_DEBUG_ROUNDS")) == 1;
-            unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + 64 : nullptr;
-            int last_printed = -1;
+        // runs one geometry until no tile is active, or (stop_at > 0) until a round has at most stop_at active tiles; returns whether
+        // tiles are still active (their flags of the next round are then in run.flags_of(run.parity))
+        auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
+            RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail, nullptr);
+            if (small) { run.grid_full = unsigned(std::min(run.ntiles, 16 * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
             run.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
-                                    unsigned pull_max) {
-                if constexpr (std::is_same<Alg, AreaAlg>::value) {
-                    if (d_w)
-                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, true, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
-                                           fcur, fnext, lnext, pull_max, d_P, d_w, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);
-                    else
-                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::AreaEval, false, false>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::AreaEval{}, geom, list, count,
-                                           fcur, fnext, lnext, pull_max, d_P, nullptr, nullptr, info32, d_rows, d_out, out_nodata, contcheck, dbg);
-                } else {
-                    if (d_w)
-                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, true, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
-                                           list, count, fcur, fnext, lnext, pull_max, d_P, d_w, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);
-                    else
-                        hipLaunchKernelGGL((dsweep::sweep_kernel<dsweep::DecayEval, false, true>), dim3(grid), dim3(dsweep::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, geom,
-                                           list, count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);
-                }
-            };
+                                    unsigned pull_max) { launch(small, gg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
             run.print_counts = dbg_rounds;
-            if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%zu tiles):", ntiles);
+            if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%d tiles of %d):", run.ntiles, small ? 32 : 64);
             if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
-            rc = run.start();
-            if (rc != TDX_OK) return rc;
+            int last_printed = -1;
+            int rcl = run.start();
+            if (rcl != TDX_OK) return rcl;
+            *active_left = false;
             while (!run.done) {
-                rc = run.enqueue();
-                if (rc != TDX_OK) return rc;
+                rcl = run.enqueue();
+                if (rcl != TDX_OK) return rcl;
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 run.collect();
                 if (dbg) {   // per batch of rounds: average phase times (us) and hops per activation
@@ -837,9 +644,35 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                             ctx->h_mail[67] / na / 100.0, ctx->h_mail[68] / na, ctx->h_mail[69] / na, ctx->h_mail[70] / na);
                     last_printed = int(run.rounds) - 1;
                 }
+                if (!run.done && stop_at > 0 && run.last_count <= stop_at) { *active_left = true; *parity_out = run.parity; break; }
             }
             rounds += run.rounds;
             launches += run.launches;
+            return TDX_OK;
+        };
+        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
+        bool bulk = bulk_until > 0 && ntiles32 > bulk_until;
+        for (;;) {
+            bool left = false;
+            int par = 0;
+            if (bulk) {
+                // bulk phase on 32 x 32 tiles: every 32-tile under an active 64-tile starts active
+                hipLaunchKernelGGL(dsweep::flags_down_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, flags, geom.tiles_x, flags32, geom32.tiles_x,
+                                   geom32.tiles_y);
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+                rc = run_rounds(true, geom32, sched32, bulk_until, &left, &par);
+                if (rc != TDX_OK) return rc;
+                if (left) {   // what is still active goes on in 64 x 64 tiles
+                    uint32_t* f32next = par ? sched32.list + 2 * ntiles32 : sched32.flags;
+                    hipLaunchKernelGGL(dsweep::flags_up_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, f32next, geom32.tiles_x, geom32.tiles_y, flags,
+                                       geom.tiles_x);
+                }
+                bulk = false;   // (strip re-activations are few tiles: 64 x 64)
+            } else left = true;
+            if (left) {
+                rc = run_rounds(false, geom, sched, 0, &left, &par);
+                if (rc != TDX_OK) return rc;
+            }
             if (!st.multi()) break;
             // the neighbours' boundary rows: cells finished there release the owned cells they drain into (addBorders() + queue
             // refill of src/areadinf.cpp:241-262); tiles that see a changed halo cell run again
