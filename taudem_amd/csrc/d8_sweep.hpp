@@ -31,8 +31,15 @@
 
 namespace d8sweep {
 using namespace tdxk;
-constexpr int TS = tilek::TS, LH = TS + 2;
-constexpr int NT = 1024, RPL = TS * TS / NT, NSTAGE = (LH * LH + NT - 1) / NT;
+// Two tile geometries over the same arrays (the state of a sweep is the work array alone): 32 x 32 tiles (256 threads, a few tens
+// of KB of LDS: several tiles per CU) carry the BULK rounds, in which every tile of the raster is active and a tile's time is its
+// longest in-tile chain - what counts is how many tiles a CU works on at once; 64 x 64 tiles (1024 threads, one tile per CU) carry
+// the TAIL, where a round is one tile crossing of the longest flow path and fewer crossings win.
+template <int TSZ>
+struct Dim {
+    static constexpr int TS = TSZ, LH = TSZ + 2, NT = TSZ == 64 ? 1024 : 256, RPL = TSZ * TSZ / NT, NSTAGE = (LH * LH + NT - 1) / NT;
+};
+constexpr int LH = tilek::TS + 2;   // (row pitch of the staged window of the 64 x 64 geometry: not used by the engine itself)
 constexpr int BULK_SWEEPS = 12;
 constexpr uint32_t PENDING_BITS = 0x7FC0DEADu;   // a quiet NaN no arithmetic produces: "participating, not evaluated yet"
 constexpr unsigned INFO_CON = 1u << 8, INFO_PART = 1u << 13, INFO_DEAD = 1u << 14, INFO_OWNMASK = 1u << 24;
@@ -81,6 +88,7 @@ static __global__ __launch_bounds__(256) void setup_kernel(const int16_t* __rest
 }
 
 // rim bit (tilek::RES_* numbering) of the neighbouring tile that holds the cell (nx2, ny2), which lies outside this tile
+template <int TS>
 __device__ __forceinline__ int rim_bit(int nx2, int ny2) {
     return ny2 < 0 ? (nx2 < 0 ? 16 : (nx2 >= TS ? 32 : 1)) : (ny2 >= TS ? (nx2 < 0 ? 64 : (nx2 >= TS ? 128 : 2)) : (nx2 < 0 ? 4 : 8));
 }
@@ -158,8 +166,9 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
 };
 
 constexpr int QCAP = 512;
-template <class Alg>
+template <class Alg, int TSZ>
 struct Lds {
+    static constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH;
     typename Alg::Cell v[LH * LH];
     typename Alg::Aux aux[Alg::HAS_AUX ? TS * TS : 1];
     float dist[Alg::HAS_DIST ? TS * 9 : 1];
@@ -181,10 +190,11 @@ struct Arrays {   // global arrays of one sweep
     const uint32_t* info;
 };
 
-template <class Alg>
-__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg>& S, const Arrays<Alg>& A) {
+template <class Alg, int TSZ>
+__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg, TSZ>& S, const Arrays<Alg>& A) {
     using Cell = typename Alg::Cell;
-    const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * RPL;
+    constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL, NSTAGE = Dim<TSZ>::NSTAGE;
+    const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
     if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
@@ -243,7 +253,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
             const int k = __ffs(int(m));
             const int nx2 = cx + d1(k), ny2 = ly + d2(k);
-            if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rim |= rim_bit(nx2, ny2);
+            if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rim |= rim_bit<TS>(nx2, ny2);
         }
     };
     auto load_nbrs = [&](int cl, Cell (&nb)[9]) {   // unconditional and together: one LDS latency for the whole neighbourhood
@@ -300,7 +310,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     auto walk = [&](int c, int phase) {
         unsigned inf = S.info[c];
         for (;;) {
-            const int ly = c >> 6, cx = c & 63, cl = (ly + 1) * LH + cx + 1;
+            const int ly = c / TS, cx = c % TS, cl = (ly + 1) * LH + cx + 1;
             Cell nb[9];
             load_nbrs(cl, nb);
             alg.eval(S, c, cl, ly, inf, nb);
@@ -309,7 +319,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
                 const int k = __ffs(int(m));
                 const int nx2 = cx + d1(k), ny2 = ly + d2(k);
-                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit(nx2, ny2); continue; }
+                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit<TS>(nx2, ny2); continue; }
                 const int tc = ny2 * TS + nx2, sh = 8 * (tc & 3);
                 const unsigned old = __hip_atomic_fetch_sub(&S.cnt[tc >> 2], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned tinf = S.info[tc];
@@ -348,13 +358,13 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     return res;
 }
 
-template <class Alg>
-__global__ __launch_bounds__(NT) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+template <class Alg, int TSZ>
+__global__ __launch_bounds__(Dim<TSZ>::NT) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
                                                    unsigned pull_max, Arrays<Alg> A) {
-    __shared__ Lds<Alg> S;
+    __shared__ Lds<Alg, TSZ> S;
     __shared__ tilek::TileLds L;
-    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg>(alg, g, tile, full, S, A); });
+    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A); });
 }
 
 // the pending pattern that is left (cells on or below a cycle, cells fed by the p == 0 quirk) becomes `value`
@@ -403,35 +413,84 @@ template <> struct BitsOf<4> { using type = uint32_t; };
 template <> struct BitsOf<8> { using type = uint2; };
 template <> struct BitsOf<16> { using type = uint4; };
 
-// Runs the sweep to the global fixed point.  `flags` holds (1 + SCHED_LIST_WORDS) * ntiles words, `counts` 2 * COUNT_RING.
-// The work array must be initialised (pending pattern on participating owned cells) and its halo rows exchanged; cells still
-// pending on return (on or below a cycle, fed by the p == 0 quirk) are the caller's to finish.
+// activation flags between the two tile geometries (a 64 x 64 tile = 2 x 2 tiles of 32 x 32)
+static __global__ __launch_bounds__(256) void flags_down_kernel(const uint32_t* __restrict__ f64, int tiles_x64, uint32_t* __restrict__ f32, int tiles_x32,
+                                                                int tiles_y32) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles_x32 * tiles_y32) return;
+    const int tx = t % tiles_x32, ty = t / tiles_x32;
+    f32[t] = f64[(ty >> 1) * tiles_x64 + (tx >> 1)] ? tilek::FLAG_FULL : 0u;
+}
+static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restrict__ f32, int tiles_x32, int tiles_y32, uint32_t* __restrict__ f64, int tiles_x64) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles_x32 * tiles_y32) return;
+    if (f32[t]) {
+        f32[t] = 0u;
+        const int tx = t % tiles_x32, ty = t / tiles_x32;
+        f64[(ty >> 1) * tiles_x64 + (tx >> 1)] = tilek::FLAG_HALO;   // walks only: the bulk sweeps have run
+    }
+}
+
+// Runs the sweep to the global fixed point: bulk rounds on 32 x 32 tiles until a round has at most TDX_D8_BULK_UNTIL (default 6000)
+// active tiles, the rest on 64 x 64 tiles.  The work array must be initialised (pending pattern on participating owned cells) and
+// its halo rows exchanged; cells still pending on return (on or below a cycle, fed by the p == 0 quirk) are the caller's to finish.
 template <class Alg>
-static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32_t* flags, unsigned long long* counts, int64_t* rounds_out, int64_t* launches_out,
-               int64_t* outer_out) {
+static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32_t* /*flags_unused*/, unsigned long long* counts, int64_t* rounds_out,
+               int64_t* launches_out, int64_t* outer_out) {
     using Bits = typename BitsOf<sizeof(typename Alg::Cell)>::type;
     hipStream_t s = ctx->stream;
     const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
-    const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
-    const tilek::Sched sched{flags, flags + ntiles, counts};
-    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
-    int rc;
-    for (;;) {
-        RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, geom, sched, ctx->h_mail, nullptr);
+    tilek::TileGeom geom32 = geom;
+    geom32.tiles_x = (st.nx + 31) / 32; geom32.tiles_y = (st.ny_arr + 31) / 32;
+    const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y), ntiles32 = size_t(geom32.tiles_x) * size_t(geom32.tiles_y);
+    uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+    uint32_t* flags32 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, ntiles32 * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+    if (!flags || !flags32) return TDX_ERR_NOMEM;
+    const tilek::Sched sched{flags, flags + ntiles, counts}, sched32{flags32, flags32 + ntiles32, counts};
+    static const unsigned long long bulk_until = getenv("TDX_D8_BULK_UNTIL") ? strtoull(getenv("TDX_D8_BULK_UNTIL"), nullptr, 10) : 6000ull;
+    auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
+        RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail, nullptr);
+        if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
         runner.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
                                    unsigned pull_max) {
-            hipLaunchKernelGGL((sweep_kernel<Alg>), dim3(grid), dim3(NT), 0, ls, alg, geom, list, count, fcur, fnext, lnext, pull_max, A);
+            if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
+            else hipLaunchKernelGGL((sweep_kernel<Alg, 64>), dim3(grid), dim3(Dim<64>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
         };
-        rc = runner.start();
-        if (rc != TDX_OK) return rc;
+        int rcl = runner.start();
+        if (rcl != TDX_OK) return rcl;
+        *active_left = false;
         while (!runner.done) {
-            rc = runner.enqueue();
-            if (rc != TDX_OK) return rc;
+            rcl = runner.enqueue();
+            if (rcl != TDX_OK) return rcl;
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             runner.collect();
+            if (!runner.done && stop_at > 0 && runner.last_count <= stop_at) { *active_left = true; *parity_out = runner.parity; break; }
         }
         if (rounds_out) *rounds_out += runner.rounds;
         if (launches_out) *launches_out += runner.launches;
+        return TDX_OK;
+    };
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
+    bool bulk = bulk_until > 0 && ntiles32 > bulk_until;
+    int rc;
+    for (;;) {
+        bool left = false;
+        int par = 0;
+        if (bulk) {
+            hipLaunchKernelGGL(flags_down_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, flags, geom.tiles_x, flags32, geom32.tiles_x, geom32.tiles_y);
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+            rc = run_rounds(true, geom32, sched32, bulk_until, &left, &par);
+            if (rc != TDX_OK) return rc;
+            if (left) {   // what is still active goes on in 64 x 64 tiles
+                uint32_t* f32next = par ? sched32.list + 2 * ntiles32 : sched32.flags;
+                hipLaunchKernelGGL(flags_up_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, f32next, geom32.tiles_x, geom32.tiles_y, flags, geom.tiles_x);
+            }
+            bulk = false;   // (strip re-activations are few tiles: 64 x 64)
+        } else left = true;
+        if (left) {
+            rc = run_rounds(false, geom, sched, 0, &left, &par);
+            if (rc != TDX_OK) return rc;
+        }
         if (!st.multi()) break;
         // the neighbours' boundary rows (as bit patterns: a pending record must compare equal to itself): cells finished there
         // release the owned cells they drain into (addBorders() + queue refill of src/aread8.cpp:282-303); tiles that see a changed
