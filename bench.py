@@ -33,20 +33,25 @@ KCLASS_STAGE = {"relax": "pitremove", "bfs": "d8flowdir", "flatdir": "d8flowdir"
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries of this same command
-    (profiles/pmc_fetch_summary.json, profiles/pmc_write_summary.json; scripts/gpu_pmc.sh + scripts/pmc_summary.py).
-    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries of this same command: the newest
+    profiles/rNN?_pmc_{fetch,write}_summary.json pair (scripts/gpu_r02_profile.sh + scripts/pmc_summary.py; round 1's pair has no
+    prefix).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
     (MI355X_MICROARCH.md, HBM): it is doubled here.  Returns (bytes, note) or (None, reason)."""
+    import glob
+
     try:
-        f = json.load(open(os.path.join(ROOT, "profiles", "pmc_fetch_summary.json")))
-        w = json.load(open(os.path.join(ROOT, "profiles", "pmc_write_summary.json")))
+        pairs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_fetch_summary.json"))) or [os.path.join(ROOT, "profiles", "pmc_fetch_summary.json")]
+        ffile = pairs[-1]
+        wfile = ffile.replace("pmc_fetch_summary", "pmc_write_summary")
+        f = json.load(open(ffile))
+        w = json.load(open(wfile))
         fk = [k for k in f if kernel_substr in k]
         wk = [k for k in w if kernel_substr in k]
         if not fk or not wk:
             return None, "kernel not in the PMC summaries"
         fetch = f[fk[0]]["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * 2.0
         write = w[wk[0]]["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
-        return fetch + write, "profiles/pmc_{fetch,write}_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
+        return fetch + write, f"profiles/{os.path.basename(ffile)} + {os.path.basename(wfile)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
     except Exception as e:  # no summaries committed
         return None, f"no PMC summary ({e.__class__.__name__})"
 
