@@ -416,6 +416,9 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
 
         // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
         int64_t last = total;
+        const int64_t total0 = total;
+        bool sparse = false;                // this iteration works from lists (few flats left): no pass over the whole raster
+        unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
         for (;;) {
             // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
             FlatLevels fl;
@@ -426,7 +429,11 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
                                    rmask, tile_flags);
             };
-            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, &classify);
+            if (sparse) {
+                rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq);
+                if (rc != TDX_OK) return rc;
+            }
+            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
@@ -458,9 +465,13 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4));
                 if (!zwork) return TDX_ERR_NOMEM;
             }
-            rc = flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);
+            // (the choice must be the same on every rank - the list path exchanges two more halo rows -, hence global counts)
+            static const bool no_sparse = getenv("TDX_FLATS_DENSE") != nullptr;
+            sparse = !no_sparse && (total * 8 <= total0 || total <= (int64_t(1) << 20));
+            rc = sparse ? flats_overwrite_elevation_sparse(ctx, inx, qnext, nleft, lvl, rq, fl, zwork) : flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);
             if (rc != TDX_OK) return rc;
             zcur = zwork;
+            nq_old = nq;
             std::swap(qlist, qnext);
             nq = nleft;
             last = total;

@@ -344,8 +344,9 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
         if (rc != TDX_OK) return rc;
         int64_t last = total;
         bool first = true;
+        unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
         for (;;) {
-            if (!first) { rc = flats_reset_markers(ctx, st, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
+            if (!first) { rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
@@ -373,9 +374,11 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
             if (stats) { stats->flat_iterations++; stats->flats_left = total; }
             if (!(total > 0 && total < last)) break;     // src/dinf.cpp:230
             if (!zwork) { zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4)); if (!zwork) return TDX_ERR_NOMEM; }
-            rc = flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);   // src/dinf.cpp:822-828
+            // src/dinf.cpp:822-828 (only where the next iteration reads it when few flats are left)
+            rc = nleft <= n / 32 ? flats_overwrite_elevation_sparse(ctx, inx, qnext, nleft, lvl, rq, fl, zwork) : flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);
             if (rc != TDX_OK) return rc;
             zcur = zwork;
+            nq_old = nq;
             std::swap(qlist, qnext);
             nq = nleft; last = total;
         }

@@ -165,6 +165,36 @@ static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, co
     if (i < n) Zout[i] = (float)flat_elev2(lvl[i], rq[i], fl);
 }
 
+// The next iteration's elevation only where it will be read: on the cells of the new flat queue and their 8 neighbours (flat
+// cells are interior cells).  Several threads may store the same value to one cell.
+static __global__ __launch_bounds__(256) void overwrite_elev_sparse_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int nx,
+                                                                           const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq, FlatLevels fl,
+                                                                           float* __restrict__ Zout) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const size_t c = list[q];
+    int32_t l[9], r[9];
+#pragma unroll
+    for (int k = 0; k <= 8; k++) {
+        const size_t n = k ? size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k)) : c;
+        l[k] = lvl[n]; r[k] = rq[n];
+    }
+#pragma unroll
+    for (int k = 0; k <= 8; k++) {
+        const size_t n = k ? size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k)) : c;
+        Zout[n] = (float)flat_elev2(l[k], r[k], fl);
+    }
+}
+
+// markers of the cells of the PREVIOUS queue back to "not in Q"
+static __global__ __launch_bounds__(256) void unmark_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int32_t* __restrict__ lvl,
+                                                              int32_t* __restrict__ rq) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    lvl[list[q]] = -1;
+    rq[list[q]] = -1;
+}
+
 }  // namespace flatk
 
 static inline int flats_read_counters(tdx_context* ctx, int nwords) {
@@ -181,6 +211,27 @@ static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const u
     int rc = strip_exchange<int32_t>(ctx, st, lvl, -1);   // queue membership of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
     return strip_exchange<int32_t>(ctx, st, rq, -1);
+}
+
+// Same markers as flats_reset_markers when lvl / rq are "not in Q" everywhere except on the cells of the previous queue `qold`
+// (which is what a flat iteration leaves behind): a later iteration of a few thousand cells does not rewrite two rasters.
+static inline int flats_reset_markers_after(tdx_context* ctx, const Strip& st, const uint32_t* qold, unsigned long long nq_old, const uint32_t* qlist,
+                                            unsigned long long nq, int32_t* lvl, int32_t* rq) {
+    const size_t n = size_t(st.nx) * size_t(st.ny_arr);
+    if (nq_old > n / 16) return flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
+    if (nq_old) hipLaunchKernelGGL(flatk::unmark_q_kernel, dim3(tdx_blocks_for(nq_old, 256)), dim3(256), 0, ctx->stream, qold, nq_old, lvl, rq);
+    if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
+    int rc = strip_exchange<int32_t>(ctx, st, lvl, -1);
+    if (rc != TDX_OK) return rc;
+    return strip_exchange<int32_t>(ctx, st, rq, -1);
+}
+
+// elevDEM := (float)elev2 where the next iteration (queue `qlist`) reads it: the queue cells and their neighbours
+static inline int flats_overwrite_elevation_sparse(tdx_context* ctx, int nx, const uint32_t* qlist, unsigned long long nq, const int32_t* lvl, const int32_t* rq,
+                                                   FlatLevels fl, float* zout) {
+    TdxSpan sp(ctx, TDX_K_MISC);
+    if (nq) hipLaunchKernelGGL(flatk::overwrite_elev_sparse_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, nx, lvl, rq, fl, zout);
+    return TDX_OK;
 }
 
 static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const int32_t* lvl, const int32_t* rq, FlatLevels fl, float* zout) {
