@@ -320,14 +320,25 @@ struct TileTopo {   // what both tile kernels derive from the staged P tile
     unsigned indeg;
 };
 
-// stage P (tile + ring, outside the array = nodata) into LDS; ya0 = array row of the tile's first row
+// stage P (tile + ring, outside the array = nodata) into LDS; ya0 = array row of the tile's first row.  All loads of a lane are
+// issued back to back (addresses clamped, validity applied afterwards: loads inside a loop with a bounds branch wait for each other).
 __device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, int ny_arr, int x0, int ya0, int16_t nodata, int16_t* sP) {
-    for (int e = threadIdx.x; e < TH * TH; e += 256) {
-        const int ly = e / TH, lx = e - ly * TH;
+    constexpr int NIT = (TH * TH + 255) / 256;
+    int16_t v[NIT];
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+        const int e = int(threadIdx.x) + i * 256, ec = e < TH * TH ? e : TH * TH - 1;
+        const int ly = ec / TH, lx = ec - ly * TH;
         const int gx = x0 + lx - 1, gy = ya0 + ly - 1;
-        int16_t v = nodata;
-        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny_arr) v = P[size_t(gy) * size_t(nx) + size_t(gx)];
-        sP[e] = v;
+        const int gxc = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= ny_arr ? ny_arr - 1 : gy);
+        v[i] = P[size_t(gyc) * size_t(nx) + size_t(gxc)];
+        if (gx == gxc && gy == gyc) ok |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+        const int e = int(threadIdx.x) + i * 256;
+        if (e < TH * TH) sP[e] = ((ok >> i) & 1u) ? v[i] : nodata;
     }
 }
 __device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && ((p >= 0 && p <= 8) || p == P_SINK); }
@@ -370,9 +381,14 @@ __device__ __forceinline__ bool ring_cell(int j, int rv, int& hx, int& hy) {
     return false;
 }
 
-__global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
+__device__ unsigned long long g_ad8_dbg[8];   // TDX_AD8_DEBUG=1: phase cycles of ad8_tile_local_kernel summed over the tiles (thread 0)
+template <bool DBG>
+__global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, unsigned long long* __restrict__ node_acc,
                                                              uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next) {
+    unsigned long long tcs[6];
+#define AD8_MARK(i) do { if (DBG) tcs[i] = clock64(); } while (0)
+    AD8_MARK(0);
     // 26 KB of LDS per tile (6 workgroups per CU): the in-tile targets overwrite the interior of the staged P tile
     // once every lane has derived its topology from it; the ring cells keep their directions for the entry search
     __shared__ int16_t sP[TH * TH];
@@ -385,21 +401,60 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
     sIn[tid] = 0u;
     __syncthreads();
+    AD8_MARK(1);
     unsigned src = 0;       // rows of this lane that start a walk
     unsigned exit_up = 0, exit_down = 0;   // rows whose crossing leaves towards the row above / below the cell
     int16_t tgt[16];
+    {
+        // the lane's window of directions in registers (four quarter bands of 4 rows: 3 x 6 unconditional LDS reads each, so that
+        // 6 workgroups per CU still fit the register file), then branch-free topology: initNeighborD8up
+        // (src/commonLib.cpp:251-282) and the contamination test of src/aread8.cpp:241-242
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int ly = ry0 + r;
-        const TileTopo t = tile_topo(sP, lx, ly, rv, nodata);
-        tgt[r] = t.tgt;
-        if (t.tgt == -2) {
-            const int dy = d2(sP[(ly + 1) * TH + lx + 1]);
-            if (dy < 0) exit_up |= 1u << r;
-            if (dy > 0) exit_down |= 1u << r;
+        for (int h = 0; h < 4; h++) {
+            int win[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) win[i][j] = sP[(ry0 + 4 * h + j) * TH + lx + i];
+            }
+            int ptgt[4];   // direction of the cell the row drains to (speculative read, address from a clamped direction)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = win[1][q + 1];
+                const int pc = (p >= 1 && p <= 8) ? p : 1;
+                ptgt[q] = sP[(ry0 + 4 * h + q + d2(pc) + 1) * TH + lx + d1(pc) + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = 4 * h + q, ly = ry0 + r;
+                const int p = win[1][q + 1];
+                const bool part = ly < rv && p_part(int16_t(p), nodata);
+                unsigned indeg = 0;
+                bool con = false, poison = false;
+#pragma unroll
+                for (int k = 1; k <= 8; k++) {
+                    const int pn = win[1 + d1(k)][q + 1 + d2(k)];   // (static indices after unrolling)
+                    const bool nod = pn == int(nodata);
+                    const bool drains = !nod && (k <= 4 ? (pn == k + 4 || (k == 4 && pn == 0)) : pn == k - 4);
+                    con |= nod;
+                    poison |= drains && pn == 0;   // k == 4: counted in the in-degree but never decremented (src/aread8.cpp:262)
+                    if (drains && pn != 0 && in_tile(lx + d1(k), ly + d2(k), rv)) indeg++;
+                }
+                int t = -1;
+                if (part && p >= 1 && p <= 8 && p_part(int16_t(ptgt[q]), nodata)) {
+                    const int tlx = lx + d1(p), tly = ly + d2(p);
+                    t = in_tile(tlx, tly, rv) ? tly * TS + tlx : -2;
+                    if (t == -2) {
+                        if (d2(p) < 0) exit_up |= 1u << r;
+                        if (d2(p) > 0) exit_down |= 1u << r;
+                    }
+                }
+                tgt[r] = int16_t(t);
+                sAcc[ly * TS + lx] = part ? lw_pack(1u, 0u, con ? 1u : 0u, poison ? 1u : 0u, indeg) : lw_pack(0u, 0u, 0u, 0u, 15u);
+                if (part && indeg == 0) src |= 1u << r;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the next quarter's reads behind this quarter's arithmetic)
         }
-        sAcc[ly * TS + lx] = t.part ? lw_pack(1u, 0u, t.con ? 1u : 0u, t.poison ? 1u : 0u, t.indeg) : lw_pack(0u, 0u, 0u, 0u, 15u);
-        if (t.part && t.indeg == 0) src |= 1u << r;
     }
     __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
 #define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
@@ -407,22 +462,25 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
     for (int r = 0; r < 16; r++)
         if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = tgt[r];   // row rv is the bottom ring row of a partial tile: keep it
     __syncthreads();
-    // Kahn sweep of the in-tile flows: one returning 32-bit LDS atomic per hop
+    AD8_MARK(2);
+    // Kahn sweep of the in-tile flows: one returning 32-bit LDS atomic per hop; the target of the NEXT hop is read alongside the
+    // atomic (both only need the current target), so a hop is one LDS round trip, not two
     while (src) {
         const int r = __ffs(int(src)) - 1;
         src &= src - 1u;
-        int c = (ry0 + r) * TS + lx;
+        const int c = (ry0 + r) * TS + lx;
         unsigned w = sAcc[c];
-        for (;;) {
-            const int t = S_TGT(c);
-            if (t < 0) break;
+        int t = S_TGT(c);
+        while (t >= 0) {
+            const int tn = S_TGT(t);
             const unsigned add = lw_pack(lw_cnt(w), 1u, lw_con(w) ? 1u : 0u, lw_poi(w) ? 1u : 0u, 0u);
             const unsigned nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
             if (lw_arr(nw) != lw_indeg(nw)) break;   // someone else will be the last contributor
-            c = t; w = nw;
+            w = nw; t = tn;
         }
     }
     __syncthreads();
+    AD8_MARK(3);
     // crossings that enter the tile: follow the in-tile path of the entry cell to where it leaves
     for (int j = tid; j < 4 * TH; j += 256) {
         int hx, hy;
@@ -443,6 +501,7 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
         node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
     }
     __syncthreads();
+    AD8_MARK(4);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ly = ry0 + r, c = ly * TS + lx;
@@ -463,6 +522,13 @@ __global__ __launch_bounds__(256) void ad8_tile_local_kernel(const int16_t* __re
         }
     }
 #undef S_TGT
+    if (DBG) {
+        __syncthreads();
+        AD8_MARK(5);
+        if (tid == 0)
+            for (int i = 0; i < 5; i++) atomicAdd(&g_ad8_dbg[i], tcs[i + 1] - tcs[i]);
+    }
+#undef AD8_MARK
 }
 
 // Walk the crossing forest from the completed node u (word w): the last arrival at a node continues.
@@ -541,24 +607,41 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
     __syncthreads();
     int16_t tgt[16];
     unsigned partmask = 0;
+    {
+        // the 16 words of phase A and the directions (own cell, cell drained to) are fetched unconditionally, back to back
+        uint32_t cw[16];
+        int pown[16], ptgt[16];
+        const int gx = x0 + lx, gxc = gx < g.nx ? gx : g.nx - 1;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int ly = ry0 + r;
-        const int gx = x0 + lx, gy = ya0 + ly;
-        const int16_t p = sP[(ly + 1) * TH + lx + 1];
-        tgt[r] = -1;
-        if (ly < rv && p_part(p, nodata)) {
-            partmask |= 1u << r;
-            if (p >= 1 && p <= 8) {
-                const int tlx = lx + d1(p), tly = ly + d2(p);
-                if (in_tile(tlx, tly, rv) && p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) tgt[r] = int16_t(tly * TS + tlx);
-            }
+        for (int r = 0; r < 16; r++) {
+            const int ly = ry0 + r, lyc = ly < rv ? ly : rv - 1;
+            cw[r] = cellw[size_t(ya0 + lyc) * size_t(g.nx) + size_t(gxc)];
         }
-        uint32_t cw = 0u;
-        if (gx < g.nx && ly < rv) cw = cellw[size_t(gy) * size_t(g.nx) + size_t(gx)];
-        sCnt[ly * TS + lx] = cw & 0x3FFFFFFFu;
-        const unsigned fl = cw >> 30;   // bit 0 contaminated, bit 1 not evaluated
-        if (fl) atomicOr(&sFlag[(ly * TS + lx) >> 4], fl << (2 * ((ly * TS + lx) & 15)));
+#pragma unroll
+        for (int r = 0; r < 16; r++) pown[r] = sP[(ry0 + r + 1) * TH + lx + 1];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int pc = (pown[r] >= 1 && pown[r] <= 8) ? pown[r] : 1;
+            ptgt[r] = sP[(ry0 + r + d2(pc) + 1) * TH + lx + d1(pc) + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ly = ry0 + r;
+            const int p = pown[r];
+            int t = -1;
+            if (ly < rv && p_part(int16_t(p), nodata)) {
+                partmask |= 1u << r;
+                if (p >= 1 && p <= 8) {
+                    const int tlx = lx + d1(p), tly = ly + d2(p);
+                    if (in_tile(tlx, tly, rv) && p_part(int16_t(ptgt[r]), nodata)) t = tly * TS + tlx;
+                }
+            }
+            tgt[r] = int16_t(t);
+            const uint32_t w = (gx < g.nx && ly < rv) ? cw[r] : 0u;
+            sCnt[ly * TS + lx] = w & 0x3FFFFFFFu;
+            const unsigned fl = w >> 30;   // bit 0 contaminated, bit 1 not evaluated
+            if (fl) atomicOr(&sFlag[(ly * TS + lx) >> 4], fl << (2 * ((ly * TS + lx) & 15)));
+        }
     }
     __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
 #define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
@@ -848,7 +931,17 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     TDX_HIP_CHECK(ctx, hipMemsetAsync(delivered, 0, size_t(st.nx) * 2, s));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_tile_local_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
+        static const bool ad8_debug = getenv("TDX_AD8_DEBUG") != nullptr;
+        if (ad8_debug) {
+            unsigned long long z[8] = {};
+            TDX_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_ad8_dbg), z, sizeof(z)));
+            hipLaunchKernelGGL(ad8_tile_local_kernel<true>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            TDX_HIP_CHECK(ctx, hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ad8_dbg), sizeof(z)));
+            fprintf(stderr, "ad8_tile_local: cycles per tile: stage %.0f, topology %.0f, targets %.0f, Kahn walks %.0f, entry walks %.0f, write-back %.0f\n",
+                    double(z[0]) / double(ntiles), double(z[1]) / double(ntiles) , 0.0, double(z[2]) / double(ntiles), double(z[3]) / double(ntiles), double(z[4]) / double(ntiles));
+        } else
+            hipLaunchKernelGGL(ad8_tile_local_kernel<false>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     int64_t outer = 1;
