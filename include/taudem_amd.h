@@ -201,6 +201,30 @@ int tdx_dinfrevaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64
 int tdx_dinfrevaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
                      const double* dxc, const double* dyc, const float* w, float w_nodata,
                      float* racc, float* dmax, tdx_stats* stats);
+/* dsllArea() src/DinfConcLimAccum.cpp:61-326: concentration limited accumulation.  ctpt = csol where the indicator dg (int16,
+ * a SHORT grid in the reference) is > 0, else sum over the contributing cells of p * ctpt * q * dm divided by the cell's own q;
+ * cells with q <= 0 get no value.  Result float, nodata -FLT_MAX.  Outlets as for tdx_areadinf. */
+int tdx_dinfconclimaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                             const double* dxc, const double* dyc, const float* d_dm, float dm_nodata, const int16_t* d_dg,
+                             const float* d_q, float q_nodata, float csol, int contcheck,
+                             const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* d_ctpt, tdx_stats* stats);
+int tdx_dinfconclimaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                         const double* dxc, const double* dyc, const float* dm, float dm_nodata, const int16_t* dg,
+                         const float* q, float q_nodata, float csol, int contcheck,
+                         const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets, float* ctpt, tdx_stats* stats);
+/* tlaccum() src/DinfTransLimAccum.cpp:61-372: transport limited accumulation.  tla = min(inflow + tsup, tc), tdep = what stays
+ * behind; with a concentration grid cs (and then ctpt != NULL) the concentration of the transported material as well.  All
+ * float, nodata -FLT_MAX; cs and ctpt are both NULL or both given. */
+int tdx_dinftranslimaccum_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
+                              const double* dxc, const double* dyc, const float* d_tsup, float tsup_nodata, const float* d_tc,
+                              float tc_nodata, const float* d_cs, float cs_nodata, int contcheck,
+                              const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                              float* d_tla, float* d_tdep, float* d_ctpt, tdx_stats* stats);
+int tdx_dinftranslimaccum(tdx_context* ctx, const float* ang, int64_t nx, int64_t ny, float ang_nodata,
+                          const double* dxc, const double* dyc, const float* tsup, float tsup_nodata, const float* tc,
+                          float tc_nodata, const float* cs, float cs_nodata, int contcheck,
+                          const int32_t* outlet_x, const int32_t* outlet_y, int64_t n_outlets,
+                          float* tla, float* tdep, float* ctpt, tdx_stats* stats);
 
 /* ---- row strips across GPUs (replaces linearpart<T>, src/linearpart.h:55-565) ---------------------- */
 /* One process per GPU holds one horizontal strip of the raster plus ONE halo row above and below it,
@@ -296,6 +320,16 @@ int tdx_dinfupdependence_strip(tdx_context* ctx, const tdx_comm* comm, float* d_
                                const double* dxc, const double* dyc, int32_t* d_dg, float* d_dep, tdx_stats* stats);
 int tdx_dinfrevaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
                            const double* dxc, const double* dyc, float* d_w, float w_nodata, float* d_racc, float* d_dmax, tdx_stats* stats);
+/* the limited D-infinity accumulations on strips (outlet_row: array row of the strip, as for tdx_areadinf_strip) */
+int tdx_dinfconclimaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                               const double* dxc, const double* dyc, const float* d_dm, float dm_nodata, const int16_t* d_dg,
+                               const float* d_q, float q_nodata, float csol, int contcheck,
+                               const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets, float* d_ctpt, tdx_stats* stats);
+int tdx_dinftranslimaccum_strip(tdx_context* ctx, const tdx_comm* comm, float* d_ang, int64_t nx, int64_t ny_local, float ang_nodata,
+                                const double* dxc, const double* dyc, const float* d_tsup, float tsup_nodata, const float* d_tc,
+                                float tc_nodata, const float* d_cs, float cs_nodata, int contcheck,
+                                const int32_t* outlet_x, const int32_t* outlet_row, int64_t n_outlets,
+                                float* d_tla, float* d_tdep, float* d_ctpt, tdx_stats* stats);
 /* GridNet on a strip (d_mask: optional int32 strip array whose halo rows the library fills) */
 int tdx_gridnet_strip(tdx_context* ctx, const tdx_comm* comm, int16_t* d_p, int64_t nx, int64_t ny_local, int16_t p_nodata,
                       const double* dxc, const double* dyc, int32_t* d_mask, int32_t thresh,
@@ -370,6 +404,15 @@ int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const ch
 int tdx_tool_dinfupdependence(const char* angfile, const char* dgfile, const char* depfile);
 /* int dsaccum(char* angfile, char* wgfile, char* raccfile, char* dmaxfile)   src/DinfRevAccum.cpp:51 */
 int tdx_tool_dinfrevaccum(const char* angfile, const char* wgfile, const char* raccfile, const char* dmaxfile);
+/* int dsllArea(char* angfile, char* ctptfile, char* dmfile, char* datasrc, char* lyrname, int uselyrname, int lyrno, char* qfile,
+ *              char* dgfile, int useOutlets, int contcheck, float cSol)          src/DinfConcLimAccum.cpp:61-62 */
+int tdx_tool_dinfconclimaccum(const char* angfile, const char* ctptfile, const char* dmfile, const char* datasrc, const char* lyrname,
+                              int uselyrname, int lyrno, const char* qfile, const char* dgfile, int useOutlets, int contcheck, float cSol);
+/* int tlaccum(char* angfile, char* tsupfile, char* tcfile, char* tlafile, char* depfile, char* cinfile, char* coutfile,
+ *             char* datasrc, char* lyrname, int uselyrname, int lyrno, int useOutlets, int usec, int contcheck)   src/DinfTransLimAccum.cpp:61-63 */
+int tdx_tool_dinftranslimaccum(const char* angfile, const char* tsupfile, const char* tcfile, const char* tlafile, const char* depfile,
+                               const char* cinfile, const char* coutfile, const char* datasrc, const char* lyrname, int uselyrname,
+                               int lyrno, int useOutlets, int usec, int contcheck);
 /* int threshold(char*,char*,char*,float,int)                       src/Threshold.cpp:49 */
 int tdx_tool_threshold(const char* ssafile, const char* srcfile, const char* maskfile, float thresh, int usemask);
 /* selects the HIP device used by the tdx_tool_* functions (default 0 / env TAUDEM_AMD_DEVICE) */

@@ -203,6 +203,41 @@ def dinfrevaccum(ang, w, nodata=-3.402823466e38, w_nodata=-9999.0, dx=1.0, dy=1.
     return racc, dmax
 
 
+def dinfconclimaccum(ang, dm, dg, q, csol=1.0, nodata=-3.402823466e38, dm_nodata=-9999.0, q_nodata=-9999.0, dx=1.0, dy=1.0, contcheck=True, outlets=None):
+    """ctpt of src/DinfConcLimAccum.cpp (nodata -FLT_MAX); dg is the int16 indicator grid."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    dm = np.ascontiguousarray(dm, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    dg = np.ascontiguousarray(dg, dtype=np.int16)
+    ny, nx = ang.shape
+    out = np.empty((ny, nx), dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinfconclimaccum(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(dm), C.c_float(dm_nodata), _p(dg), _p(q),
+                               C.c_float(q_nodata), C.c_float(csol), C.c_int(int(contcheck)), ox, oy, C.c_int(no), C.c_int(use), _p(out))
+    return out
+
+
+def dinftranslimaccum(ang, tsup, tc, cs=None, nodata=-3.402823466e38, tsup_nodata=-9999.0, tc_nodata=-9999.0, cs_nodata=-9999.0, dx=1.0, dy=1.0,
+                      contcheck=True, outlets=None):
+    """(tla, tdep, ctpt or None) of src/DinfTransLimAccum.cpp (nodata -FLT_MAX)."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    tsup = np.ascontiguousarray(tsup, dtype=np.float32)
+    tc = np.ascontiguousarray(tc, dtype=np.float32)
+    ny, nx = ang.shape
+    tla = np.empty((ny, nx), dtype=np.float32)
+    dep = np.empty((ny, nx), dtype=np.float32)
+    usec = cs is not None
+    csa = np.ascontiguousarray(cs, dtype=np.float32) if usec else None
+    cso = np.empty((ny, nx), dtype=np.float32) if usec else None
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    lib().orc_dinftranslimaccum(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(tsup), C.c_float(tsup_nodata), _p(tc),
+                                C.c_float(tc_nodata), _p(csa), C.c_float(cs_nodata), C.c_int(int(usec)), C.c_int(int(contcheck)), ox, oy, C.c_int(no),
+                                C.c_int(use), _p(tla), _p(dep), _p(cso))
+    return tla, dep, cso
+
+
 def prop(a, k, dx, dy):
     return lib().orc_prop(C.c_float(a), C.c_int(k), C.c_double(dx), C.c_double(dy))
 

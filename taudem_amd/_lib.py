@@ -145,6 +145,16 @@ _SIGNATURES = {
     "tdx_dinfrevaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _P]),
     "tdx_tool_dinfupdependence": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "tdx_tool_dinfrevaccum": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    # ctx, ang, nx, ny, ang_nodata, dxc, dyc, dm, dm_nodata, dg, q, q_nodata, csol, contcheck, ox, oy, n_outlets, ctpt, stats
+    "tdx_dinfconclimaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _F, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfconclimaccum_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _F, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    "tdx_dinfconclimaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _P, _F, _F, C.c_int, _P, _P, _I64, _P, _P]),
+    # ctx, ang, nx, ny, ang_nodata, dxc, dyc, tsup, tsup_nodata, tc, tc_nodata, cs, cs_nodata, contcheck, ox, oy, n_outlets, tla, tdep, ctpt, stats
+    "tdx_dinftranslimaccum": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _F, _P, _F, C.c_int, _P, _P, _I64, _P, _P, _P, _P]),
+    "tdx_dinftranslimaccum_dev": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _F, _P, _F, C.c_int, _P, _P, _I64, _P, _P, _P, _P]),
+    "tdx_dinftranslimaccum_strip": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _P, _P, _P, _F, _P, _F, _P, _F, C.c_int, _P, _P, _I64, _P, _P, _P, _P]),
+    "tdx_tool_dinfconclimaccum": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_float]),
+    "tdx_tool_dinftranslimaccum": (C.c_int, [C.c_char_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_synth_dem_dev": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _I64, _I64, _P]),
     "tdx_raster_info_read": (C.c_int, [C.c_char_p, C.POINTER(TdxRasterInfo)]),
     "tdx_raster_read": (C.c_int, [C.c_char_p, C.c_int, _P, _P, _P]),

@@ -302,6 +302,53 @@ class Context:
                                                    float(w_nodata), pr, pm, C.byref(st)), self._h)
         return (racc, dmax, st.as_dict()) if stats else (racc, dmax)
 
+    def dinfconclimaccum(self, ang, dm, dg, q, csol=1.0, nodata=float(ANG_NODATA), dm_nodata=-9999.0, q_nodata=-9999.0, dx=1.0, dy=1.0, contcheck=True,
+                         outlets=None, stats=False):
+        """ctpt = dsllArea(ang, dm, dg, q)  (src/DinfConcLimAccum.cpp:61): dg int16, ctpt float32 (nodata -FLT_MAX)."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        ctpt = self._out(ang, np.float32, (ny, nx))
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        pm, mdev = self._ptr(dm, np.float32, (ny, nx), "dm")
+        pg, gdev = self._ptr(dg, np.int16, (ny, nx), "dg")
+        pq, qdev = self._ptr(q, np.float32, (ny, nx), "q")
+        po, _ = self._ptr(ctpt, np.float32, (ny, nx), "ctpt")
+        if mdev != dev or gdev != dev or qdev != dev:
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(ang, dm, dg, q)
+        check(self._pick(dev, "tdx_dinfconclimaccum")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), pm, float(dm_nodata),
+                                                       pg, pq, float(q_nodata), float(csol), int(bool(contcheck)), ox, oy, no, po, C.byref(st)), self._h)
+        del keep
+        return (ctpt, st.as_dict()) if stats else ctpt
+
+    def dinftranslimaccum(self, ang, tsup, tc, cs=None, nodata=float(ANG_NODATA), tsup_nodata=-9999.0, tc_nodata=-9999.0, cs_nodata=-9999.0, dx=1.0, dy=1.0,
+                          contcheck=True, outlets=None, stats=False):
+        """tla, tdep, ctpt = tlaccum(ang, tsup, tc[, cs])  (src/DinfTransLimAccum.cpp:61): float32, nodata -FLT_MAX; ctpt is None without cs."""
+        ny, nx = ang.shape
+        dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+        tla = self._out(ang, np.float32, (ny, nx))
+        dep = self._out(ang, np.float32, (ny, nx))
+        cso = self._out(ang, np.float32, (ny, nx)) if cs is not None else None
+        pa, dev = self._ptr(ang, np.float32, name="ang")
+        ps, sdev = self._ptr(tsup, np.float32, (ny, nx), "tsup")
+        pc, cdev = self._ptr(tc, np.float32, (ny, nx), "tc")
+        pi, idev = self._ptr(cs, np.float32, (ny, nx), "cs")
+        pt, _ = self._ptr(tla, np.float32, (ny, nx), "tla")
+        pd, _ = self._ptr(dep, np.float32, (ny, nx), "tdep")
+        po, _ = self._ptr(cso, np.float32, (ny, nx), "ctpt")
+        if sdev != dev or cdev != dev or (cs is not None and idev != dev):
+            raise ValueError("all rasters must be on the same side (host or device)")
+        ox, oy, no, keep = self._outlets(outlets)
+        st = TdxStats()
+        self._sync_torch(ang, tsup, tc, cs)
+        check(self._pick(dev, "tdx_dinftranslimaccum")(self._h, pa, nx, ny, float(nodata), C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), ps,
+                                                        float(tsup_nodata), pc, float(tc_nodata), pi, float(cs_nodata), int(bool(contcheck)), ox, oy, no, pt, pd, po,
+                                                        C.byref(st)), self._h)
+        del keep
+        return (tla, dep, cso, st.as_dict()) if stats else (tla, dep, cso)
+
     def synth_dem(self, n_or_shape, seed=1234, x0=0, y0=0, base_wavelength=None, out=None):
         """Seeded fractal DEM generated on the device (torch tensor on cuda:<device>)."""
         import torch

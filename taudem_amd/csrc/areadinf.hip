@@ -12,6 +12,7 @@
 // libm (one value per row); everything else is exactly-rounded +,-,/ on the device.
 #include "context.hpp"
 #include "device_common.hpp"
+#include "dinf_outlets.hpp"
 #include "dinf_prop.hpp"
 #include "flats.hpp"
 #include "strips.hpp"
@@ -30,7 +31,7 @@ constexpr int32_t CNT_SOURCE = -1;
 constexpr uint32_t DINF_PENDING_BITS = 0x7FC0DEADu;
 constexpr int32_t CNT_DONE = -2;       // evaluated: what a strip neighbour looks for in the exchanged boundary rows
 constexpr int WALK_STACK = 48;
-constexpr float ANG_OUTSIDE = 100.0f, ANG_SINK = 200.0f;   // re-coded angles of outlets mode, see dinf_apply_reach_kernel
+constexpr float ANG_OUTSIDE = TDX_ANG_OUTSIDE, ANG_SINK = TDX_ANG_SINK;   // re-coded angles of outlets mode (dinf_outlets.hpp)
 
 // does neighbour k of (x,y) drain into (x,y)?  returns the proportion (>0) or a value <= 0
 __device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, const RowProp* __restrict__ rows, int nx, int ny, int x, int y,
@@ -527,32 +528,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     float* ang_use = d_ang;
     if (n_outlets >= 0) {
-        // upstream closure of the outlets, then the ordinary sweep on the re-coded angles
-        TdxSpan sp(ctx, TDX_K_BFS);
-        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
-        const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
-        int32_t* reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
-        uint8_t* mask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
-        float* aprime = static_cast<float*>(ctx->scratch(TDX_S_P, n * 4));
-        uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
-        unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
-        int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
-        if (!reach || !mask || !aprime || !flags || !counts || !d_oxy) return TDX_ERR_NOMEM;
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(reach, 0, n * 4, s));
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
-        hipLaunchKernelGGL(dinf_reach_mask_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, mask);
-        if (n_outlets > 0) {
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(dinf_reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets),
-                               inx, st.y0, st.y1, geom.tiles_x, reach, flags);
-        }
-        int64_t rr = 0, ll = 0;
-        rc = reach_closure(ctx, st, reach, mask, flags, flags + ntiles, counts, &rr, &ll);
+        rc = dinf_outlet_recode(ctx, st, d_ang, ang_nodata, d_rows, outlet_x, outlet_y, n_outlets, &ang_use, stats);
         if (rc != TDX_OK) return rc;
-        hipLaunchKernelGGL(dinf_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_ang, reach, n, ang_nodata, aprime);
-        ang_use = aprime;
-        if (stats) stats->launches[TDX_K_BFS] += ll;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     }
     uint32_t* info32 = nullptr;
@@ -749,6 +726,39 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
 }
 
 }  // namespace
+
+int dinf_outlet_recode(tdx_context* ctx, const Strip& st, const float* d_ang, float ang_nodata, const RowProp* d_rows, const int32_t* outlet_x,
+                       const int32_t* outlet_y, int64_t n_outlets, float** ang_use, tdx_stats* stats) {
+    hipStream_t s = ctx->stream;
+    const int inx = st.nx, iny = st.ny_arr;
+    const size_t n = size_t(inx) * size_t(iny);
+    TdxSpan sp(ctx, TDX_K_BFS);
+    const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+    const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y);
+    int32_t* reach = static_cast<int32_t*>(ctx->scratch(TDX_S_N, n * 4));
+    uint8_t* mask = static_cast<uint8_t*>(ctx->scratch(TDX_S_O, n));
+    float* aprime = static_cast<float*>(ctx->scratch(TDX_S_P, n * 4));
+    uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
+    unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+    int32_t* d_oxy = static_cast<int32_t*>(ctx->scratch(TDX_S_R, size_t(n_outlets ? n_outlets : 1) * 8));
+    if (!reach || !mask || !aprime || !flags || !counts || !d_oxy) return TDX_ERR_NOMEM;
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(reach, 0, n * 4, s));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
+    hipLaunchKernelGGL(dinf_reach_mask_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, d_rows, mask);
+    if (n_outlets > 0) {
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(dinf_reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets), inx,
+                           st.y0, st.y1, geom.tiles_x, reach, flags);
+    }
+    int64_t rr = 0, ll = 0;
+    int rc = reach_closure(ctx, st, reach, mask, flags, flags + ntiles, counts, &rr, &ll);
+    if (rc != TDX_OK) return rc;
+    hipLaunchKernelGGL(dinf_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_ang, reach, n, ang_nodata, aprime);
+    *ang_use = aprime;
+    if (stats) stats->launches[TDX_K_BFS] += ll;
+    return TDX_OK;
+}
 
 extern "C" int tdx_areadinf_dev(tdx_context* ctx, const float* d_ang, int64_t nx, int64_t ny, float ang_nodata,
                                 const double* dxc, const double* dyc, const float* d_w, int contcheck,

@@ -8,6 +8,8 @@
 //   tdx_tool_dinfflowdir     <- setdir()    src/dinf.cpp:109-284
 //   tdx_tool_areadinf        <- area()      src/areadinf.cpp:53-300
 //   tdx_tool_dinfdecayaccum  <- dmarea()    src/dinfdecayaccum.cpp:61-324
+//   tdx_tool_dinfconclimaccum  <- dsllArea()  src/DinfConcLimAccum.cpp:61-326
+//   tdx_tool_dinftranslimaccum <- tlaccum()   src/DinfTransLimAccum.cpp:61-372
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -330,6 +332,132 @@ int tdx_tool_dinfupdependence(const char* angfile, const char* dgfile, const cha
     printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt, writet - computet,
            writet - begint);
     print_gpu_stats("dinfupdependence", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
+int tdx_tool_dinfconclimaccum(const char* angfile, const char* ctptfile, const char* dmfile, const char* datasrc, const char* /*lyrname*/, int /*uselyrname*/,
+                              int /*lyrno*/, const char* qfile, const char* dgfile, int useOutlets, int contcheck, float cSol) {
+    printf("DinfConcLimAccum version %s\n", TDVERSION);
+    const double begint = now_s();
+    Raster ang, dm, dg, q;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, ang.info, ox, oy); if (rc != TDX_OK) return rc; }
+    rc = load_raster(dmfile, tdx::DType::F32, dm);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, dm.info, dmfile)) { printf("File sizes do not match\n%s\n", dmfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    rc = load_raster(dgfile, tdx::DType::I16, dg);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, dg.info, dgfile)) { printf("File sizes do not match\n%s\n", dgfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    rc = load_raster(qfile, tdx::DType::F32, q);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, q.info, qfile)) { printf("File sizes do not match\n%s\n", qfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    const double readt = now_s();
+    std::vector<float> out(ang.f.size());
+    tdx_stats st;
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            float* d_dm = j.strip<float>(dm.f.data());
+            float* d_q = j.strip<float>(q.f.data());
+            int16_t* d_dg = j.strip<int16_t>(dg.s.data());
+            float* d_out = j.strip<float>(nullptr);
+            if (!d_ang || !d_dm || !d_q || !d_dg || !d_out) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_dinfconclimaccum_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_dm, (float)dm.info.nodata, d_dg,
+                                                     d_q, (float)q.info.nodata, cSol, contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? lrow.data() : nullptr,
+                                                     useOutlets ? int64_t(ox.size()) : -1, d_out, s);
+            return e != TDX_OK ? e : (j.fetch(out.data(), d_out) ? TDX_OK : TDX_ERR_HIP);
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinfconclimaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(), dm.f.data(),
+                                  (float)dm.info.nodata, dg.s.data(), q.f.data(), (float)q.info.nodata, cSol, contcheck, useOutlets ? ox.data() : nullptr,
+                                  useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, out.data(), &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
+    const double computet = now_s();
+    rc = save_raster(ctptfile, tdx::DType::F32, out.data(), ang.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt, writet - computet,
+           writet - begint);
+    print_gpu_stats("dinfconclimaccum", st, ang.info.nx * ang.info.ny);
+    return 0;
+}
+
+int tdx_tool_dinftranslimaccum(const char* angfile, const char* tsupfile, const char* tcfile, const char* tlafile, const char* depfile, const char* cinfile,
+                               const char* coutfile, const char* datasrc, const char* /*lyrname*/, int /*uselyrname*/, int /*lyrno*/, int useOutlets, int usec,
+                               int contcheck) {
+    printf("DinfTransLimAccum version %s\n", TDVERSION);
+    const double begint = now_s();
+    Raster ang, tsup, tc, cin;
+    int rc = load_raster(angfile, tdx::DType::F32, ang);
+    if (rc != TDX_OK) return rc;
+    std::vector<int32_t> ox, oy;
+    if (useOutlets == 1) { rc = load_outlets(datasrc, ang.info, ox, oy); if (rc != TDX_OK) return rc; }
+    rc = load_raster(tsupfile, tdx::DType::F32, tsup);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, tsup.info, tsupfile)) { printf("File sizes do not match\n%s\n", tsupfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    rc = load_raster(tcfile, tdx::DType::F32, tc);
+    if (rc != TDX_OK) return rc;
+    if (!compare_rasters(ang.info, angfile, tc.info, tcfile)) { printf("File sizes do not match\n%s\n", tcfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    if (usec == 1) {
+        rc = load_raster(cinfile, tdx::DType::F32, cin);
+        if (rc != TDX_OK) return rc;
+        if (!compare_rasters(ang.info, angfile, cin.info, cinfile)) { printf("File sizes do not match\n%s\n", cinfile); fflush(stdout); return TDX_ERR_OUTLETS; }
+    }
+    const double readt = now_s();
+    std::vector<float> tla(ang.f.size()), dep(ang.f.size()), cso(usec ? ang.f.size() : 0);
+    tdx_stats st;
+    const int nproc = tool_gpus();
+    if (nproc > 1) {
+        rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
+            float* d_ang = j.strip<float>(ang.f.data());
+            float* d_ts = j.strip<float>(tsup.f.data());
+            float* d_tc = j.strip<float>(tc.f.data());
+            float* d_ci = usec ? j.strip<float>(cin.f.data()) : nullptr;
+            float* d_tla = j.strip<float>(nullptr);
+            float* d_dep = j.strip<float>(nullptr);
+            float* d_co = usec ? j.strip<float>(nullptr) : nullptr;
+            if (!d_ang || !d_ts || !d_tc || !d_tla || !d_dep || (usec && (!d_ci || !d_co))) return TDX_ERR_NOMEM;
+            const std::vector<double> dxs = j.rows_of(ang.info.dxc), dys = j.rows_of(ang.info.dyc);
+            const std::vector<int32_t> lrow = j.local_rows(oy);
+            const int e = tdx_dinftranslimaccum_strip(j.ctx, j.comm, d_ang, j.nx, j.nyl, (float)ang.info.nodata, dxs.data(), dys.data(), d_ts, (float)tsup.info.nodata, d_tc,
+                                                      (float)tc.info.nodata, d_ci, usec ? (float)cin.info.nodata : 0.f, contcheck, useOutlets ? ox.data() : nullptr,
+                                                      useOutlets ? lrow.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, d_tla, d_dep, d_co, s);
+            if (e != TDX_OK) return e;
+            if (!j.fetch(tla.data(), d_tla) || !j.fetch(dep.data(), d_dep) || (usec && !j.fetch(cso.data(), d_co))) return TDX_ERR_HIP;
+            return TDX_OK;
+        });
+        if (rc != TDX_OK) return rc;
+    } else {
+        CtxGuard g;
+        if (g.rc != TDX_OK) return g.rc;
+        rc = tdx_dinftranslimaccum(g.c, ang.f.data(), ang.info.nx, ang.info.ny, (float)ang.info.nodata, ang.info.dxc.data(), ang.info.dyc.data(), tsup.f.data(),
+                                   (float)tsup.info.nodata, tc.f.data(), (float)tc.info.nodata, usec ? cin.f.data() : nullptr, usec ? (float)cin.info.nodata : 0.f,
+                                   contcheck, useOutlets ? ox.data() : nullptr, useOutlets ? oy.data() : nullptr, useOutlets ? int64_t(ox.size()) : -1, tla.data(),
+                                   dep.data(), usec ? cso.data() : nullptr, &st);
+        if (rc != TDX_OK) { report(g.c); return rc; }
+    }
+    const double computet = now_s();
+    rc = save_raster(tlafile, tdx::DType::F32, tla.data(), ang.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    rc = save_raster(depfile, tdx::DType::F32, dep.data(), ang.info, (double)TDX_ANG_NODATA);
+    if (rc != TDX_OK) return rc;
+    if (usec == 1) {
+        rc = save_raster(coutfile, tdx::DType::F32, cso.data(), ang.info, (double)TDX_ANG_NODATA);
+        if (rc != TDX_OK) return rc;
+    }
+    const double writet = now_s();
+    printf("Processors: %d\nRead time: %f\nCompute time: %f\nWrite time: %f\nTotal time: %f\n", nproc, readt - begint, computet - readt, writet - computet,
+           writet - begint);
+    print_gpu_stats("dinftranslimaccum", st, ang.info.nx * ang.info.ny);
     return 0;
 }
 

@@ -172,7 +172,7 @@ struct Lds {
     typename Alg::Cell v[LH * LH];
     typename Alg::Aux aux[Alg::HAS_AUX ? TS * TS : 1];
     float dist[Alg::HAS_DIST ? TS * 9 : 1];
-    double rows[Alg::HAS_ROWS ? TS : 1];   // per-row value of the tile's rows (D-infinity: a2 = atan2(dy, dx))
+    double rows[Alg::HAS_ROWS ? LH : 1];   // per-row value of the tile's rows and the ring rows, window row ly + 1 (D-infinity: a2 = atan2(dy, dx))
     uint32_t info[TS * TS];
     uint32_t cnt[TS * TS / 4];   // one byte per cell: contributors still pending (255: not a pending cell of this rank)
     uint16_t q[2][QCAP];         // ready cells handed on to the next phase (a finished cell may release several)
@@ -223,7 +223,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             if (Alg::HAS_AUX) { if (A.aux) sa[r] = A.aux[idx]; else sa[r] = typename Alg::Aux{}; }
         }
         double srow = 0.;
-        if (Alg::HAS_ROWS && tid < TS) srow = A.rows[y0 + tid >= g.ny ? g.ny - 1 : y0 + tid];
+        if (Alg::HAS_ROWS && tid < LH) { const int gy = y0 - 1 + tid; srow = A.rows[gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy)]; }
         float sdist = 0.f;
         if (Alg::HAS_DIST && tid < TS * 9) { const int gy = y0 + tid / 9; sdist = A.dist[size_t(gy >= g.ny ? g.ny - 1 : gy) * 9 + size_t(tid % 9)]; }
 #pragma unroll
@@ -237,7 +237,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             if (Alg::HAS_AUX) S.aux[(ry0 + r) * TS + lx] = sa[r];
         }
         if (Alg::HAS_DIST && tid < TS * 9) S.dist[tid] = sdist;
-        if (Alg::HAS_ROWS && tid < TS) S.rows[tid] = srow;
+        if (Alg::HAS_ROWS && tid < LH) S.rows[tid] = srow;
     }
     __syncthreads();
     unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet) and can become ready

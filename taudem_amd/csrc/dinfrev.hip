@@ -91,7 +91,7 @@ struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 if (!r.on[t] || !((inf >> (r.k[t] - 1)) & 1u)) continue;   // prop > 0, inside the raster, with an angle
-                const double p = prop_dev(a.x, r.k[t], S.rows[ly]);
+                const double p = prop_dev(a.x, r.k[t], S.rows[ly + 1]);
                 float depp = 0.f;
 #pragma unroll
                 for (int k = 1; k <= 8; k++) if (k == r.k[t]) depp = nb[k];
@@ -125,7 +125,7 @@ struct RevAccAlg {   // src/DinfRevAccum.cpp:176-199; record = {racc, dmax}
 #pragma unroll
                 for (int k = 1; k <= 8; k++) if (k == r.k[t]) n = nb[k];
                 if (is_nodata_f(n.x, TDX_ANG_NODATA)) continue;        // a receiver whose weight was nodata
-                const double p = prop_dev(a.x, r.k[t], S.rows[ly]);
+                const double p = prop_dev(a.x, r.k[t], S.rows[ly + 1]);
                 const float valn = (float)(p * n.x);
                 racc = racc + valn;
                 if (n.y > dmax) dmax = n.y;

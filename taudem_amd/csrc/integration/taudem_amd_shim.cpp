@@ -33,6 +33,10 @@ int depgrd(char* angfile, char* dgfile, char* depfile)
 { return tdx_tool_dinfupdependence(angfile, dgfile, depfile); }
 int dsaccum(char* angfile, char* wgfile, char* raccfile, char* dmaxfile)
 { return tdx_tool_dinfrevaccum(angfile, wgfile, raccfile, dmaxfile); }
+int dsllArea(char* angfile, char* ctptfile, char* dmfile, char* datasrc, char* lyrname, int uselyrname, int lyrno, char* qfile, char* dgfile, int useOutlets, int contcheck, float cSol)
+{ return tdx_tool_dinfconclimaccum(angfile, ctptfile, dmfile, datasrc, lyrname, uselyrname, lyrno, qfile, dgfile, useOutlets, contcheck, cSol); }
+int tlaccum(char* angfile, char* tsupfile, char* tcfile, char* tlafile, char* depfile, char* cinfile, char* coutfile, char* datasrc, char* lyrname, int uselyrname, int lyrno, int useOutlets, int usec, int contcheck)
+{ return tdx_tool_dinftranslimaccum(angfile, tsupfile, tcfile, tlafile, depfile, cinfile, coutfile, datasrc, lyrname, uselyrname, lyrno, useOutlets, usec, contcheck); }
 int threshold(char* ssafile, char* srcfile, char* maskfile, float thresh, int usemask)
 { return tdx_tool_threshold(ssafile, srcfile, maskfile, thresh, usemask); }
 

@@ -78,3 +78,15 @@ def depgrd(angfile, dgfile, depfile):
 def dsaccum(angfile, wgfile, raccfile, dmaxfile):
     """src/DinfRevAccum.cpp:51"""
     return _lib.load().tdx_tool_dinfrevaccum(_b(angfile), _b(wgfile), _b(raccfile), _b(dmaxfile))
+
+
+def dsllArea(angfile, ctptfile, dmfile, datasrc="", lyrname="", uselyrname=0, lyrno=0, qfile="", dgfile="", useOutlets=0, contcheck=1, cSol=1.0):
+    """src/DinfConcLimAccum.cpp:61"""
+    return _lib.load().tdx_tool_dinfconclimaccum(_b(angfile), _b(ctptfile), _b(dmfile), _b(datasrc), _b(lyrname), int(uselyrname), int(lyrno), _b(qfile), _b(dgfile),
+                                                 int(useOutlets), int(contcheck), float(cSol))
+
+
+def tlaccum(angfile, tsupfile, tcfile, tlafile, depfile, cinfile="", coutfile="", datasrc="", lyrname="", uselyrname=0, lyrno=0, useOutlets=0, usec=0, contcheck=1):
+    """src/DinfTransLimAccum.cpp:61"""
+    return _lib.load().tdx_tool_dinftranslimaccum(_b(angfile), _b(tsupfile), _b(tcfile), _b(tlafile), _b(depfile), _b(cinfile), _b(coutfile), _b(datasrc), _b(lyrname),
+                                                  int(uselyrname), int(lyrno), int(useOutlets), int(usec), int(contcheck))

@@ -1,4 +1,4 @@
-"""The reverse D-infinity flow algebra (DinfUpDependence, DinfRevAccum): the C restatement against the rasters
+"""The D-infinity flow algebra tools of SURVEY.md 8f rank 4 (DinfUpDependence, DinfRevAccum, DinfConcLimAccum, DinfTransLimAccum): the C restatement against the rasters
 of the real reference tools (CPU), and the HIP path against both (GPU) - bit for bit when fed the reference's own angles."""
 import os
 import subprocess
@@ -22,6 +22,53 @@ def test_oracle_matches_reference(name, oracle):
     racc, dmax = oracle.dinfrevaccum(g["ang"], h["wg"], dx=g["dxc"], dy=g["dyc"])
     assert bits_equal(racc, h["racc"]), describe_diff(racc, h["racc"], "racc")
     assert bits_equal(dmax, h["dmax"]), describe_diff(dmax, h["dmax"], "dmax")
+
+
+def _outl(h):
+    return np.ascontiguousarray(h["outlets_xy"][:, 0]), np.ascontiguousarray(h["outlets_xy"][:, 1])   # (column indices, row indices)
+
+
+CONC_RUNS = [("ctpt", dict(csol=2.5)), ("ctpt_nc", dict(contcheck=False)), ("ctpt_outlets_nc", dict(contcheck=False, outlets=True))]
+TRANS_RUNS = [(("tla", "tdep", None), dict()), (("tla_cs_nc", "tdep_cs_nc", "tctpt_cs_nc"), dict(cs=True, contcheck=False)),
+              (("tla_cs_outlets_nc", "tdep_cs_outlets_nc", "tctpt_cs_outlets_nc"), dict(cs=True, contcheck=False, outlets=True))]
+
+
+def _run_limited(impl, g, h):
+    """Every DinfConcLimAccum / DinfTransLimAccum run of the golden generator through `impl` (the oracle module or a Context)."""
+    out = {}
+    ang = np.ascontiguousarray(g["ang"])
+    for key, kw in CONC_RUNS:
+        kw = dict(kw)
+        if kw.pop("outlets", False):
+            kw["outlets"] = _outl(h)
+        out[key] = impl.dinfconclimaccum(ang, h["dm2"], h["dgs"], h["q"], dx=g["dxc"], dy=g["dyc"], **kw)
+    for keys, kw in TRANS_RUNS:
+        kw = dict(kw)
+        if kw.pop("outlets", False):
+            kw["outlets"] = _outl(h)
+        if kw.pop("cs", False):
+            kw["cs"] = h["cs"]
+        res = impl.dinftranslimaccum(ang, h["tsup"], h["tc"], dx=g["dxc"], dy=g["dyc"], **kw)
+        for k, r in zip(keys, res):
+            if k:
+                out[k] = r
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_limited_accumulations_match_reference(name, oracle):
+    g, h = load_golden(name), load_golden_flowalg(name)
+    assert int((h["ctpt_outlets_nc"] > -1e30).sum()) > 10 and int((h["tla"] > -1e30).sum()) > 1000   # the goldens are not trivially empty
+    for k, r in _run_limited(oracle, g, h).items():
+        assert bits_equal(r, h[k]), describe_diff(r, h[k], k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_limited_accumulations_match_reference(name, ctx):
+    g, h = load_golden(name), load_golden_flowalg(name)
+    for k, r in _run_limited(ctx, g, h).items():
+        assert bits_equal(r, h[k]), describe_diff(r, h[k], k)
 
 
 @pytest.mark.gpu
@@ -79,3 +126,85 @@ def test_cli(tmp_path, ngpus):
         a, info = T.read_raster(f(name + ".tif"), np.float32)
         assert bits_equal(a, h[key]), describe_diff(a, h[key], key)
     assert T.raster_info(f("xdep.tif"))["nodata"] == -1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ngpus", [1, 3])
+def test_cli_limited_accumulations(tmp_path, ngpus):
+    """bin/dinfconclimaccum and bin/dinftranslimaccum (flags of src/DinfConcLimAccummn.cpp, src/DinfTransLimAccummn.cpp) on files, one GPU and
+    three row strips, against the rasters of the reference tools."""
+    g, h = load_golden("holes"), load_golden_flowalg("holes")
+    ny, nx = g["ang"].shape
+    dx, dy = float(g["dx"]), float(g["dy"])
+    gt = (1000.0, dx, 0.0, 5000.0 + dy * ny, 0.0, -dy)
+    f = lambda s: str(tmp_path / s)  # noqa: E731
+    T.write_raster(f("xang.tif"), np.ascontiguousarray(g["ang"]), -3.402823466e38, geotransform=gt)
+    for nm, key in (("xdm", "dm2"), ("xq", "q"), ("xtsup", "tsup"), ("xtc", "tc"), ("cs", "cs")):
+        T.write_raster(f(nm + ".tif"), np.ascontiguousarray(h[key]), -9999.0, geotransform=gt)
+    T.write_raster(f("xdg.tif"), np.ascontiguousarray(h["dgs"]), -1, geotransform=gt)
+    with open(f("outlets.txt"), "w") as fo:
+        for x, y in h["outlets_xy"]:
+            fo.write(f"{float(gt[0] + (int(x) + 0.5) * gt[1])!r} {float(gt[3] + (int(y) + 0.5) * gt[5])!r}\n")
+    N = ["--gpus", str(ngpus)] if ngpus > 1 else []
+
+    def run(tool, *args):
+        r = subprocess.run([os.path.join(BIN, tool), *args], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    def same(path, key):
+        a, _ = T.read_raster(path, np.float32)
+        assert bits_equal(a, h[key]), describe_diff(a, h[key], key)
+
+    out = run("dinfconclimaccum", *N, f("x.tif"))                     # simple usage: xang / xdg / xdm / xq -> xctpt, csol 1
+    assert "DinfConcLimAccum version 5.4.0" in out and f"Processors: {ngpus}" in out
+    base = ["-ang", f("xang.tif"), "-dg", f("xdg.tif"), "-dm", f("xdm.tif"), "-q", f("xq.tif")]
+    run("dinfconclimaccum", *base, "-ctpt", f("c25.tif"), "-csol", "2.5", *N)
+    same(f("c25.tif"), "ctpt")
+    run("dinfconclimaccum", *base, "-ctpt", f("cnc.tif"), "-nc", *N)
+    same(f("cnc.tif"), "ctpt_nc")
+    run("dinfconclimaccum", *base, "-ctpt", f("co.tif"), "-nc", "-o", f("outlets.txt"), *N)
+    same(f("co.tif"), "ctpt_outlets_nc")
+    assert T.raster_info(f("xctpt.tif"))["nodata"] == pytest.approx(-3.402823466e38)
+
+    out = run("dinftranslimaccum", *N, f("x.tif"))                    # simple usage: xang / xtsup / xtc -> xtla, xtdep
+    assert "DinfTransLimAccum version 5.4.0" in out
+    same(f("xtla.tif"), "tla")
+    same(f("xtdep.tif"), "tdep")
+    tb = ["-ang", f("xang.tif"), "-tsup", f("xtsup.tif"), "-tc", f("xtc.tif")]
+    run("dinftranslimaccum", *tb, "-tla", f("t2.tif"), "-tdep", f("d2.tif"), "-cs", f("cs.tif"), "-ctpt", f("c2.tif"), "-nc", *N)
+    same(f("t2.tif"), "tla_cs_nc"); same(f("d2.tif"), "tdep_cs_nc"); same(f("c2.tif"), "tctpt_cs_nc")
+    run("dinftranslimaccum", *tb, "-tla", f("t3.tif"), "-tdep", f("d3.tif"), "-cs", f("cs.tif"), "-ctpt", f("c3.tif"), "-nc", "-o", f("outlets.txt"), *N)
+    same(f("t3.tif"), "tla_cs_outlets_nc"); same(f("d3.tif"), "tdep_cs_outlets_nc"); same(f("c3.tif"), "tctpt_cs_outlets_nc")
+    run("dinftranslimaccum", *tb, "-tla", f("t4.tif"), "-tdep", f("d4.tif"), "-cs", f("cs.tif"), *N)   # -cs without -ctpt: no concentration
+    same(f("t4.tif"), "tla")
+
+
+@pytest.mark.gpu
+def test_gpu_limited_vs_oracle_larger(ctx, oracle):
+    """Both limited accumulations on a 1100 x 900 raster with nodata holes (several tiles in both geometries), against the restatement."""
+    rng = np.random.default_rng(77)
+    dem = oracle.synth_dem((1100, 900), 47)
+    dem[300:330, 500:640] = -9999.0
+    ang, _, _ = oracle.dinfflowdir(oracle.pitremove(dem, -9999.0), -3.0e38, 30.0, 20.0)
+    shp = ang.shape
+    dm = (0.9 + 0.1 * rng.random(shp, dtype=np.float32)).astype(np.float32)
+    dm[rng.random(shp) < 0.001] = -9999.0
+    q = (0.5 + rng.random(shp, dtype=np.float32)).astype(np.float32)
+    q[rng.random(shp) < 0.002] = 0.0
+    dg = (rng.random(shp) < 0.01).astype(np.int16)
+    tsup = rng.random(shp, dtype=np.float32)
+    tc = (rng.random(shp, dtype=np.float32) * 50).astype(np.float32)
+    tc[rng.random(shp) < 0.001] = -9999.0
+    cs = rng.random(shp, dtype=np.float32)
+    outl = (np.array([450, 120], dtype=np.int32), np.array([1000, 700], dtype=np.int32))
+    for kw in (dict(), dict(contcheck=False, outlets=outl)):
+        a = ctx.dinfconclimaccum(ang, dm, dg, q, csol=3.0, dx=30.0, dy=20.0, **kw)
+        b = oracle.dinfconclimaccum(ang, dm, dg, q, csol=3.0, dx=30.0, dy=20.0, **kw)
+        assert bits_equal(a, b), describe_diff(a, b, "ctpt")
+        for c_in in (None, cs):
+            ra = ctx.dinftranslimaccum(ang, tsup, tc, cs=c_in, dx=30.0, dy=20.0, **kw)
+            rb = oracle.dinftranslimaccum(ang, tsup, tc, cs=c_in, dx=30.0, dy=20.0, **kw)
+            for x, y, nm in zip(ra, rb, ("tla", "tdep", "ctpt")):
+                if y is not None:
+                    assert bits_equal(x, y), describe_diff(x, y, nm)
