@@ -178,6 +178,15 @@ def test_cli_limited_accumulations(tmp_path, ngpus):
     same(f("t3.tif"), "tla_cs_outlets_nc"); same(f("d3.tif"), "tdep_cs_outlets_nc"); same(f("c3.tif"), "tctpt_cs_outlets_nc")
     run("dinftranslimaccum", *tb, "-tla", f("t4.tif"), "-tdep", f("d4.tif"), "-cs", f("cs.tif"), *N)   # -cs without -ctpt: no concentration
     same(f("t4.tif"), "tla")
+    # the reference's own unmodified mains on the shim (oracle/Makefile `shimmed`)
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if ngpus == 1 and os.path.exists(os.path.join(ref, "shim_dinfconclimaccum")):
+        for tool, args, path, key in (("dinfconclimaccum", [*base, "-ctpt", f("s1.tif"), "-csol", "2.5"], f("s1.tif"), "ctpt"),
+                                      ("dinftranslimaccum", [*tb, "-tla", f("s2.tif"), "-tdep", f("s3.tif"), "-cs", f("cs.tif"), "-ctpt", f("s4.tif"), "-nc"], f("s4.tif"),
+                                       "tctpt_cs_nc")):
+            r = subprocess.run([os.path.join(ref, "shim_" + tool), *args], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            same(path, key)
 
 
 @pytest.mark.gpu
