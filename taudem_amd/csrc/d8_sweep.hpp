@@ -104,6 +104,8 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
     static constexpr bool HAS_AUX = true;
     static constexpr bool HAS_DIST = false;
     static constexpr bool HAS_ROWS = false;
+    static constexpr int kBulkSweeps = BULK_SWEEPS;
+    static constexpr bool kBulkOnHalo = false;
     // cells whose pending count includes this one: the cell it drains to
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     int mode;            // 0 sum, 1 max, 2 min
@@ -141,6 +143,8 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr bool HAS_AUX = false;
     static constexpr bool HAS_DIST = true;
     static constexpr bool HAS_ROWS = false;
+    static constexpr int kBulkSweeps = BULK_SWEEPS;
+    static constexpr bool kBulkOnHalo = false;
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
     static __host__ __device__ __forceinline__ float4 outside() { const int m1 = -1; float z; memcpy(&z, &m1, 4); return make_float4(-1.0f, -1.0f, z, 0.f); }
@@ -266,9 +270,12 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         for (int k = 1; k <= 8; k++) pb |= pending(Alg::head(nb[k])) ? 1u << (k - 1) : 0u;
         return pb;
     };
-    // ---- bulk: lockstep sweeps over the lane's own cells (ready = no contributor pending), no atomics
-    if (full) {
-        for (int sweep = 0; sweep < BULK_SWEEPS; sweep++) {
+    // ---- bulk: lockstep sweeps over the lane's own cells (ready = no contributor pending), no atomics.  Forward sweeps (one or two
+    // receivers per cell: long thin chains) run a dozen of them on a fresh tile and leave the stream cells to the walks; REVERSE
+    // sweeps fan out (a finished cell releases up to eight senders: a wide front, which would overflow the walks' hand-over queue
+    // again and again) and run them to the end on every activation.
+    if (full || Alg::kBulkOnHalo) {
+        for (int sweep = 0; sweep < Alg::kBulkSweeps; sweep++) {
             bool prog = false;
 #pragma unroll
             for (int rr = 0; rr < RPL; rr++) {

@@ -67,6 +67,8 @@ struct ConcLimAlg {   // src/DinfConcLimAccum.cpp:226-262; record = {ctpt, q, dm
     using Cell = float4;
     using Aux = float;                           // indicator grid value (int bits)
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
+    static constexpr int kBulkSweeps = d8sweep::BULK_SWEEPS;
+    static constexpr bool kBulkOnHalo = false;
     float dm_nodata, q_nodata, csol;
     int contcheck;
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
@@ -104,6 +106,8 @@ struct TransLimAlg {   // src/DinfTransLimAccum.cpp:236-307; record = {tla, csou
     using Cell = float4;
     using Aux = float2;                          // {tsup, tc}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
+    static constexpr int kBulkSweeps = d8sweep::BULK_SWEEPS;
+    static constexpr bool kBulkOnHalo = false;
     float tsup_nodata, tc_nodata, cin_nodata;
     int usec, contcheck;
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }

@@ -77,6 +77,8 @@ struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
     using Cell = float;
     using Aux = float2;                          // {angle, disturbance grid value (int bits)}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
+    static constexpr int kBulkSweeps = 1 << 20;      // to the end: the reverse sweep is a wide front (d8_sweep.hpp)
+    static constexpr bool kBulkOnHalo = true;
     static __device__ __forceinline__ float head(float c) { return c; }
     static __host__ __device__ __forceinline__ float outside() { return -1.0f; }
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { return (inf >> 16) & 0xFFu; }
@@ -106,6 +108,8 @@ struct RevAccAlg {   // src/DinfRevAccum.cpp:176-199; record = {racc, dmax}
     using Cell = float2;
     using Aux = float2;                          // {angle, weight}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
+    static constexpr int kBulkSweeps = 1 << 20;      // to the end: the reverse sweep is a wide front (d8_sweep.hpp)
+    static constexpr bool kBulkOnHalo = true;
     float w_nodata;
     static __device__ __forceinline__ float head(const float2& c) { return c.x; }
     static __host__ __device__ __forceinline__ float2 outside() { return make_float2(TDX_ANG_NODATA, TDX_ANG_NODATA); }
