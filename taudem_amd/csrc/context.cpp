@@ -138,6 +138,7 @@ void tdx_context_destroy(tdx_context* c) {
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_batch) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -17,6 +17,7 @@ struct tdx_context {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // second stream for side-by-side relaxations (created on first use)
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr};   // round batches in flight (tile_relax.hpp), created on first use
     std::string err;
     int num_cus = 256;
 

@@ -924,7 +924,13 @@ struct RoundRunner {
     int ring_len;                        // rounds that fit the count ring before it wraps (TDX_RELAX_RING: test hook)
     bool lds_variant;                    // TDX_RELAX_LDS=1: the LDS-resident tile kernel instead of the register-resident one
     unsigned pull_max;                   // list entries per cursor atomic in large rounds (TDX_RELAX_PULL: test hook)
-    int r = 0, parity = 0, batch = 4, last_batch = 0;
+    // Batches are enqueued and collected through a two-slot queue, so that the host can read the counts of batch k while batch
+    // k + 1 is already running (drive() / tile_relax_run_pair): a host round trip between batches costs ~40 us of idle GPU, a
+    // relaxation has 5-7 of them, a step a dozen relaxations.  parity: flag half of the first round AFTER the collected batches.
+    int r = 0, parity = 0, batch = 4;
+    int r_enq = 0, parity_enq = 0, n_enq = 0, n_col = 0, fl_batch[2] = {0, 0};
+    int ev_base = 0;                     // ctx->ev_batch[ev_base + slot]
+    int batch_max = 64;                  // drive() / the pair lower it: with two batches in flight a whole batch of empty rounds follows the last one
     bool done = false;
     int64_t rounds = 0, launches = 0;
     unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
@@ -951,15 +957,19 @@ struct RoundRunner {
         TDX_HIP_CHECK(ctx, hipMemsetAsync(flags_of(1), 0, size_t(ntiles) * 4, s));
         hipLaunchKernelGGL(first_list_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, list_of(0), sc.counts);
         r = 0; parity = 0;
+        r_enq = 0; parity_enq = 0; n_enq = 0; n_col = 0;
         return TDX_OK;
     }
-    int enqueue() {
+    int enqueue() {   // at most two batches may be in flight
         using namespace tilek;
         if (batch > ring_len - 2) batch = ring_len - 2;
-        if (r + batch + 1 > ring_len) {   // counts[r + batch] (written by the batch's last round) must be inside the ring
-            hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, sc.counts, r);
-            r = 0;
+        if (r_enq + batch + 1 > ring_len) {   // counts[r + batch] (written by the batch's last round) must be inside the ring
+            hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, sc.counts, r_enq);
+            r_enq = 0;
         }
+        const int slot = n_enq & 1;
+        uint64_t* hs = h + slot * 64;
+        const int r = r_enq, parity = parity_enq;   // (shadow the collected state inside this function)
         const bool timed = ctx->kernel_timing && s == ctx->stream;
         // the tail of a relaxation: a small grid launches faster (any grid size is correct, the cursor covers the list)
         const unsigned grid = (rounds > 0 && last_count <= 256ull) ? grid_small : grid_full;
@@ -978,20 +988,53 @@ struct RoundRunner {
             if (timed && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
         }
         launches += batch;
-        last_batch = batch;
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(h, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        fl_batch[slot] = batch;
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(hs, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        hipEvent_t& ev = ctx->ev_batch[ev_base + slot];
+        if (!ev) TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        TDX_HIP_CHECK(ctx, hipEventRecord(ev, s));
+        r_enq += batch;
+        parity_enq = (parity_enq + batch) & 1;
+        n_enq++;
+        if (batch < batch_max) batch = std::min(2 * batch, batch_max);
         return TDX_OK;
     }
-    void collect() {   // the stream must have been synchronised
-        for (int b = 0; b < last_batch; b++) {
-            if (h[b] == 0) { done = true; break; }
-            last_count = h[b];
+    int wait_oldest() {   // the oldest batch in flight has finished and its counts are on the host
+        TDX_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_batch[ev_base + (n_col & 1)]));
+        return TDX_OK;
+    }
+    void collect() {   // the oldest batch in flight; its counts must have arrived (wait_oldest() or a synchronised stream)
+        const int slot = n_col & 1, nb = fl_batch[slot];
+        const uint64_t* hs = h + slot * 64;
+        for (int b = 0; b < nb; b++) {
+            if (hs[b] == 0) { done = true; break; }
+            last_count = hs[b];
             rounds++;
-            if (print_counts) fprintf(stderr, " %llu", (unsigned long long)h[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
+            if (print_counts) fprintf(stderr, " %llu", (unsigned long long)hs[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
         }
-        r += last_batch;
-        parity = (parity + last_batch) & 1;
-        if (batch < 64) batch *= 2;
+        r += nb;
+        parity = (parity + nb) & 1;
+        n_col++;
+    }
+    // to the fixed point with two batches in flight; on return one batch of empty rounds may still be running on `s`
+    static int pipelined_batch_max() {
+        static const int v = getenv("TDX_RELAX_BATCH") ? std::max(2, std::min(atoi(getenv("TDX_RELAX_BATCH")), 64)) : 16;
+        return v;
+    }
+    int drive() {
+        batch_max = pipelined_batch_max();
+        int rc = start();
+        if (rc != TDX_OK) return rc;
+        rc = enqueue();
+        if (rc != TDX_OK) return rc;
+        while (!done) {
+            rc = enqueue();
+            if (rc != TDX_OK) return rc;
+            rc = wait_oldest();
+            if (rc != TDX_OK) return rc;
+            collect();
+        }
+        return TDX_OK;
     }
 };
 
@@ -1006,20 +1049,26 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     }
     TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + 64, nullptr);
+    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + 128, nullptr);
+    B.ev_base = 2;
+    A.batch_max = B.batch_max = RoundRunner<Op>::pipelined_batch_max();
     int rc = A.start();
     if (rc != TDX_OK) return rc;
     rc = B.start();
     if (rc != TDX_OK) return rc;
-    while (!A.done || !B.done) {
-        const bool ra = !A.done, rb = !B.done;
-        if (ra) { rc = A.enqueue(); if (rc != TDX_OK) return rc; }
-        if (rb) { rc = B.enqueue(); if (rc != TDX_OK) return rc; }
-        if (ra) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (rb) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
-        if (ra) A.collect();
-        if (rb) B.collect();
+    rc = A.enqueue();
+    if (rc != TDX_OK) return rc;
+    rc = B.enqueue();
+    if (rc != TDX_OK) return rc;
+    while (!A.done || !B.done) {   // two batches in flight per relaxation: the host reads one batch's counts while the next one runs
+        if (!A.done) { rc = A.enqueue(); if (rc != TDX_OK) return rc; }
+        if (!B.done) { rc = B.enqueue(); if (rc != TDX_OK) return rc; }
+        if (!A.done) { rc = A.wait_oldest(); if (rc != TDX_OK) return rc; A.collect(); }
+        if (!B.done) { rc = B.wait_oldest(); if (rc != TDX_OK) return rc; B.collect(); }
     }
+    // what follows on the context's stream comes after everything on the second one (incl. its last batch of empty rounds)
+    TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream2));
+    TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     if (rounds_out) *rounds_out += A.rounds + B.rounds;
     if (launches_out) *launches_out += A.launches + B.launches;
     return TDX_OK;
@@ -1059,14 +1108,8 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
         run.print_counts = debug_level > 0;
         if (debug_level == 2) fprintf(stderr, "\nrounds(%d tiles):", ntiles);
-        int rc = run.start();
+        int rc = run.drive();
         if (rc != TDX_OK) return rc;
-        while (!run.done) {
-            rc = run.enqueue();
-            if (rc != TDX_OK) return rc;
-            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            run.collect();
-        }
         rounds += run.rounds;
         launches += run.launches;
     }
