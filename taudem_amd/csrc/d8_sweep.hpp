@@ -228,8 +228,14 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         }
         double srow = 0.;
         if (Alg::HAS_ROWS && tid < LH) { const int gy = y0 - 1 + tid; srow = A.rows[gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy)]; }
-        float sdist = 0.f;
-        if (Alg::HAS_DIST && tid < TS * 9) { const int gy = y0 + tid / 9; sdist = A.dist[size_t(gy >= g.ny ? g.ny - 1 : gy) * 9 + size_t(tid % 9)]; }
+        constexpr int NDIST = (TS * 9 + NT - 1) / NT;   // (32 x 32 tiles: 288 table entries for 256 threads)
+        float sdist[NDIST];
+#pragma unroll
+        for (int i = 0; i < NDIST; i++) {
+            const int e = tid + i * NT, ec = e < TS * 9 ? e : TS * 9 - 1;
+            const int gy = y0 + ec / 9;
+            sdist[i] = Alg::HAS_DIST ? A.dist[size_t(gy >= g.ny ? g.ny - 1 : gy) * 9 + size_t(ec % 9)] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < NSTAGE; i++) {
             const int e = tid + i * NT;
@@ -240,7 +246,10 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             S.info[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? si[r] : 0u;
             if (Alg::HAS_AUX) S.aux[(ry0 + r) * TS + lx] = sa[r];
         }
-        if (Alg::HAS_DIST && tid < TS * 9) S.dist[tid] = sdist;
+        if (Alg::HAS_DIST) {
+#pragma unroll
+            for (int i = 0; i < NDIST; i++) if (tid + i * NT < TS * 9) S.dist[tid + i * NT] = sdist[i];
+        }
         if (Alg::HAS_ROWS && tid < LH) S.rows[tid] = srow;
     }
     __syncthreads();

@@ -217,3 +217,43 @@ def test_gpu_limited_vs_oracle_larger(ctx, oracle):
             for x, y, nm in zip(ra, rb, ("tla", "tdep", "ctpt")):
                 if y is not None:
                     assert bits_equal(x, y), describe_diff(x, y, nm)
+
+
+@pytest.mark.gpu
+def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle):
+    """A raster large enough (3100 x 2900 = 8 827 tiles of 32 x 32 > TDX_D8_BULK_UNTIL) that the generic dependency sweep starts on 32 x 32
+    tiles and hands over to 64 x 64 tiles: every tool built on it, forward and reverse, bit for bit against the restatement.  (The
+    directions come from the restatement's FlowDir tools so that both sides sweep the same graph.)"""
+    rng = np.random.default_rng(2024)
+    shape = (3100, 2900)
+    dem = oracle.synth_dem(shape, 61)
+    dem[1200:1260, 800:1100] = -9999.0
+    fel = ctx.pitremove(dem, -9999.0)
+    p, _ = ctx.d8flowdir(fel, -3.0e38, 30.0, 25.0)
+    ang, _ = ctx.dinfflowdir(fel, -3.0e38, 30.0, 25.0)
+    w = (rng.random(shape, dtype=np.float32) * 10.0).astype(np.float32)
+    w[rng.random(shape) < 0.001] = -9999.0
+    outl = (np.array([1450, 300], dtype=np.int32), np.array([2900, 1700], dtype=np.int32))
+
+    def same(a, b, name):
+        assert bits_equal(a, b), describe_diff(a, b, name)
+
+    same(ctx.aread8(p, -32768, weights=w, weights_nodata=-9999.0), oracle.aread8(p, -32768, weights=w, weights_nodata=-9999.0), "weighted ad8")
+    same(ctx.aread8(p, -32768, weights=w, weights_nodata=-9999.0, contcheck=False, outlets=outl),
+         oracle.aread8(p, -32768, weights=w, weights_nodata=-9999.0, contcheck=False, outlets=outl), "weighted ad8, outlets")
+    same(ctx.d8flowpathextremeup(p, w, -32768, usemax=True), oracle.d8flowpathextremeup(p, w, -32768, usemax=True), "ssa")
+    for a, b, nm in zip(ctx.gridnet(p, -32768, 30.0, 25.0), oracle.gridnet(p, -32768, 30.0, 25.0), ("plen", "tlen", "gord")):
+        same(np.asarray(a), np.asarray(b), nm)
+    dm = (0.9 + 0.1 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+    same(ctx.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, weights=np.abs(w)), oracle.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, weights=np.abs(w)), "dsca")
+    dg = (rng.random(shape) < 0.003).astype(np.int32)
+    same(ctx.dinfupdependence(ang, dg, dx=30.0, dy=25.0), oracle.dinfupdependence(ang, dg, dx=30.0, dy=25.0), "dep")
+    for a, b, nm in zip(ctx.dinfrevaccum(ang, w, dx=30.0, dy=25.0), oracle.dinfrevaccum(ang, w, dx=30.0, dy=25.0), ("racc", "dmax")):
+        same(a, b, nm)
+    q = (0.5 + rng.random(shape, dtype=np.float32)).astype(np.float32)
+    same(ctx.dinfconclimaccum(ang, dm, dg.astype(np.int16), q, csol=1.5, dx=30.0, dy=25.0),
+         oracle.dinfconclimaccum(ang, dm, dg.astype(np.int16), q, csol=1.5, dx=30.0, dy=25.0), "ctpt")
+    tc = (rng.random(shape, dtype=np.float32) * 80).astype(np.float32)
+    for a, b, nm in zip(ctx.dinftranslimaccum(ang, np.abs(w), tc, cs=dm, dx=30.0, dy=25.0, contcheck=False, outlets=outl),
+                        oracle.dinftranslimaccum(ang, np.abs(w), tc, cs=dm, dx=30.0, dy=25.0, contcheck=False, outlets=outl), ("tla", "tdep", "ctpt")):
+        same(a, b, nm)
