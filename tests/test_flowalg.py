@@ -257,3 +257,44 @@ def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle):
     for a, b, nm in zip(ctx.dinftranslimaccum(ang, np.abs(w), tc, cs=dm, dx=30.0, dy=25.0, contcheck=False, outlets=outl),
                         oracle.dinftranslimaccum(ang, np.abs(w), tc, cs=dm, dx=30.0, dy=25.0, contcheck=False, outlets=outl), ("tla", "tdep", "ctpt")):
         same(a, b, nm)
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_sweep_tools_three_strips_equal_one_gpu_at_size(ctx, oracle, tmp_path):
+    """3100 x 2900 again, through files and `--gpus 3`: the strip protocol of the generic sweep (record rows exchanged as bit patterns, tiles
+    re-activated by changed halo cells, forward and reverse) must reproduce the one-GPU rasters bit for bit."""
+    rng = np.random.default_rng(77)
+    shape = (3100, 2900)
+    dem = oracle.synth_dem(shape, 62)
+    fel = ctx.pitremove(dem, -9999.0)
+    p, _ = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    ang, _ = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    w = (rng.random(shape, dtype=np.float32) * 10.0).astype(np.float32)
+    tc = (rng.random(shape, dtype=np.float32) * 80).astype(np.float32)
+    gt = (0.0, 30.0, 0.0, 30.0 * shape[0], 0.0, -30.0)
+    f = lambda s: str(tmp_path / s)  # noqa: E731
+    T.write_raster(f("p.tif"), np.ascontiguousarray(p), -32768, geotransform=gt)
+    T.write_raster(f("ang.tif"), np.ascontiguousarray(ang), -3.402823466e38, geotransform=gt)
+    T.write_raster(f("w.tif"), w, -9999.0, geotransform=gt)
+    T.write_raster(f("tc.tif"), tc, -9999.0, geotransform=gt)
+
+    def run(tool, *args):
+        r = subprocess.run([os.path.join(BIN, tool), "--gpus", "3", *args], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ("Processors: 3" in r.stdout or "Processes: 3" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
+
+    def same(path, a, name, dt=np.float32):
+        b, _ = T.read_raster(path, dt)
+        assert bits_equal(b, np.asarray(a)), describe_diff(b, np.asarray(a), name)
+
+    run("aread8", "-p", f("p.tif"), "-ad8", f("ad8w.tif"), "-wg", f("w.tif"))
+    same(f("ad8w.tif"), ctx.aread8(p, -32768, weights=w, weights_nodata=-9999.0), "weighted ad8")
+    run("gridnet", "-p", f("p.tif"), "-plen", f("plen.tif"), "-tlen", f("tlen.tif"), "-gord", f("gord.tif"))
+    pl, tl, go = ctx.gridnet(p, -32768, 30.0, 30.0)
+    same(f("plen.tif"), pl, "plen"); same(f("tlen.tif"), tl, "tlen"); same(f("gord.tif"), go, "gord", np.int16)
+    run("dinfrevaccum", "-ang", f("ang.tif"), "-wg", f("w.tif"), "-racc", f("racc.tif"), "-dmax", f("dmax.tif"))
+    ra, dm = ctx.dinfrevaccum(ang, w, dx=30.0, dy=30.0)
+    same(f("racc.tif"), ra, "racc"); same(f("dmax.tif"), dm, "dmax")
+    run("dinftranslimaccum", "-ang", f("ang.tif"), "-tsup", f("w.tif"), "-tc", f("tc.tif"), "-tla", f("tla.tif"), "-tdep", f("tdep.tif"))
+    tla, tdep, _ = ctx.dinftranslimaccum(ang, w, tc, dx=30.0, dy=30.0)
+    same(f("tla.tif"), tla, "tla"); same(f("tdep.tif"), tdep, "tdep")

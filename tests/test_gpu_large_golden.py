@@ -101,3 +101,39 @@ def test_cpu_large_digests(oracle, n):
     check_digest("p", p, R["p"])
     check_digest("sd8", sd8, R["sd8"])
     check_digest("ad8", oracle.aread8(p, -32768), R["ad8"])
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_reference_digests_through_three_strips(ctx, tmp_path):
+    """The same 4096^2 reference digests, but every tool run as THREE row strips (`--gpus 3`: one thread, one context and one strip per rank,
+    the library's own transport between them - the multi-GPU path at a size where strips hold hundreds of tiles and the sweeps use both
+    tile geometries), files in, files out like the reference run that produced the digests."""
+    import subprocess
+
+    import taudem_amd as T
+
+    cases = _load(LARGE)
+    if "4096" not in cases:
+        pytest.skip("no reference digests for 4096^2")
+    case = cases["4096"]
+    n, R = case["n"], case["rasters"]
+    bin_dir = os.path.join(os.path.dirname(HERE), "taudem_amd", "bin")
+    f = lambda s: str(tmp_path / s)  # noqa: E731
+    dem = ctx.synth_dem(n, seed=case["seed"]).cpu().numpy()
+    gt = (0.0, case["dx"], 0.0, case["dy"] * n, 0.0, -case["dy"])
+    T.write_raster(f("dem.tif"), dem, case["nodata"], geotransform=gt, lzw=False)
+    del dem
+
+    def run(tool, *args):
+        r = subprocess.run([os.path.join(bin_dir, tool), "--gpus", "3", *args], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ("Processors: 3" in r.stdout or "Processes: 3" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
+
+    run("pitremove", "-z", f("dem.tif"), "-fel", f("fel.tif"))
+    run("d8flowdir", "-fel", f("fel.tif"), "-p", f("p.tif"), "-sd8", f("sd8.tif"))
+    run("aread8", "-p", f("p.tif"), "-ad8", f("ad8.tif"))
+    run("dinfflowdir", "-fel", f("fel.tif"), "-ang", f("ang.tif"), "-slp", f("slp.tif"))
+    run("areadinf", "-ang", f("ang.tif"), "-sca", f("sca.tif"))
+    for name, dt in (("fel", np.float32), ("p", np.int16), ("sd8", np.float32), ("ad8", np.float32), ("slp", np.float32), ("ang", np.float32), ("sca", np.float32)):
+        a, _ = T.read_raster(f(name + ".tif"), dt)
+        check_digest(name + " (3 strips)", a, R[name])
