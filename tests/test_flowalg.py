@@ -241,9 +241,18 @@ def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle):
     same(ctx.aread8(p, -32768, weights=w, weights_nodata=-9999.0), oracle.aread8(p, -32768, weights=w, weights_nodata=-9999.0), "weighted ad8")
     same(ctx.aread8(p, -32768, weights=w, weights_nodata=-9999.0, contcheck=False, outlets=outl),
          oracle.aread8(p, -32768, weights=w, weights_nodata=-9999.0, contcheck=False, outlets=outl), "weighted ad8, outlets")
+    same(ctx.aread8(p, -32768, contcheck=False, outlets=outl), oracle.aread8(p, -32768, contcheck=False, outlets=outl), "ad8, outlets (tile contraction)")
     same(ctx.d8flowpathextremeup(p, w, -32768, usemax=True), oracle.d8flowpathextremeup(p, w, -32768, usemax=True), "ssa")
+    same(ctx.d8flowpathextremeup(p, w, -32768, usemax=False, contcheck=False, outlets=outl),
+         oracle.d8flowpathextremeup(p, w, -32768, usemax=False, contcheck=False, outlets=outl), "ssa min, outlets")
     for a, b, nm in zip(ctx.gridnet(p, -32768, 30.0, 25.0), oracle.gridnet(p, -32768, 30.0, 25.0), ("plen", "tlen", "gord")):
         same(np.asarray(a), np.asarray(b), nm)
+    mask = rng.integers(0, 10, shape).astype(np.int32)
+    for a, b, nm in zip(ctx.gridnet(p, -32768, 30.0, 25.0, mask=mask, thresh=2, outlets=outl),
+                        oracle.gridnet(p, -32768, 30.0, 25.0, mask=mask, thresh=2, outlets=outl), ("plen (mask, outlets)", "tlen", "gord")):
+        same(np.asarray(a), np.asarray(b), nm)
+    same(ctx.areadinf(ang, dx=30.0, dy=25.0, weights=np.abs(w), contcheck=False, outlets=outl),
+         oracle.areadinf(ang, dx=30.0, dy=25.0, weights=np.abs(w), contcheck=False, outlets=outl), "sca, weights + outlets")
     dm = (0.9 + 0.1 * rng.random(shape, dtype=np.float32)).astype(np.float32)
     same(ctx.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, weights=np.abs(w)), oracle.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, weights=np.abs(w)), "dsca")
     dg = (rng.random(shape) < 0.003).astype(np.int32)
