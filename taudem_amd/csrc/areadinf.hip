@@ -363,41 +363,49 @@ constexpr int QCAP = 512;
 //         [16:24) contributor k reaches this cell through ITS second target (selects which of its two proportions applies)
 //   P     the two proportions of the cell's own outflow as doubles (the fp64 divisions of prop() leave the serial path)
 // and the result array starts as "pending" on participating owned cells.
-__global__ __launch_bounds__(256) void setup_kernel(const float* __restrict__ ANG, int nx, int ny, int y_own0, int y_own1, float nodata,
-                                                    const RowProp* __restrict__ rows, uint32_t* __restrict__ info, double2* __restrict__ P,
-                                                    float* __restrict__ OUT, float out_nodata) {
+// Two passes (dinf_prop.hpp): the cell's own outflow (two fp64 divisions) -> P and a code byte; then a byte stencil -> info.
+__global__ __launch_bounds__(256) void setup_out_kernel(const float* __restrict__ ANG, size_t n, int nx, int y_own0, int y_own1, float nodata,
+                                                        const RowProp* __restrict__ rows, uint8_t* __restrict__ code, double2* __restrict__ P,
+                                                        float* __restrict__ OUT, float out_nodata) {
+    const size_t idx = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int y = int(idx / size_t(nx));
+    const float ang = ANG[idx];
+    const bool nd = is_nodata_f(ang, nodata), part = !(nd || ang == ANG_OUTSIDE);
+    double2 pp;
+    code[idx] = uint8_t(dinf_code(ang, nd, part, rows[y].a2, &pp.x, &pp.y));
+    P[idx] = pp;
+    if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
+}
+__global__ __launch_bounds__(256) void setup_in_kernel(const uint8_t* __restrict__ code, int nx, int ny, uint32_t* __restrict__ info) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= ny) return;
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    unsigned inf = 0;
-    for (int k = 1; k <= 8; k++) {
+    unsigned c[9];
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {   // all loads first (clamped), validity afterwards
         const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { inf |= 0x100u; continue; }
-        const float an = ANG[size_t(yn) * size_t(nx) + size_t(xn)];
-        if (is_nodata_f(an, nodata)) { inf |= 0x100u; continue; }
-        const double a2n = rows[yn].a2;
-        const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
-        if ((float)prop_dev(an, kk, a2n) > 0.0f) {
-            inf |= 1u << (k - 1);
-            const int s1n = dinf_sector(an, a2n);
-            if ((kk == 0 ? 8 : kk) != s1n) inf |= 1u << (16 + k - 1);   // not its first target: its second
-        }
+        const bool in = xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+        c[k] = code[size_t(in ? yn : y) * size_t(nx) + size_t(in ? xn : x)];
+        if (!in) c[k] = DINF_CODE_NODATA;
     }
-    const float ang = ANG[idx];
-    double2 pp = make_double2(0., 0.);
-    const bool part = !(is_nodata_f(ang, nodata) || ang == ANG_OUTSIDE);
-    if (part) {
-        const double a2 = rows[y].a2;
-        const int s1 = dinf_sector(ang, a2);
-        inf |= unsigned(s1 - 1) << 9;
-        const double p1 = prop_dev(ang, s1, a2), p2 = prop_dev(ang, s1 % 8 + 1, a2);
-        if (p1 > 0.0) { inf |= 1u << 12; pp.x = p1; }
-        if (p2 > 0.0) { inf |= 1u << 13; pp.y = p2; }
+    const unsigned own = code[idx];
+    unsigned inf = 0;
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        if (c[k] == DINF_CODE_NODATA) { inf |= 0x100u; continue; }
+        const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
+        const int via = dinf_code_sends(c[k], kk == 0 ? 8 : kk);
+        if (via) inf |= 1u << (k - 1);
+        if (via == 2) inf |= 1u << (16 + k - 1);                       // not its first target: its second
+    }
+    if (own != DINF_CODE_NODATA && (own & DINF_CODE_PART)) {
+        inf |= (own & 7u) << 9;
+        if (own & DINF_CODE_P1) inf |= 1u << 12;
+        if (own & DINF_CODE_P2) inf |= 1u << 13;
     }
     info[idx] = inf;
-    P[idx] = pp;
-    if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
 }
 
 __device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == DINF_PENDING_BITS; }
@@ -544,8 +552,13 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         if (use_walk)
             hipLaunchKernelGGL(dinf_setup_kernel, grid2d, dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info, cnt, d_out, out_nodata);
         else
-            hipLaunchKernelGGL(dsweep::setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, ang_use, inx, iny, st.y0, st.y1, ang_nodata, d_rows, info32,
-                               d_P, d_out, out_nodata);
+        {
+            uint8_t* code = static_cast<uint8_t*>(ctx->scratch(TDX_S_B, n));
+            if (!code) return TDX_ERR_NOMEM;
+            hipLaunchKernelGGL(dsweep::setup_out_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, ang_use, n, inx, st.y0, st.y1, ang_nodata, d_rows, code, d_P, d_out,
+                               out_nodata);
+            hipLaunchKernelGGL(dsweep::setup_in_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, code, inx, iny, info32);
+        }
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     // halo rows of the result (and of the walk's counters) start as "not evaluated"

@@ -45,3 +45,56 @@ __device__ __forceinline__ int dinf_sector(float ang, double a2) {   // number o
     return sector < 1 ? 1 : sector;
 }
 
+
+// ---- the outflow of a cell as one byte (pass 1 of the setup stencils of the D-infinity sweeps) ------------------------------
+// prop() is positive only for the two directions that bracket the angle (src/commonLib.cpp:83-88): s1 = dinf_sector(angle) and
+// s1 % 8 + 1.  Whether neighbour k drains into a cell - prop(angle_n, (k + 4) % 8) > 0, evaluated eight times per cell by
+// initNeighborDinfup (src/commonLib.cpp:99-131) - is therefore a property of the NEIGHBOUR's own two proportions: pass 1 computes
+// them once per cell (two fp64 divisions instead of ten) and leaves this byte, pass 2 is a byte stencil.
+//   0xFF: no angle (nodata)      else [0:3) s1 - 1, [3] prop(s1) > 0, [4] prop(s1 % 8 + 1) > 0, [5] the cell participates
+constexpr unsigned DINF_CODE_NODATA = 0xFFu, DINF_CODE_P1 = 8u, DINF_CODE_P2 = 16u, DINF_CODE_PART = 32u;
+__device__ __forceinline__ unsigned dinf_code(float ang, bool nodata, bool participates, double a2, double* p1, double* p2) {
+    *p1 = 0.; *p2 = 0.;
+    if (nodata) return DINF_CODE_NODATA;
+    unsigned c = 0;
+    if (participates) {
+        c |= DINF_CODE_PART;
+        const int s1 = dinf_sector(ang, a2);
+        c |= unsigned(s1 - 1);
+        const double q1 = prop_dev(ang, s1, a2), q2 = prop_dev(ang, s1 % 8 + 1, a2);
+        if (q1 > 0.0) { c |= DINF_CODE_P1; *p1 = q1; }
+        if (q2 > 0.0) { c |= DINF_CODE_P2; *p2 = q2; }
+    }
+    return c;
+}
+// does the cell with code `c` send flow in direction kk (1..8)?  0: no, 1: with its first proportion, 2: with its second
+__device__ __forceinline__ int dinf_code_sends(unsigned c, int kk) {
+    if (c == DINF_CODE_NODATA) return 0;
+    const int s1 = int(c & 7u) + 1, s2 = s1 % 8 + 1;
+    if (s1 == kk && (c & DINF_CODE_P1)) return 1;
+    if (s2 == kk && (c & DINF_CODE_P2)) return 2;
+    return 0;
+}
+
+// pass 1 alone (no proportions kept): `inert` = an angle value whose cells have a valid angle but neither send nor participate
+// (TDX_ANG_OUTSIDE of outlets mode; any value no raster holds otherwise)
+static __global__ __launch_bounds__(256) void dinf_code_kernel(const float* __restrict__ ANG, size_t n, int nx, float nodata, float inert,
+                                                               const double* __restrict__ a2row, uint8_t* __restrict__ code) {
+    const size_t idx = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const float ang = ANG[idx];
+    const bool nd = tdxk::is_nodata_f(ang, nodata);
+    double p1, p2;
+    code[idx] = uint8_t(dinf_code(ang, nd, !(nd || ang == inert), a2row[idx / size_t(nx)], &p1, &p2));
+}
+// the 8 neighbour codes of (x, y): loads first (clamped), cells outside the raster read as "no angle"
+__device__ __forceinline__ void dinf_code_window(const uint8_t* __restrict__ code, int nx, int ny, int x, int y, unsigned (&c)[9]) {
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+        const int xn = x + tdxk::d1(k), yn = y + tdxk::d2(k);
+        const bool in = xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+        c[k] = code[size_t(in ? yn : y) * size_t(nx) + size_t(in ? xn : x)];
+        if (!in) c[k] = DINF_CODE_NODATA;
+    }
+    c[0] = code[size_t(y) * size_t(nx) + size_t(x)];
+}

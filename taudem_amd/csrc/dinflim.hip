@@ -31,32 +31,25 @@ constexpr unsigned FINFO_P1 = 1u << 12, FINFO_P2 = 1u << 15;
 
 // Per cell: [0:8) contributors (dependency and value), [8] a neighbour is missing (off the raster or without angle: edge
 // contamination), [9:12) s1 - 1, [12] / [15] prop > 0 towards s1 / s1 % 8 + 1, [13] the cell participates
-__global__ __launch_bounds__(256) void fwd_setup_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata, const RowProp* __restrict__ rows,
-                                                        uint32_t* __restrict__ info) {
+__global__ __launch_bounds__(256) void fwd_setup_kernel(const uint8_t* __restrict__ code, int nx, int ny, uint32_t* __restrict__ info) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= ny) return;
-    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    unsigned c[9];
+    dinf_code_window(code, nx, ny, x, y, c);   // (codes: pass 1, dinf_prop.hpp - two fp64 divisions per cell instead of ten)
     unsigned inf = 0;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
-        const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) { inf |= d8sweep::INFO_CON; continue; }
-        const float an = ANG[size_t(yn) * size_t(nx) + size_t(xn)];
-        if (is_nodata_f(an, nodata)) { inf |= d8sweep::INFO_CON; continue; }
-        const float p = (float)prop_dev(an, (k + 4) % 8, rows[yn].a2);   // `float p` in the reference (src/commonLib.cpp:99)
-        if (p > 0.0f) inf |= 1u << (k - 1);
+        if (c[k] == DINF_CODE_NODATA) { inf |= d8sweep::INFO_CON; continue; }
+        const int kk = (k + 4) % 8;
+        if (dinf_code_sends(c[k], kk == 0 ? 8 : kk)) inf |= 1u << (k - 1);   // `float p > 0` of src/commonLib.cpp:99 == the sender's own proportion > 0
     }
-    const float ang = ANG[idx];
-    if (!is_nodata_f(ang, nodata) && ang != TDX_ANG_OUTSIDE) {
-        inf |= d8sweep::INFO_PART;
-        const double a2 = rows[y].a2;
-        const int s1 = dinf_sector(ang, a2);
-        inf |= unsigned(s1 - 1) << 9;
-        if (prop_dev(ang, s1, a2) > 0.0) inf |= FINFO_P1;
-        if (prop_dev(ang, s1 % 8 + 1, a2) > 0.0) inf |= FINFO_P2;
+    if (c[0] != DINF_CODE_NODATA && (c[0] & DINF_CODE_PART)) {
+        inf |= d8sweep::INFO_PART | ((c[0] & 7u) << 9);
+        if (c[0] & DINF_CODE_P1) inf |= FINFO_P1;
+        if (c[0] & DINF_CODE_P2) inf |= FINFO_P2;
     }
-    info[idx] = inf;
+    info[size_t(y) * size_t(nx) + size_t(x)] = inf;
 }
 __device__ __forceinline__ unsigned fwd_rel_mask(unsigned inf) {
     const int s1 = int((inf >> 9) & 7u) + 1, s2 = s1 % 8 + 1;
@@ -232,7 +225,10 @@ int fwd_prepare(tdx_context* ctx, const Strip& st, float* d_ang, float ang_nodat
     R.flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));   // (after the closure, which uses the same slot)
     if (!R.flags) return TDX_ERR_NOMEM;
     TdxSpan sp(ctx, TDX_K_STENCIL);
-    hipLaunchKernelGGL(fwd_setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, R.ang_use, inx, iny, ang_nodata, R.d_rows, R.info);
+    uint8_t* code = static_cast<uint8_t*>(ctx->scratch(TDX_S_D, n));
+    if (!code) return TDX_ERR_NOMEM;
+    hipLaunchKernelGGL(dinf_code_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, R.ang_use, n, inx, ang_nodata, TDX_ANG_OUTSIDE, R.d_a2, code);
+    hipLaunchKernelGGL(fwd_setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, code, inx, iny, R.info);
     if (stats) stats->launches[TDX_K_STENCIL]++;
     return TDX_OK;
 }
@@ -381,8 +377,8 @@ extern "C" int tdx_dinftranslimaccum(tdx_context* ctx, const float* ang, int64_t
     float* d_c = static_cast<float*>(ctx->scratch(TDX_S_IO2, n * 4));
     float* d_t = static_cast<float*>(ctx->scratch(TDX_S_IO3, n * 4));
     float* d_d = static_cast<float*>(ctx->scratch(TDX_S_IO4, n * 4));
-    float* d_ci = cs ? static_cast<float*>(ctx->scratch(TDX_S_D, n * 4)) : nullptr;
-    float* d_co = cs ? static_cast<float*>(ctx->scratch(TDX_S_E, n * 4)) : nullptr;
+    float* d_ci = cs ? static_cast<float*>(ctx->scratch(TDX_S_E, n * 4)) : nullptr;
+    float* d_co = cs ? static_cast<float*>(ctx->scratch(TDX_S_F, n * 4)) : nullptr;
     if (!d_a || !d_s || !d_c || !d_t || !d_d || (cs && (!d_ci || !d_co))) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_a, ang, n * 4, hipMemcpyHostToDevice, ctx->stream));
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_s, tsup, n * 4, hipMemcpyHostToDevice, ctx->stream));

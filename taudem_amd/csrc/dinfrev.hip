@@ -25,41 +25,31 @@ constexpr unsigned RINFO_P1 = 1u << 12, RINFO_P2 = 1u << 15;
 
 // Per cell: [0:8) receivers that count (dependency), [9:12) s1 - 1, [12] / [15] prop > 0 towards s1 / s1 % 8 + 1, [13] the cell has an
 // angle, [16:24) neighbours that send flow to the cell (they wait for it)
-__global__ __launch_bounds__(256) void rev_setup_kernel(const float* __restrict__ ANG, int nx, int ny, float nodata, const double* __restrict__ a2row,
-                                                        uint32_t* __restrict__ info) {
+__global__ __launch_bounds__(256) void rev_setup_kernel(const uint8_t* __restrict__ code, int nx, int ny, uint32_t* __restrict__ info) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nx || y >= ny) return;
-    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    const float ang = ANG[idx];
+    unsigned c[9];
+    dinf_code_window(code, nx, ny, x, y, c);   // (codes: pass 1, dinf_prop.hpp - two fp64 divisions per cell instead of ten)
     unsigned inf = 0;
-    if (!is_nodata_f(ang, nodata)) {
-        inf |= d8sweep::INFO_PART;
-        const double a2 = a2row[y];
-        const int s1 = dinf_sector(ang, a2);
-        inf |= unsigned(s1 - 1) << 9;
+    if (c[0] != DINF_CODE_NODATA) {
+        inf |= d8sweep::INFO_PART | ((c[0] & 7u) << 9);
+        const int s1 = int(c[0] & 7u) + 1, s2 = s1 % 8 + 1;
+        // receivers that count: prop > 0, inside the raster, with an angle (src/DinfRevAccum.cpp:141-150)
+        unsigned has_angle = 0;   // bit k - 1: neighbour k lies in the raster and has an angle
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int k = t == 0 ? s1 : (s1 % 8 + 1);
-            if (!(prop_dev(ang, k, a2) > 0.0)) continue;
-            inf |= t == 0 ? RINFO_P1 : RINFO_P2;
-            const int xn = x + d1(k), yn = y + d2(k);
-            if (xn >= 0 && xn < nx && yn >= 0 && yn < ny && !is_nodata_f(ANG[size_t(yn) * size_t(nx) + size_t(xn)], nodata)) inf |= 1u << (k - 1);
-        }
-    }
-    // who waits for this cell: neighbours with an angle whose flow reaches it (only meaningful when the cell itself has an angle:
-    // a receiver without one is not counted by its senders)
-    if (inf & d8sweep::INFO_PART) {
+        for (int k = 1; k <= 8; k++) has_angle |= (c[k] != DINF_CODE_NODATA) ? 1u << (k - 1) : 0u;
+        if (c[0] & DINF_CODE_P1) inf |= RINFO_P1 | (has_angle & (1u << (s1 - 1)));
+        if (c[0] & DINF_CODE_P2) inf |= RINFO_P2 | (has_angle & (1u << (s2 - 1)));
+        // who waits for this cell: neighbours with an angle whose flow reaches it (only meaningful when the cell itself has an angle:
+        // a receiver without one is not counted by its senders)
 #pragma unroll
         for (int k = 1; k <= 8; k++) {
-            const int xn = x + d1(k), yn = y + d2(k);
-            if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) continue;
-            const float an = ANG[size_t(yn) * size_t(nx) + size_t(xn)];
-            if (is_nodata_f(an, nodata)) continue;
-            if (prop_dev(an, (k + 4) % 8, a2row[yn]) > 0.0) inf |= 1u << (16 + k - 1);
+            const int kk = (k + 4) % 8;
+            if (dinf_code_sends(c[k], kk == 0 ? 8 : kk)) inf |= 1u << (16 + k - 1);
         }
     }
-    info[idx] = inf;
+    info[size_t(y) * size_t(nx) + size_t(x)] = inf;
 }
 
 // the two receiver directions in ascending k (the reference's loop order), with their proportion slots
@@ -188,7 +178,10 @@ int rev_prepare(tdx_context* ctx, const Strip& st, float* d_ang, float ang_nodat
     int rc = strip_exchange<float>(ctx, st, d_ang, ang_nodata);   // flowData->share()
     if (rc != TDX_OK) return rc;
     TdxSpan sp(ctx, TDX_K_STENCIL);
-    hipLaunchKernelGGL(rev_setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, d_ang, inx, iny, ang_nodata, R.d_a2, R.info);
+    uint8_t* code = static_cast<uint8_t*>(ctx->scratch(TDX_S_D, n));
+    if (!code) return TDX_ERR_NOMEM;
+    hipLaunchKernelGGL(dinf_code_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_ang, n, inx, ang_nodata, -1.0e30f, R.d_a2, code);   // (no outlets mode here)
+    hipLaunchKernelGGL(rev_setup_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, code, inx, iny, R.info);
     if (stats) stats->launches[TDX_K_STENCIL]++;
     return TDX_OK;
 }
