@@ -307,3 +307,38 @@ def test_sweep_tools_three_strips_equal_one_gpu_at_size(ctx, oracle, tmp_path):
     run("dinftranslimaccum", "-ang", f("ang.tif"), "-tsup", f("w.tif"), "-tc", f("tc.tif"), "-tla", f("tla.tif"), "-tdep", f("tdep.tif"))
     tla, tdep, _ = ctx.dinftranslimaccum(ang, w, tc, dx=30.0, dy=30.0)
     same(f("tla.tif"), tla, "tla"); same(f("tdep.tif"), tdep, "tdep")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,seed", [((1, 1), 1), ((1, 9), 2), ((3, 3), 3), ((2, 70), 4), ((65, 64), 5), ((64, 129), 6), ((130, 67), 7)])
+def test_flow_algebra_on_small_and_ragged_rasters(shape, seed, ctx, oracle):
+    """Degenerate and tile-edge shapes (one cell, one row, exactly one tile plus a row / a column) with RANDOM angles - cycles, flow off the
+    raster, nodata angles and inputs everywhere: all four flow-algebra tools and DinfDecayAccum against the restatement."""
+    rng = np.random.default_rng(seed)
+    ang = (rng.random(shape) * 2 * np.pi).astype(np.float32)
+    ang[rng.random(shape) < 0.1] = -3.402823466e38          # no angle
+    ang[rng.random(shape) < 0.05] = -1.0                      # unresolved flat (a valid angle value < 0: prop() is 0 everywhere)
+    w = (rng.random(shape) * 5).astype(np.float32)
+    w[rng.random(shape) < 0.1] = -9999.0
+    dm = (0.5 + rng.random(shape) * 0.5).astype(np.float32)
+    dm[rng.random(shape) < 0.05] = -9999.0
+    q = (rng.random(shape) * 2 - 0.2).astype(np.float32)      # some q <= 0
+    dg16 = (rng.random(shape) < 0.2).astype(np.int16)
+    tc = (rng.random(shape) * 3).astype(np.float32)
+    cs = rng.random(shape).astype(np.float32)
+    cs[rng.random(shape) < 0.05] = -9999.0
+
+    def same(a, b, name):
+        assert bits_equal(a, b), describe_diff(a, b, name)
+
+    for cc in (True, False):
+        same(ctx.dinfdecayaccum(ang, dm, dx=10.0, dy=7.0, weights=np.abs(w), contcheck=cc), oracle.dinfdecayaccum(ang, dm, dx=10.0, dy=7.0, weights=np.abs(w), contcheck=cc), "dsca")
+        same(ctx.dinfconclimaccum(ang, dm, dg16, q, csol=0.7, dx=10.0, dy=7.0, contcheck=cc), oracle.dinfconclimaccum(ang, dm, dg16, q, csol=0.7, dx=10.0, dy=7.0, contcheck=cc), "ctpt")
+        for c_in in (None, cs):
+            for x, y, nm in zip(ctx.dinftranslimaccum(ang, w, tc, cs=c_in, dx=10.0, dy=7.0, contcheck=cc), oracle.dinftranslimaccum(ang, w, tc, cs=c_in, dx=10.0, dy=7.0, contcheck=cc),
+                                ("tla", "tdep", "ctpt")):
+                if y is not None:
+                    same(x, y, nm)
+    same(ctx.dinfupdependence(ang, dg16.astype(np.int32), dx=10.0, dy=7.0), oracle.dinfupdependence(ang, dg16.astype(np.int32), dx=10.0, dy=7.0), "dep")
+    for x, y, nm in zip(ctx.dinfrevaccum(ang, w, dx=10.0, dy=7.0), oracle.dinfrevaccum(ang, w, dx=10.0, dy=7.0), ("racc", "dmax")):
+        same(x, y, nm)
