@@ -44,6 +44,7 @@ extern "C" {
 #define TDX_ERR_ARG (-1)
 #define TDX_ERR_HIP (-2)
 #define TDX_ERR_NOGPU (-3)
+#define TDX_ERR_VERIFY (-4) /* TDX_SWEEP_VERIFY=1: a swept cell does not follow from its contributors' final records */
 #define TDX_ERR_NOMEM (-999) /* src/linearpart.h:155 */
 
 /* nodata conventions of the reference's outputs */

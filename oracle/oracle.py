@@ -166,6 +166,39 @@ def areadinf(ang, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contchec
     return sca
 
 
+def areadinf_check(ang, sca, nodata=-3.402823466e38, dx=1.0, dy=1.0, weights=None, contcheck=True, threads=None):
+    """Linear-time pin of area()'s per-cell expression (src/areadinf.cpp:187-217) to a given result: returns (number of cells of `sca` that are
+    not what their contributors' values in `sca` give, index of the first one or -1).  0 means `sca` is the raster areadinf(ang) produces."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    sca = np.ascontiguousarray(sca, dtype=np.float32)
+    ny, nx = ang.shape
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    first = C.c_long(-1)
+    f = lib().orc_areadinf_check
+    f.restype = C.c_long
+    bad = f(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(weights), C.c_int(int(contcheck)), _p(sca),
+            C.c_int(int(threads or os.cpu_count() or 1)), C.byref(first))
+    return int(bad), int(first.value)
+
+
+def dinf_first_pass_check(fel, ang, slp, nodata=-3.0e38, dx=1.0, dy=1.0, threads=None):
+    """Linear-time pin of setdir()'s first pass (src/dinf.cpp:549-593, SET2 :317-373): returns (mismatching cells, first index or -1, cells
+    the pass leaves flat).  On non-flat cells ang / slp must be bit-exact; on flat cells only the slope and the range of the angle are checked."""
+    fel = np.ascontiguousarray(fel, dtype=np.float32)
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    slp = np.ascontiguousarray(slp, dtype=np.float32)
+    ny, nx = fel.shape
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    first, flats = C.c_long(-1), C.c_long(0)
+    f = lib().orc_dinf_first_pass_check
+    f.restype = C.c_long
+    bad = f(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(ang), _p(slp), C.c_int(int(threads or os.cpu_count() or 1)),
+            C.byref(first), C.byref(flats))
+    return int(bad), int(first.value), int(flats.value)
+
+
 def dinfdecayaccum(ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None):
     ang = np.ascontiguousarray(ang, dtype=np.float32)
     dm = np.ascontiguousarray(dm, dtype=np.float32)

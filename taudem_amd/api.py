@@ -37,11 +37,23 @@ class Context:
         h = C.c_void_p()
         check(self._lib.tdx_context_create(int(device), C.byref(h)))
         self._h = h
+        self._owned = True
         self.device = int(device)
+
+    @classmethod
+    def borrow(cls, handle, device: int):
+        """A Context over a tdx_context* that somebody else owns (a rank of a tdx_group: taudem_amd.distributed.StripGroup)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = handle if isinstance(handle, C.c_void_p) else C.c_void_p(handle)
+        self._owned = False
+        self.device = int(device)
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.tdx_context_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._lib.tdx_context_destroy(self._h)
             self._h = None
 
     def set_option(self, name: str, value: int):

@@ -922,6 +922,7 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     unsigned long long *outbox = boxes, *inbox = boxes + 2 * size_t(st.nx);
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "aread8");
     int rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);   // directions of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
@@ -1088,6 +1089,7 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
         unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
         if (!info || !flags || !counts) return TDX_ERR_NOMEM;
         ctx->begin_call(stats);
+        strip_mark(ctx, st, "aread8");
         rc = strip_exchange<int16_t>(ctx, st, p_use, p_nodata);
         if (rc != TDX_OK) return rc;
         {
@@ -1123,6 +1125,7 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
     if (!cnt || !recvbuf) return TDX_ERR_NOMEM;
     const dim3 grid2d((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "aread8");
     rc = strip_exchange<int16_t>(ctx, st, p_use, p_nodata);
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));

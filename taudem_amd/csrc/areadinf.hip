@@ -11,6 +11,7 @@
 // prop() needs atan2(dy,dx) only through the per-row table aref[] - computed on the host with the host
 // libm (one value per row); everything else is exactly-rounded +,-,/ on the device.
 #include "context.hpp"
+#include "d8_sweep.hpp"
 #include "device_common.hpp"
 #include "dinf_outlets.hpp"
 #include "dinf_prop.hpp"
@@ -465,6 +466,51 @@ struct DecayEval {   // src/dinfdecayaccum.cpp:213-245
     }
 };
 
+// Verifier of the D-infinity sweep (TDX_SWEEP_VERIFY=1; the contract is spelled out in d8_sweep.hpp): one streaming pass over the
+// quiescent result that gathers every owned cell's neighbourhood straight from global memory - no tiles, no LDS, nothing shared with
+// the sweep but the policy's expression - and checks that a pending cell has a pending contributor and that an evaluated cell is,
+// bit for bit, what its contributors' final values give.  out[0] cells checked, out[1] mismatches, out[2] first mismatching index.
+template <class Eval, bool HAS_W, bool HAS_DM>
+__global__ __launch_bounds__(256) void verify_kernel(Eval ev, const float* __restrict__ ANG, float ang_nodata, int nx, int ny, int y_own0, int y_own1,
+                                                     const double2* __restrict__ P, const float* __restrict__ W, const float* __restrict__ DM,
+                                                     const uint32_t* __restrict__ INFO, const RowProp* __restrict__ rows, const float* __restrict__ OUT,
+                                                     float out_nodata, int contcheck, unsigned long long* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = y_own0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool checked = false, wrong = false;
+    size_t idx = 0;
+    if (x < nx && y < y_own1) {
+        idx = size_t(y) * size_t(nx) + size_t(x);
+        const float ang = ANG[idx], me = OUT[idx];
+        const bool part = !(is_nodata_f(ang, ang_nodata) || ang == ANG_OUTSIDE);
+        checked = true;
+        if (!part) wrong = __float_as_uint(me) != __float_as_uint(out_nodata);
+        else {
+            const unsigned inf = INFO[idx];
+            Nbr8 nb;
+#pragma unroll
+            for (int k = 1; k <= 8; k++) {
+                const int xn = x + d1(k), yn = y + d2(k);
+                const bool in = xn >= 0 && xn < nx && yn >= 0 && yn < ny;
+                const size_t n = size_t(in ? yn : y) * size_t(nx) + size_t(in ? xn : x);
+                nb.v[k] = in ? OUT[n] : out_nodata;
+                nb.p[k] = in ? P[n] : make_double2(0., 0.);
+                nb.dm[k] = (HAS_DM && in) ? DM[n] : 0.f;
+            }
+            const unsigned pb = pending_bits(nb) & inf & 0xFFu;
+            if (pending(me)) wrong = pb == 0u;        // ready, never evaluated
+            else if (pb != 0u) wrong = true;          // evaluated ahead of a contributor
+            else wrong = __float_as_uint(ev.eval(nb, HAS_W ? W[idx] : 0.f, rows[y].dx, inf, contcheck, HAS_W)) != __float_as_uint(me);
+        }
+    }
+    const unsigned long long bc = __ballot(checked), bw = __ballot(wrong);
+    if (bw) atomicMin(out + 2, wrong ? (unsigned long long)idx : ~0ull);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, (unsigned long long)__popcll(bc));
+        if (bw) atomicAdd(out + 1, (unsigned long long)__popcll(bw));
+    }
+}
+
 // activation flags between the two tile geometries (a 64 x 64 tile = 2 x 2 tiles of 32 x 32)
 static __global__ __launch_bounds__(256) void flags_down_kernel(const uint32_t* __restrict__ f64, int tiles_x64, uint32_t* __restrict__ f32, int tiles_x32,
                                                                 int tiles_y32) {
@@ -530,6 +576,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     const dim3 grid2d((inx + 63) / 64, (st.y1 - st.y0 + 3) / 4);
 
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "areadinf / dinfdecayaccum");
     int rc = strip_exchange<float>(ctx, st, d_ang, ang_nodata);   // angles of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
     if (d_dm) { rc = strip_exchange<float>(ctx, st, d_dm, dm_nodata); if (rc != TDX_OK) return rc; }
@@ -583,7 +630,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         static const bool dbg_cycles = dbg_rounds && atoi(getenv("TDX_DEBUG_ROUNDS")) == 1;
         // the bulk phase ends when a round has at most this many active 32 x 32 tiles (0: no bulk phase)
         static const unsigned long long bulk_until = getenv("TDX_DINF_BULK_UNTIL") ? strtoull(getenv("TDX_DINF_BULK_UNTIL"), nullptr, 10) : 6000ull;
-        unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + 64 : nullptr;
+        unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_DBG_SWEEP : nullptr;
         auto launch = [&](bool small, const tilek::TileGeom& gg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur,
                           uint32_t* fnext, uint32_t* lnext, unsigned pull_max) {
 #define TDX_DSWEEP_LAUNCH(NS)                                                                                                                                   \
@@ -609,7 +656,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         // runs one geometry until no tile is active, or (stop_at > 0) until a round has at most stop_at active tiles; returns whether
         // tiles are still active (their flags of the next round are then in run.flags_of(run.parity))
         auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
-            RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail, nullptr);
+            RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
             if (small) { run.grid_full = unsigned(std::min(run.ntiles, 16 * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
             run.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
                                     unsigned pull_max) { launch(small, gg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
@@ -626,12 +673,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 run.collect();
                 if (dbg) {   // per batch of rounds: average phase times (us) and hops per activation
-                    TDX_HIP_CHECK(ctx, hipMemcpy(ctx->h_mail + 64, dbg, 64, hipMemcpyDeviceToHost));
+                    TDX_HIP_CHECK(ctx, hipMemcpy(ctx->h_mail + TDX_MAIL_DBG_SWEEP, dbg, 64, hipMemcpyDeviceToHost));
                     TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
-                    const double na = double(ctx->h_mail[71] ? ctx->h_mail[71] : 1);
+                    const double na = double(ctx->h_mail[TDX_MAIL_DBG_SWEEP + 7] ? ctx->h_mail[TDX_MAIL_DBG_SWEEP + 7] : 1);
                     fprintf(stderr, "\n  [rounds %d..%lld] activations %.0f: stage %.1f scan+bulk %.1f walks %.1f writeback %.1f us; hops/act %.1f, busiest lane %.1f, phases %.2f\n",
-                            last_printed + 1, (long long)run.rounds - 1, na, ctx->h_mail[64] / na / 100.0, ctx->h_mail[65] / na / 100.0, ctx->h_mail[66] / na / 100.0,
-                            ctx->h_mail[67] / na / 100.0, ctx->h_mail[68] / na, ctx->h_mail[69] / na, ctx->h_mail[70] / na);
+                            last_printed + 1, (long long)run.rounds - 1, na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 0] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 1] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 2] / na / 100.0,
+                            ctx->h_mail[TDX_MAIL_DBG_SWEEP + 3] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 4] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 5] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 6] / na);
                     last_printed = int(run.rounds) - 1;
                 }
                 if (!run.done && stop_at > 0 && run.last_count <= stop_at) { *active_left = true; *parity_out = run.parity; break; }
@@ -673,6 +720,25 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             outer++;
         }
         if (stats) stats->launches[TDX_K_ACCUM] += launches;
+        if (d8sweep::verify_enabled()) {
+            unsigned long long* d_ver = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_VERIFY;
+            const unsigned long long init[3] = {0ull, 0ull, ~0ull};
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_ver, init, sizeof init, hipMemcpyHostToDevice, s));
+            TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));   // `init` is a local
+#define TDX_DSWEEP_VERIFY(EV, EVOBJ, HW, HD, DMP)                                                                                                             \
+    hipLaunchKernelGGL((dsweep::verify_kernel<EV, HW, HD>), grid2d, dim3(256), 0, s, EVOBJ, ang_use, ang_nodata, inx, iny, st.y0, st.y1, d_P, d_w, DMP, info32, \
+                       d_rows, d_out, out_nodata, contcheck, d_ver)
+            if constexpr (std::is_same<Alg, AreaAlg>::value) {
+                if (d_w) TDX_DSWEEP_VERIFY(dsweep::AreaEval, dsweep::AreaEval{}, true, false, nullptr);
+                else TDX_DSWEEP_VERIFY(dsweep::AreaEval, dsweep::AreaEval{}, false, false, nullptr);
+            } else {
+                if (d_w) TDX_DSWEEP_VERIFY(dsweep::DecayEval, dsweep::DecayEval{alg.dm_nodata}, true, true, alg.DM);
+                else TDX_DSWEEP_VERIFY(dsweep::DecayEval, dsweep::DecayEval{alg.dm_nodata}, false, true, alg.DM);
+            }
+#undef TDX_DSWEEP_VERIFY
+            rc = d8sweep::verify_report(ctx, "D-infinity dependency sweep", d_ver, inx);
+            if (rc != TDX_OK) return rc;
+        }
     } else {
     rc = strip_exchange<int32_t>(ctx, st, cnt, CNT_NOT_PART);
     if (rc != TDX_OK) return rc;

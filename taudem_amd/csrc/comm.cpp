@@ -15,7 +15,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -75,11 +77,13 @@ RcclApi& rccl() {
 class HostBarrier {   // sense-reversing barrier of the rank threads of one process
 public:
     explicit HostBarrier(int n) : n_(n) {}
-    void wait() {
+    // false: the other ranks did not arrive within TDX_COMM_TIMEOUT seconds (default 600) - one of them has failed or left the loop
+    bool wait() {
+        static const double limit_s = getenv("TDX_COMM_TIMEOUT") ? atof(getenv("TDX_COMM_TIMEOUT")) : 600.0;
         std::unique_lock<std::mutex> lk(m_);
         const unsigned gen = gen_;
-        if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); }
-        else cv_.wait(lk, [&] { return gen_ != gen; });
+        if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); return true; }
+        return cv_.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen_ != gen; });
     }
 private:
     std::mutex m_;
@@ -111,15 +115,25 @@ int rccl_exchange(void* user, uint64_t bytes) {
     hipStream_t s = r->ctx->stream;
     r->exchanges++;
     TDX_NCCL(a.GroupStart());
+    // inside the group the first failure is remembered and the group is ALWAYS closed: a thread that returned between GroupStart
+    // and GroupEnd would queue every later RCCL call (the communicator's destruction included) into a group that never ends
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    auto note = [&](ncclResult_t e, const char* w) { if (first == ncclSuccess && e != ncclSuccess) { first = e; what = w; } };
     if (rank > 0) {
-        TDX_NCCL(a.Send(r->c.send_up, bytes, ncclChar, rank - 1, r->comm, s));
-        TDX_NCCL(a.Recv(r->c.recv_up, bytes, ncclChar, rank - 1, r->comm, s));
+        note(a.Send(r->c.send_up, bytes, ncclChar, rank - 1, r->comm, s), "ncclSend(up)");
+        note(a.Recv(r->c.recv_up, bytes, ncclChar, rank - 1, r->comm, s), "ncclRecv(up)");
     }
     if (rank < size - 1) {
-        TDX_NCCL(a.Send(r->c.send_down, bytes, ncclChar, rank + 1, r->comm, s));
-        TDX_NCCL(a.Recv(r->c.recv_down, bytes, ncclChar, rank + 1, r->comm, s));
+        note(a.Send(r->c.send_down, bytes, ncclChar, rank + 1, r->comm, s), "ncclSend(down)");
+        note(a.Recv(r->c.recv_down, bytes, ncclChar, rank + 1, r->comm, s), "ncclRecv(down)");
     }
-    TDX_NCCL(a.GroupEnd());
+    note(a.GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess) {
+        g_tdx_thread_error = "rank " + std::to_string(rank) + " of " + std::to_string(size) + ", exchange " + std::to_string(r->exchanges) + ": " + what + ": " +
+                             a.GetErrorString(first);
+        return 1;
+    }
     return 0;
 }
 int rccl_allreduce_dev(void* user, int64_t* d_values, int32_t count, int32_t op) {
@@ -216,8 +230,10 @@ extern "C" int tdx_rccl_selftest(tdx_context* ctx) {
     std::vector<unsigned char> h(bytes), back(bytes, 0);
     for (size_t i = 0; i < bytes; i++) h[i] = (unsigned char)(i * 7 + 3);
     if (hipMemcpyAsync(r->c.send_up, h.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) fail = 1;
-    if (!fail && (a.GroupStart() != ncclSuccess || a.Send(r->c.send_up, bytes, ncclChar, 0, r->comm, s) != ncclSuccess ||
-                  a.Recv(r->c.recv_down, bytes, ncclChar, 0, r->comm, s) != ncclSuccess || a.GroupEnd() != ncclSuccess)) fail = 2;
+    if (!fail && a.GroupStart() == ncclSuccess) {   // (the group is closed whatever happens inside it)
+        const bool sent = a.Send(r->c.send_up, bytes, ncclChar, 0, r->comm, s) == ncclSuccess && a.Recv(r->c.recv_down, bytes, ncclChar, 0, r->comm, s) == ncclSuccess;
+        if (a.GroupEnd() != ncclSuccess || !sent) fail = 2;
+    } else if (!fail) fail = 2;
     if (!fail && hipMemcpyAsync(back.data(), r->c.recv_down, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) fail = 3;
     int64_t v[2] = {41, -7};
     if (!fail && r->c.allreduce(r, v, 2, TDX_OP_SUM) != 0) fail = 4;   // synchronises the stream
@@ -248,13 +264,17 @@ int peer_exchange(void* user, uint64_t bytes) {
     tdx_group* g = me->g;
     tdx_context* ctx = g->ctxs[size_t(me->rank)];
     // every rank has synchronised its stream before calling (host-synchronous contract): after the barrier all send buffers are final
-    g->bar->wait();
+    auto late = [&](const char* where) {
+        g_tdx_thread_error = "peer transport: rank " + std::to_string(me->rank) + " of " + std::to_string(g->size) + " waited in vain for the other ranks at " + where;
+        return 1;
+    };
+    if (!g->bar->wait()) return late("the barrier before an exchange");
     int fail = 0;
     if (hipSetDevice(ctx->device) != hipSuccess) fail = 1;
     if (!fail && me->rank > 0 && hipMemcpyAsync(me->c.recv_up, g->pr[size_t(me->rank - 1)].c.send_down, bytes, hipMemcpyDefault, ctx->stream) != hipSuccess) fail = 1;
     if (!fail && me->rank < g->size - 1 && hipMemcpyAsync(me->c.recv_down, g->pr[size_t(me->rank + 1)].c.send_up, bytes, hipMemcpyDefault, ctx->stream) != hipSuccess) fail = 1;
     if (!fail && hipStreamSynchronize(ctx->stream) != hipSuccess) fail = 1;
-    g->bar->wait();   // nobody refills a send buffer before its neighbour has copied it
+    if (!g->bar->wait()) return late("the barrier after an exchange");   // nobody refills a send buffer before its neighbour has copied it
     return fail;
 }
 int peer_allreduce(void* user, int64_t* values, int32_t count, int32_t op) {
@@ -262,7 +282,11 @@ int peer_allreduce(void* user, int64_t* values, int32_t count, int32_t op) {
     tdx_group* g = me->g;
     if (count > RED_MAX) return 1;
     memcpy(&g->red[size_t(me->rank) * RED_MAX], values, size_t(count) * 8);
-    g->bar->wait();
+    auto late = [&]() {
+        g_tdx_thread_error = "peer transport: rank " + std::to_string(me->rank) + " of " + std::to_string(g->size) + " waited in vain for the other ranks at an all-reduce";
+        return 1;
+    };
+    if (!g->bar->wait()) return late();
     int64_t acc[RED_MAX];
     for (int i = 0; i < count; i++) {
         int64_t a = g->red[size_t(i)];
@@ -272,7 +296,7 @@ int peer_allreduce(void* user, int64_t* values, int32_t count, int32_t op) {
         }
         acc[i] = a;
     }
-    g->bar->wait();   // all ranks have read the slots
+    if (!g->bar->wait()) return late();   // all ranks have read the slots
     memcpy(values, acc, size_t(count) * 8);
     return 0;
 }

@@ -1,5 +1,6 @@
 #include "context.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 thread_local std::string g_tdx_thread_error;
@@ -32,6 +33,7 @@ hipEvent_t tdx_context::get_event() {
 }
 
 void tdx_context::begin_call(tdx_stats* st) {
+    comm_exchanges = comm_allreduces = 0;
     cur_stats = st;
     timing = (st != nullptr);
     spans.clear();
@@ -72,6 +74,12 @@ void tdx_context::end_call() {
             if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) cur_stats->ms_kernel[s.kclass] += t;
         }
     }
+    if (comm_size > 1) {
+        static const bool trace = getenv("TDX_COMM_TRACE") != nullptr && atoi(getenv("TDX_COMM_TRACE")) != 0;
+        if (trace)
+            fprintf(stderr, "taudem_amd[rank %d/%d] %s: %lld exchanges, %lld all-reduces%s\n", comm_rank, comm_size, stage, (long long)comm_exchanges,
+                    (long long)comm_allreduces, timing && cur_stats ? (", " + std::to_string(cur_stats->ms_total) + " ms").c_str() : "");
+    }
     timing = false;
     cur_stats = nullptr;
 }
@@ -100,9 +108,9 @@ static int context_init(tdx_context* c, int device) {
     TDX_HIP_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 256 * sizeof(uint64_t), hipHostMallocDefault));
-    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), 256 * sizeof(uint64_t)));
-    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, 256 * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), TDX_MAIL_WORDS * sizeof(uint64_t), hipHostMallocDefault));
+    TDX_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_mail), TDX_MAIL_WORDS * sizeof(uint64_t)));
+    TDX_HIP_CHECK(c, hipMemset(c->d_mail, 0, TDX_MAIL_WORDS * sizeof(uint64_t)));
     c->slots.resize(size_t(TDX_S_COUNT));
     return TDX_OK;
 }

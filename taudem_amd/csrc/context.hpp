@@ -12,6 +12,22 @@
 
 #define TDX_NUM_KCLASS 8
 
+// Layout of the two mailboxes (8-byte words; the same offsets in the pinned host copy and in the device copy).  Every user has its
+// own words, so that a round batch still in flight on either stream, a strip vote and a stage counter can never land on each other.
+enum {
+    TDX_MAIL_STAGE = 0,             // [0, 32)    counters of the running stage (flat counts, list lengths, overflow counts)
+    TDX_MAIL_DBG_RELAX = 32,        // [32, 48)   TDX_DEBUG_ROUNDS counters of the relaxation kernels
+    TDX_MAIL_DBG_SWEEP = 48,        // [48, 64)   TDX_DEBUG_ROUNDS counters of the D-infinity sweep
+    TDX_MAIL_STRIP_CHANGED = 64,    // [64, 72)   strip_exchange: changed halo cells
+    TDX_MAIL_STRIP_REDUCE = 72,     // [72, 96)   strip_allreduce_device: values reduced over the ranks (up to 24)
+    TDX_MAIL_VERIFY = 96,           // [96, 104)  sweep verifier: cells checked, mismatches, first mismatch
+    TDX_MAIL_RUN_A = 128,           // [128, 256) RoundRunner on ctx->stream: two slots of TDX_MAIL_RUN_SLOT per-round counts
+    TDX_MAIL_RUN_B = 256,           // [256, 384) RoundRunner on ctx->stream2
+    TDX_MAIL_RUN_SLOT = 64,
+    TDX_MAIL_WORDS = 384
+};
+static_assert(TDX_MAIL_RUN_A + 2 * TDX_MAIL_RUN_SLOT <= TDX_MAIL_RUN_B && TDX_MAIL_RUN_B + 2 * TDX_MAIL_RUN_SLOT <= TDX_MAIL_WORDS, "mailbox layout");
+
 struct tdx_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -27,8 +43,8 @@ struct tdx_context {
     void* scratch(int slot, size_t bytes);   // returns nullptr + sets err on failure
 
     // pinned host mailbox for small device->host readbacks (counters, flags)
-    uint64_t* h_mail = nullptr;              // 256 words, hipHostMalloc
-    uint64_t* d_mail = nullptr;              // 256 words of device memory
+    uint64_t* h_mail = nullptr;              // TDX_MAIL_WORDS words, hipHostMalloc (layout: the TDX_MAIL_* offsets below)
+    uint64_t* d_mail = nullptr;              // TDX_MAIL_WORDS words of device memory
 
     // ---- timing ----
     struct Span { hipEvent_t a, b; int kclass; };
@@ -39,6 +55,11 @@ struct tdx_context {
     bool timing = false;
     bool kernel_timing = false;               // option "kernel_timing"
     tdx_stats* cur_stats = nullptr;
+
+    // ---- multi-strip diagnostics (strips.hpp): what this rank is doing, for time-out messages and TDX_COMM_TRACE=1 ----
+    const char* stage = "";                   // tool stage of the running call ("pitremove", "d8flowdir" ...)
+    int comm_rank = 0, comm_size = 1;
+    int64_t comm_exchanges = 0, comm_allreduces = 0;   // of the running call
 
     hipEvent_t get_event();
     void begin_call(tdx_stats* st);

@@ -194,15 +194,15 @@ struct Arrays {   // global arrays of one sweep
     const uint32_t* info;
 };
 
+// Stages tile + ring of the work array, the tile's info words and the policy's per-cell / per-row inputs in LDS: every load is issued
+// before the first LDS store (addresses clamped, validity applied afterwards).  The caller synchronises.
 template <class Alg, int TSZ>
-__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg, TSZ>& S, const Arrays<Alg>& A) {
+__device__ __forceinline__ void stage_tile(const tilek::TileGeom& g, int tile, Lds<Alg, TSZ>& S, const Arrays<Alg>& A) {
     using Cell = typename Alg::Cell;
     constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL, NSTAGE = Dim<TSZ>::NSTAGE;
     const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
-    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
-    // ---- stage: every load is issued before the first LDS store (addresses clamped, validity applied afterwards)
     {
         Cell s0[NSTAGE];
         uint32_t si[RPL];
@@ -252,6 +252,17 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         }
         if (Alg::HAS_ROWS && tid < LH) S.rows[tid] = srow;
     }
+}
+
+template <class Alg, int TSZ>
+__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg, TSZ>& S, const Arrays<Alg>& A) {
+    using Cell = typename Alg::Cell;
+    constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL;
+    const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
+    stage_tile<Alg, TSZ>(g, tile, S, A);
     __syncthreads();
     unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet) and can become ready
 #pragma unroll
@@ -447,6 +458,119 @@ static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restri
     }
 }
 
+// ---- verifier (TDX_SWEEP_VERIFY=1) ------------------------------------------------------------------------------------------
+// The sweeps rely on a record being read and written by ONE instruction, so that a tile staging its ring while the neighbouring tile
+// writes back in the same round sees the old or the new record, never a mixture.  That holds for aligned 4 / 8 / 16-byte accesses on
+// gfx950, but it is not a guarantee of the HIP memory model.  With TDX_SWEEP_VERIFY=1 every sweep is followed by one more pass over the
+// QUIESCENT work array (nothing else is running): each tile is staged again and every owned, participating cell is checked -
+//   * a cell that is still pending must have a pending contributor (or be one of the cells that can never become ready);
+//   * an evaluated cell must have no pending contributor, and re-evaluating it from its contributors' FINAL records with the policy's
+//     own expression must reproduce its record bit for bit.
+// A record torn or read stale at any point of the sweep leaves a cell whose value does not follow from its contributors, which this
+// finds; the call then fails with TDX_ERR_VERIFY and names the first cell.  A policy whose evaluation consumes part of its own
+// record (TransLimAlg: the input concentration becomes the deposition) restores it through unevaluate().
+template <class Alg>
+__device__ __forceinline__ auto unevaluate_record(const Alg& alg, typename Alg::Cell& me, size_t idx, int) -> decltype(alg.unevaluate(me, idx), void()) { alg.unevaluate(me, idx); }
+template <class Alg>
+__device__ __forceinline__ void unevaluate_record(const Alg&, typename Alg::Cell&, size_t, long) {}
+
+template <class Cell>
+__device__ __forceinline__ bool same_record(const Cell& a, const Cell& b) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+    bool eq = true;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Cell) / 4; i++) eq = eq && pa[i] == pb[i];
+    return eq;
+}
+
+// out[0] = cells checked, out[1] = mismatches, out[2] = smallest linear index of a mismatch, out[3] = kind of that... (bit 62/63 of out[2])
+template <class Alg>
+__global__ __launch_bounds__(Dim<32>::NT) void verify_kernel(Alg alg, tilek::TileGeom g, Arrays<Alg> A, unsigned long long* __restrict__ out) {
+    using Cell = typename Alg::Cell;
+    constexpr int TS = Dim<32>::TS, LH = Dim<32>::LH, RPL = Dim<32>::RPL;
+    __shared__ Lds<Alg, 32> S;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    stage_tile<Alg, 32>(g, tile, S, A);
+    unsigned long long checked = 0, bad = 0, first = ~0ull;
+    for (int r = 0; r < RPL; r++) {
+        __syncthreads();   // staging / the previous row's restore has landed
+        const int ly = ry0 + r, c = ly * TS + lx, cl = (ly + 1) * LH + lx + 1;
+        const int gx = x0 + lx, gy = y0 + ly;
+        const unsigned inf = S.info[c];
+        const bool mine = gx < g.nx && gy >= g.y_own0 && gy < g.y_own1 && (inf & INFO_PART) != 0u;
+        const Cell me = S.v[cl];
+        Cell nb[9];
+#pragma unroll
+        for (int k = 1; k <= 8; k++) nb[k] = S.v[cl + d2(k) * LH + d1(k)];
+        unsigned pb = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) pb |= pending(Alg::head(nb[k])) ? 1u << (k - 1) : 0u;
+        pb &= inf & 0xFFu;
+        const size_t idx = size_t(gy) * size_t(g.nx) + size_t(gx);
+        __syncthreads();   // every lane holds its neighbourhood: the records may be rewritten
+        bool wrong = false;
+        if (mine) {
+            checked++;
+            if (pending(Alg::head(me))) wrong = pb == 0u && !(inf & INFO_DEAD);      // ready, never evaluated
+            else if (pb != 0u) wrong = true;                                         // evaluated ahead of a contributor
+            else {
+                Cell in = me;
+                unevaluate_record(alg, in, idx, 0);
+                S.v[cl] = in;
+                alg.eval(S, c, cl, ly, inf, nb);
+                const Cell again = S.v[cl];
+                S.v[cl] = me;
+                wrong = !same_record(again, me);
+            }
+        }
+        if (wrong) { bad++; first = first < idx ? first : idx; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        checked += __shfl_xor(checked, off, 64);
+        bad += __shfl_xor(bad, off, 64);
+        const unsigned long long f = __shfl_xor(first, off, 64);
+        first = f < first ? f : first;
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(out + 0, checked);
+        if (bad) { atomicAdd(out + 1, bad); atomicMin(out + 2, first); }
+    }
+}
+
+static inline bool verify_enabled() {
+    const char* e = getenv("TDX_SWEEP_VERIFY");   // read per call: the tests switch it on for single cases
+    return e != nullptr && atoi(e) != 0;
+}
+// reads back a verifier's three counters (device words out[0..2]) and turns mismatches into an error
+static inline int verify_report(tdx_context* ctx, const char* what, unsigned long long* d_out, int nx) {
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_VERIFY, d_out, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long checked = ctx->h_mail[TDX_MAIL_VERIFY], bad = ctx->h_mail[TDX_MAIL_VERIFY + 1], first = ctx->h_mail[TDX_MAIL_VERIFY + 2];
+    const bool talk = getenv("TDX_SWEEP_VERIFY") != nullptr && atoi(getenv("TDX_SWEEP_VERIFY")) > 1;
+    if (talk) fprintf(stderr, "taudem_amd: sweep verifier (%s): %llu cells checked, %llu do not follow from their contributors\n", what, checked, bad);
+    if (bad == 0) return TDX_OK;
+    char msg[256];
+    snprintf(msg, sizeof msg, "sweep verifier (%s): %llu of %llu cells do not follow from their contributors' final records; first at row %llu column %llu of the strip array",
+             what, bad, checked, first / (unsigned long long)nx, first % (unsigned long long)nx);
+    return tdx_fail(ctx, TDX_ERR_VERIFY, msg);
+}
+template <class Alg>
+static int verify(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A) {
+    tilek::TileGeom g32 = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
+    g32.tiles_x = (st.nx + 31) / 32; g32.tiles_y = (st.ny_arr + 31) / 32;
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_VERIFY;
+    const unsigned long long init[3] = {0ull, 0ull, ~0ull};
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_out, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // `init` is a local
+    hipLaunchKernelGGL((verify_kernel<Alg>), dim3(unsigned(g32.tiles_x) * unsigned(g32.tiles_y)), dim3(Dim<32>::NT), 0, ctx->stream, alg, g32, A, d_out);
+    return verify_report(ctx, "tile dependency sweep", d_out, st.nx);
+}
+
 // Runs the sweep to the global fixed point: bulk rounds on 32 x 32 tiles until a round has at most TDX_D8_BULK_UNTIL (default 6000)
 // active tiles, the rest on 64 x 64 tiles.  The work array must be initialised (pending pattern on participating owned cells) and
 // its halo rows exchanged; cells still pending on return (on or below a cycle, fed by the p == 0 quirk) are the caller's to finish.
@@ -465,7 +589,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
     const tilek::Sched sched{flags, flags + ntiles, counts}, sched32{flags32, flags32 + ntiles32, counts};
     static const unsigned long long bulk_until = getenv("TDX_D8_BULK_UNTIL") ? strtoull(getenv("TDX_D8_BULK_UNTIL"), nullptr, 10) : 6000ull;
     auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
-        RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail, nullptr);
+        RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
         if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
         runner.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
                                    unsigned pull_max) {
@@ -520,6 +644,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         if (changed == 0) break;
         if (outer_out) (*outer_out)++;
     }
+    if (verify_enabled()) return verify(ctx, st, alg, A);
     return TDX_OK;
 }
 

@@ -122,8 +122,8 @@ __device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, siz
 // Z and P.  Every owned cell gets its markers (lvl / rq: -1 outside the queue) and masks; lanes walk 16-row column
 // segments with both windows in registers (6 row loads per output row).  Semantics: flatk::classify_kernel.
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
-                                                                 int y_own0, int y_own1, int tiles_x, int32_t* __restrict__ lvl,
-                                                                 int32_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                                 int y_own0, int y_own1, int tiles_x, lvl_t* __restrict__ lvl,
+                                                                 lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
                                                                  uint32_t* __restrict__ tile_flags) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
         ldrow(y + 1, zs0, zs1, zs2, ps0, ps1, ps2);
         if (colok && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-            int32_t l = -1, q = -1;
+            lvl_t l = -1, q = -1;
             unsigned fm = 0, rm = 0;
             if (pc1 == 0) {   // a flat cell: interior, all eight neighbours valid
                 const float z0 = zc1;
@@ -203,7 +203,7 @@ struct D8Traits {
 // setFlow2 (src/d8.cpp:412-454) for every cell of the flat list
 __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restrict__ Z, int nx, const double* __restrict__ fact,
                                                           const uint32_t* __restrict__ list, unsigned long long nq,
-                                                          const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+                                                          const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
                                                           FlatLevels fl, int16_t* __restrict__ P) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void d8_recollect_kernel(const int16_t* __rest
 }
 
 __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                           const int32_t* __restrict__ lvl, int16_t* __restrict__ P) {
+                                                           const lvl_t* __restrict__ lvl, int16_t* __restrict__ P) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __res
 // that holds a flat cell are loaded at all (wave-uniform branches; flats are clustered).
 constexpr int SF2_COLS = 62;
 __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
-                                                                 const double* __restrict__ fact, const int32_t* __restrict__ lvl,
-                                                                 const int32_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
+                                                                 const double* __restrict__ fact, const lvl_t* __restrict__ lvl,
+                                                                 const lvl_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
                                                                  uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter) {
     using tilek::lane_left;
     using tilek::lane_right;
@@ -381,12 +381,13 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     if (rc != TDX_OK) return rc;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     // flat-resolution markers and the flat queue are produced by the slope pass itself
-    int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-    int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+    lvl_t* lvl = static_cast<lvl_t*>(ctx->scratch(TDX_S_A, n * sizeof(lvl_t)));
+    lvl_t* rq = static_cast<lvl_t*>(ctx->scratch(TDX_S_B, n * sizeof(lvl_t)));
     uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
     if (!lvl || !rq || !qlist) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "d8flowdir");
     rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));

@@ -171,8 +171,8 @@ struct DinfTraits {
 __device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, TDX_ANG_NODATA) && a < 0.0f; }
 
 // flat queue + markers (8 cells per lane, one atomic per block)
-__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, int32_t* __restrict__ lvl,
-                                                                 int32_t* __restrict__ rq, uint32_t* __restrict__ list,
+__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, lvl_t* __restrict__ lvl,
+                                                                 lvl_t* __restrict__ rq, uint32_t* __restrict__ list,
                                                                  unsigned long long* __restrict__ counter) {
     const size_t base = first + size_t(blockIdx.x) * (256 * 8) + threadIdx.x;   // cells [first, n): the owned rows
     unsigned mask = 0;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                             const int32_t* __restrict__ lvl, float* __restrict__ ANG) {
+                                                             const lvl_t* __restrict__ lvl, float* __restrict__ ANG) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __r
 // SET2 overload (src/dinf.cpp:375-528) for every cell of the flat list
 __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restrict__ Z, int nx, const RowGeom* __restrict__ geom,
                                                             const uint32_t* __restrict__ list, unsigned long long nq,
-                                                            const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+                                                            const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
                                                             FlatLevels fl, float* __restrict__ ANG) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
@@ -306,6 +306,7 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
 
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "dinfflowdir");
     int rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
@@ -324,8 +325,8 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
     if (stats) { stats->flats_initial = total; stats->flats_left = total; }
 
     if (total > 0) {
-        int32_t* lvl = static_cast<int32_t*>(ctx->scratch(TDX_S_A, n * 4));
-        int32_t* rq = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
+        lvl_t* lvl = static_cast<lvl_t*>(ctx->scratch(TDX_S_A, n * sizeof(lvl_t)));
+        lvl_t* rq = static_cast<lvl_t*>(ctx->scratch(TDX_S_B, n * sizeof(lvl_t)));
         uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(nq) * 4));
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(nq) * 4));
         if (!lvl || !rq || !qlist || !qnext) return TDX_ERR_NOMEM;
@@ -338,9 +339,9 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
         const size_t own_first = size_t(st.y0) * size_t(inx), own_end = size_t(st.y1) * size_t(inx);
         hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
                            qlist, d_cnt);
-        rc = strip_exchange<int32_t>(ctx, st, lvl, -1);   // queue membership of the neighbours' boundary rows
+        rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows
         if (rc != TDX_OK) return rc;
-        rc = strip_exchange<int32_t>(ctx, st, rq, -1);
+        rc = strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
         if (rc != TDX_OK) return rc;
         int64_t last = total;
         bool first = true;

@@ -103,6 +103,8 @@ struct TransLimAlg {   // src/DinfTransLimAccum.cpp:236-307; record = {tla, csou
     static constexpr bool kBulkOnHalo = false;
     float tsup_nodata, tc_nodata, cin_nodata;
     int usec, contcheck;
+    const float* cin_src;   // the input concentration raster (null without -cs): what slot w held before the evaluation turned it into the deposition
+    __device__ __forceinline__ void unevaluate(float4& me, size_t idx) const { if (usec) me.w = cin_src[idx]; }   // (sweep verifier, d8_sweep.hpp)
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
     static __host__ __device__ __forceinline__ float4 outside() { return make_float4(TDX_ANG_NODATA, TDX_ANG_NODATA, TDX_ANG_NODATA, TDX_ANG_NODATA); }
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { return fwd_rel_mask(inf); }
@@ -215,6 +217,7 @@ int fwd_prepare(tdx_context* ctx, const Strip& st, float* d_ang, float ang_nodat
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(R.d_a2, a2.data(), a2.size() * 8, hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));   // the tables are locals
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "dinfconclimaccum / dinftranslimaccum");
     int rc = strip_exchange<float>(ctx, st, d_ang, ang_nodata);   // flowData->share()
     if (rc != TDX_OK) return rc;
     R.ang_use = d_ang;
@@ -292,7 +295,7 @@ int translim_impl(tdx_context* ctx, const Strip& st, float* d_ang, float ang_nod
     hipLaunchKernelGGL(trans_aux_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_tsup, d_tc, n, aux);
     hipLaunchKernelGGL(trans_pack_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, R.info, R.ang_use, d_cin, first, nown, R.rec);
     int64_t rounds = 0, outer = 1;
-    rc = fwd_sweep(ctx, st, TransLimAlg{tsup_nodata, tc_nodata, cin_nodata, d_cin ? 1 : 0, contcheck}, R, aux, stats, &rounds, &outer);
+    rc = fwd_sweep(ctx, st, TransLimAlg{tsup_nodata, tc_nodata, cin_nodata, d_cin ? 1 : 0, contcheck, d_cin}, R, aux, stats, &rounds, &outer);
     if (rc != TDX_OK) return rc;
     hipLaunchKernelGGL(trans_unpack_kernel, dim3(tdx_blocks_for(nown, 256)), dim3(256), 0, s, R.rec, R.info, first, nown, d_tla, d_dep, d_cso);
     TDX_HIP_CHECK(ctx, hipGetLastError());

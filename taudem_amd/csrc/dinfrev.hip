@@ -175,6 +175,7 @@ int rev_prepare(tdx_context* ctx, const Strip& st, float* d_ang, float ang_nodat
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(R.d_a2, a2.data(), a2.size() * 8, hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));   // `a2` is a local
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "dinfupdependence / dinfrevaccum");
     int rc = strip_exchange<float>(ctx, st, d_ang, ang_nodata);   // flowData->share()
     if (rc != TDX_OK) return rc;
     TdxSpan sp(ctx, TDX_K_STENCIL);

@@ -34,7 +34,12 @@
 #include "tile_relax.hpp"
 
 struct FlatLevels { int T; int Tr; int has_pits; };
-struct FlatBuffers { int32_t* lvl; int32_t* rq; };
+// Level markers are stored as int16, like the reference's elev2 / dn / s partitions (SHORT_TYPE, src/d8.cpp:483,486,595): half the
+// bytes of every tile image, classification pass and list gather.  Levels saturate at LVL_SAT, which flats_bfs reports as an error
+// (the reference's int16 counters overflow there too).
+using lvl_t = int16_t;
+constexpr int LVL_SAT = 32767;
+struct FlatBuffers { lvl_t* lvl; lvl_t* rq; };
 
 // elev2 + s as the reference's int16 arithmetic leaves it (src/d8.cpp:545,640-645)
 __host__ __device__ __forceinline__ int16_t flat_elev2(int lvl, int rq, FlatLevels fl) {
@@ -52,8 +57,8 @@ using namespace tdxk;
 constexpr int CLASSIFY_ITEMS = 4;
 template <class Traits>
 __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* __restrict__ Z, int nx, int tiles_x,
-                                                       const uint32_t* __restrict__ list, unsigned long long nq, int32_t* __restrict__ lvl,
-                                                       int32_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                       const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
+                                                       lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
                                                        uint32_t* __restrict__ tile_flags) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * CLASSIFY_ITEMS) + threadIdx.x;
 #pragma unroll
@@ -90,30 +95,37 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
     }
 }
 
-// level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move
-template <int INC>   // 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
+// level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move.  S = storage type of the field in
+// HBM (the values in registers are 32-bit either way): int16 for the two level fields, where a candidate level saturates at LVL_SAT -
+// the fixed point of the saturating operator is min(level, LVL_SAT) per cell, i.e. the exact field whenever every level fits, and
+// flats_bfs turns a saturated maximum into the error the reference's overflowing int16 counters stand for; int32 for the plain marks.
+template <int INC, class S>   // INC 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
 struct LevelOpT {
     using T = int;
     static constexpr int kUniform = 0;
-    int32_t* G;
+    S* G;
     const uint8_t* M;
     static __device__ __forceinline__ int inf() { return 0x3fffffff; }
-    using Raw = int;
+    using Raw = S;
     using CellRaw = uint8_t;
-    __device__ __forceinline__ int load_raw(size_t idx) const { return G[idx]; }
-    static __device__ __forceinline__ int decode(int g) { return g > 0 ? g : inf(); }
-    __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = v; }
+    __device__ __forceinline__ S load_raw(size_t idx) const { return G[idx]; }
+    static __device__ __forceinline__ int decode(S g) { return g > 0 ? int(g) : inf(); }
+    __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = S(v); }
     __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
     static __device__ __forceinline__ void cell_decode(uint8_t m, int& cst, unsigned& mask) { cst = 0; mask = m; }
-    static __device__ __forceinline__ int apply(int, int own, int m) { return (m + INC < own) ? m + INC : own; }
+    static __device__ __forceinline__ int apply(int, int own, int m) {
+        int t = m + INC;
+        if (sizeof(S) == 2 && INC) t = t < LVL_SAT ? t : LVL_SAT;
+        return t < own ? t : own;
+    }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
 };
-using LevelOp = LevelOpT<1>;
-using ReachOp = LevelOpT<0>;
+using LevelOp = LevelOpT<1, lvl_t>;
+using ReachOp = LevelOpT<0, int32_t>;
 
 // out[0] = max level, out[1] = #cells never reached by incfall, out[2] = max incrise level
 static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                                const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+                                                                const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
                                                                 unsigned long long* __restrict__ out) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
     int ml = 0, mr = 0;
@@ -151,15 +163,15 @@ static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* 
     }
 }
 
-static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int32_t* __restrict__ lvl,
-                                                      int32_t* __restrict__ rq) {
+static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
+                                                      lvl_t* __restrict__ rq) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     lvl[list[q]] = 0;
     rq[list[q]] = 0;
 }
 
-static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq,
+static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
                                                              FlatLevels fl, float* __restrict__ Zout) {
     const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
     if (i < n) Zout[i] = (float)flat_elev2(lvl[i], rq[i], fl);
@@ -168,12 +180,12 @@ static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, co
 // The next iteration's elevation only where it will be read: on the cells of the new flat queue and their 8 neighbours (flat
 // cells are interior cells).  Several threads may store the same value to one cell.
 static __global__ __launch_bounds__(256) void overwrite_elev_sparse_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int nx,
-                                                                           const int32_t* __restrict__ lvl, const int32_t* __restrict__ rq, FlatLevels fl,
+                                                                           const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq, FlatLevels fl,
                                                                            float* __restrict__ Zout) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
-    int32_t l[9], r[9];
+    int l[9], r[9];
 #pragma unroll
     for (int k = 0; k <= 8; k++) {
         const size_t n = k ? size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k)) : c;
@@ -187,8 +199,8 @@ static __global__ __launch_bounds__(256) void overwrite_elev_sparse_kernel(const
 }
 
 // markers of the cells of the PREVIOUS queue back to "not in Q"
-static __global__ __launch_bounds__(256) void unmark_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int32_t* __restrict__ lvl,
-                                                              int32_t* __restrict__ rq) {
+static __global__ __launch_bounds__(256) void unmark_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
+                                                              lvl_t* __restrict__ rq) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     lvl[list[q]] = -1;
@@ -203,38 +215,38 @@ static inline int flats_read_counters(tdx_context* ctx, int nwords) {
     return TDX_OK;
 }
 
-static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const uint32_t* qlist, unsigned long long nq, int32_t* lvl, int32_t* rq) {
+static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const uint32_t* qlist, unsigned long long nq, lvl_t* lvl, lvl_t* rq) {
     const size_t n = size_t(st.nx) * size_t(st.ny_arr);
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(lvl, 0xFF, n * 4, ctx->stream));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(rq, 0xFF, n * 4, ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(lvl, 0xFF, n * sizeof(lvl_t), ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(rq, 0xFF, n * sizeof(lvl_t), ctx->stream));
     if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
-    int rc = strip_exchange<int32_t>(ctx, st, lvl, -1);   // queue membership of the neighbours' boundary rows
+    int rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
-    return strip_exchange<int32_t>(ctx, st, rq, -1);
+    return strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
 }
 
 // Same markers as flats_reset_markers when lvl / rq are "not in Q" everywhere except on the cells of the previous queue `qold`
 // (which is what a flat iteration leaves behind): a later iteration of a few thousand cells does not rewrite two rasters.
 static inline int flats_reset_markers_after(tdx_context* ctx, const Strip& st, const uint32_t* qold, unsigned long long nq_old, const uint32_t* qlist,
-                                            unsigned long long nq, int32_t* lvl, int32_t* rq) {
+                                            unsigned long long nq, lvl_t* lvl, lvl_t* rq) {
     const size_t n = size_t(st.nx) * size_t(st.ny_arr);
     if (nq_old > n / 16) return flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
     if (nq_old) hipLaunchKernelGGL(flatk::unmark_q_kernel, dim3(tdx_blocks_for(nq_old, 256)), dim3(256), 0, ctx->stream, qold, nq_old, lvl, rq);
     if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
-    int rc = strip_exchange<int32_t>(ctx, st, lvl, -1);
+    int rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));
     if (rc != TDX_OK) return rc;
-    return strip_exchange<int32_t>(ctx, st, rq, -1);
+    return strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
 }
 
 // elevDEM := (float)elev2 where the next iteration (queue `qlist`) reads it: the queue cells and their neighbours
-static inline int flats_overwrite_elevation_sparse(tdx_context* ctx, int nx, const uint32_t* qlist, unsigned long long nq, const int32_t* lvl, const int32_t* rq,
+static inline int flats_overwrite_elevation_sparse(tdx_context* ctx, int nx, const uint32_t* qlist, unsigned long long nq, const lvl_t* lvl, const lvl_t* rq,
                                                    FlatLevels fl, float* zout) {
     TdxSpan sp(ctx, TDX_K_MISC);
     if (nq) hipLaunchKernelGGL(flatk::overwrite_elev_sparse_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, nx, lvl, rq, fl, zout);
     return TDX_OK;
 }
 
-static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const int32_t* lvl, const int32_t* rq, FlatLevels fl, float* zout) {
+static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const lvl_t* lvl, const lvl_t* rq, FlatLevels fl, float* zout) {
     TdxSpan sp(ctx, TDX_K_MISC);
     hipLaunchKernelGGL(flatk::overwrite_elev_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, lvl, rq, fl, zout);
     return TDX_OK;
@@ -245,14 +257,14 @@ static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const in
 // (the per-level share() + MPI_Allreduce of src/d8.cpp:549-550,620-630, once per strip crossing instead
 // of once per level).
 template <class Op = flatk::LevelOp>
-static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, int32_t* field, const uint8_t* mask, tilek::Sched sc,
+static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, typename Op::Raw* field, const uint8_t* mask, tilek::Sched sc,
                                     int64_t* rounds, int64_t* launches) {
     for (;;) {
         int rc = tile_relax_run(ctx, Op{field, mask}, geom, sc, rounds, launches);
         if (rc != TDX_OK) return rc;
         if (!st.multi()) return TDX_OK;
         int64_t changed = 0;
-        rc = strip_exchange<int32_t>(ctx, st, field, -1, sc.flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
+        rc = strip_exchange<typename Op::Raw>(ctx, st, field, typename Op::Raw(-1), sc.flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
         if (rc != TDX_OK) return rc;
         if (changed == 0) return TDX_OK;
     }
@@ -290,9 +302,9 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
             hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
                                geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
     }
-    int rc = strip_exchange<int32_t>(ctx, st, b.lvl, -1);   // the neighbours' seeds
+    int rc = strip_exchange<lvl_t>(ctx, st, b.lvl, lvl_t(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;
-    rc = strip_exchange<int32_t>(ctx, st, b.rq, -1);
+    rc = strip_exchange<lvl_t>(ctx, st, b.rq, lvl_t(-1));
     if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
     static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;

@@ -228,6 +228,7 @@ int gridnet_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_noda
         int32_t* gord32 = static_cast<int32_t*>(ctx->scratch(TDX_S_B, n * 4));
         if (!cnt || !gord32) return TDX_ERR_NOMEM;
         ctx->begin_call(stats);
+        strip_mark(ctx, st, "gridnet");
         {
             TdxSpan sp(ctx, TDX_K_STENCIL);
             hipLaunchKernelGGL(gn_setup_kernel, grid2d, dim3(256), 0, s, d_p, inx, iny, p_nodata, d_mask, int(thresh), cnt, d_plen, d_tlen, gord32);
@@ -255,6 +256,7 @@ int gridnet_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_noda
     unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
     if (!info || !flags || !counts) return TDX_ERR_NOMEM;
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "gridnet");
     int rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);   // directions of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
     if (d_mask) {   // ... and their mask values (the value-contributor rule looks at the neighbour's mask)

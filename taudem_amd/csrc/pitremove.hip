@@ -180,6 +180,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     if (!flags || !list || !counts) return TDX_ERR_NOMEM;
 
     ctx->begin_call(stats);
+    strip_mark(ctx, st, "pitremove");
     int rc = strip_exchange<float>(ctx, st, d_dem, dem_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     {

@@ -6,6 +6,9 @@
 // has no halo rows at all (own = [0, ny)): kernels read rows outside the array as nodata, which is
 // what a halo row beyond the global raster holds in a strip array.
 #pragma once
+#include <chrono>
+#include <thread>
+
 #include "context.hpp"
 #include "device_common.hpp"
 
@@ -20,6 +23,12 @@ struct Strip {
 
 static inline Strip strip_single(int nx, int ny) {
     Strip s; s.nx = nx; s.ny_arr = ny; s.y0 = 0; s.y1 = ny; return s;
+}
+// marks the context with the rank and the stage of the call that is starting (time-out messages, TDX_COMM_TRACE=1)
+static inline void strip_mark(tdx_context* ctx, const Strip& st, const char* stage) {
+    ctx->stage = stage;
+    ctx->comm_rank = st.comm ? st.comm->rank : 0;
+    ctx->comm_size = st.comm ? st.comm->size : 1;
 }
 static inline Strip strip_from_comm(const tdx_comm* comm, int nx, int ny_local) {
     Strip s; s.nx = nx; s.ny_arr = ny_local + 2; s.y0 = 1; s.y1 = ny_local + 1; s.comm = comm;
@@ -64,10 +73,34 @@ __global__ void merge_row_kernel(T* halo, const T* recv, int nx, unsigned long l
 }
 }  // namespace stripk
 
+// Waits for the context's stream like hipStreamSynchronize, but BOUNDED when other ranks are involved: a collective whose partner never
+// arrives (a rank that failed, took another branch or stalled) would hang the job with no hint; after TDX_COMM_TIMEOUT seconds (default
+// 600) the call fails and says which rank waited for what, in which stage, after how many exchanges.
+static inline int strip_wait(tdx_context* ctx, const Strip& st, const char* what) {
+    if (!st.multi()) { TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return TDX_OK; }
+    static const double limit_s = getenv("TDX_COMM_TIMEOUT") ? atof(getenv("TDX_COMM_TIMEOUT")) : 600.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return TDX_OK;
+        if (e != hipErrorNotReady) { TDX_HIP_CHECK(ctx, e); }
+        if (spins > 2000) {   // ~100 us of pure polling first: the common wait is one small kernel + one row copy
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((spins & 1023u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                char msg[320];
+                snprintf(msg, sizeof msg, "rank %d of %d stalled in %s: %s did not complete within %.0f s (exchange %lld, all-reduce %lld of this call); a "
+                         "neighbouring rank has probably failed or left the loop - TDX_COMM_TRACE=1 prints every rank's counts per stage",
+                         ctx->comm_rank, ctx->comm_size, ctx->stage, what, limit_s, (long long)ctx->comm_exchanges, (long long)ctx->comm_allreduces);
+                return tdx_fail(ctx, TDX_ERR_HIP, msg);
+            }
+        }
+    }
+}
+
 // stream-ordered transport (RCCL): exchange() enqueues on the context's stream, no synchronisation around it
 static inline bool strip_ordered(const Strip& st) { return st.comm && (st.comm->flags & TDX_COMM_STREAM_ORDERED) != 0; }
 static inline int strip_pre_exchange_sync(tdx_context* ctx, const Strip& st) {
-    if (!strip_ordered(st)) TDX_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!strip_ordered(st)) return strip_wait(ctx, st, "the work before an exchange");
     return TDX_OK;
 }
 
@@ -76,24 +109,26 @@ static inline int strip_pre_exchange_sync(tdx_context* ctx, const Strip& st) {
 // one collective and ONE synchronisation; otherwise device -> host, synchronise, host all-reduce.
 static inline int strip_allreduce_device(tdx_context* ctx, const Strip& st, unsigned long long* d_v, int count, int op, int64_t* host_out) {
     hipStream_t s = ctx->stream;
+    if (st.multi()) ctx->comm_allreduces++;
     if (st.multi() && st.comm->allreduce_dev) {
         if (st.comm->allreduce_dev(st.comm->user, reinterpret_cast<int64_t*>(d_v), count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce_dev failed");
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 48, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
-        TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[48 + i]);
+        TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+        if (int rcw = strip_wait(ctx, st, "a device all-reduce (termination vote)")) return rcw;
+        for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[TDX_MAIL_STRIP_REDUCE + i]);
         return TDX_OK;
     }
-    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 48, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
-    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[48 + i]);
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+    if (int rcw = strip_wait(ctx, st, "the counters of a vote")) return rcw;
+    for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[TDX_MAIL_STRIP_REDUCE + i]);
     if (!st.multi()) return TDX_OK;
-    if (st.comm->allreduce(st.comm->user, host_out, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed");
+    if (st.comm->allreduce(st.comm->user, host_out, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     return TDX_OK;
 }
 
 static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v, int count, int op) {
     if (!st.multi()) return TDX_OK;
-    if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed");
+    ctx->comm_allreduces++;
+    if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     return TDX_OK;
 }
 
@@ -117,13 +152,14 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, arr + size_t(st.y0) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, arr + size_t(st.y1 - 1) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
-    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
+    ctx->comm_exchanges++;
+    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (!tile_flags && !nchanged) {
         if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y0 - 1) * nx, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
         if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y1) * nx, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
         return TDX_OK;
     }
-    unsigned long long* d_n = reinterpret_cast<unsigned long long*>(ctx->d_mail) + 40;
+    unsigned long long* d_n = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_STRIP_CHANGED;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), s));
     if (st.up) {
         const int yh = st.y0 - 1;
@@ -141,9 +177,9 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
         if (nchanged) *nchanged = total;
         return TDX_OK;
     }
-    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + 40, d_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    if (nchanged) *nchanged = int64_t(ctx->h_mail[40]);
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_CHANGED, d_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (int rcw = strip_wait(ctx, st, "a halo exchange")) return rcw;
+    if (nchanged) *nchanged = int64_t(ctx->h_mail[TDX_MAIL_STRIP_CHANGED]);
     return TDX_OK;
 }
 
@@ -159,7 +195,8 @@ static inline int strip_exchange_buffers(tdx_context* ctx, const Strip& st, cons
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, up_src, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, down_src, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
-    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed");
+    ctx->comm_exchanges++;
+    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (st.up && up_dst != c->recv_up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(up_dst, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down && down_dst != c->recv_down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(down_dst, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
     return TDX_OK;

@@ -48,6 +48,7 @@ struct TileGeom {
     int tiles_x, tiles_y;
     int y_own0, y_own1;     // rows [y_own0, y_own1) may be updated; others are read-only halo rows
     int max_sweeps;         // sweeps per activation before a tile yields (it re-activates itself)
+    int chain_max;          // solo rounds: tile hand-overs inside one launch (0 = one tile per launch; TDX_SOLO_CHAIN)
 };
 
 static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
@@ -57,6 +58,8 @@ static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
     g.y_own0 = y_own0; g.y_own1 = y_own1;
     static const int ms = getenv("TDX_MAX_SWEEPS") ? atoi(getenv("TDX_MAX_SWEEPS")) : MAX_SWEEPS;
     g.max_sweeps = ms;
+    static const int cm = getenv("TDX_SOLO_CHAIN") ? atoi(getenv("TDX_SOLO_CHAIN")) : 256;
+    g.chain_max = cm;
     return g;
 }
 
@@ -122,6 +125,7 @@ struct TileLds {   // LDS of one workgroup
     unsigned next;
     unsigned long long base;
     unsigned npend;                   // tiles activated by this workgroup and not yet appended to the next round's list
+    int chain;                        // solo rounds: the one tile this activation hands over to (bit 31: with FLAG_FULL), -1 = none / several
     uint32_t pend[PULL_MAX * 9];
 };
 
@@ -633,10 +637,11 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
 // are collected in LDS and appended with ONE atomic on the next round's counter per pull of the cursor: a single hot
 // address sustains only ~90 M atomics/s on MI355X, which is 0.7 ms for a round over all 65536 tiles of a 16384^2 raster.
 // Only lanes of wave 0 push; relax_kernel flushes with the whole workgroup between two barriers.
-__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, TileLds& L) {
+// the tile that direction bit `tid` of `res` (bits 0-7: N S W E NW NE SW SE rim parts; lane 8: the tile itself when capped) activates, or -1
+__device__ __forceinline__ int activation_target(int res, int tile, const TileGeom& g, uint32_t* flag) {
     const int tid = threadIdx.x;
     int target = -1;
-    uint32_t flag = FLAG_HALO;
+    *flag = FLAG_HALO;
     if (tid < 8 && ((res >> tid) & 1)) {
         const int ddx[8] = {0, 0, -1, 1, -1, 1, -1, 1};
         const int ddy[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
@@ -644,7 +649,12 @@ __device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeo
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
         if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) target = nty * g.tiles_x + ntx;
     }
-    if (tid == 8 && (res & RES_CAPPED)) { target = tile; flag = FLAG_FULL; }   // not yet at its fixed point: run again, everything dirty
+    if (tid == 8 && (res & RES_CAPPED)) { target = tile; *flag = FLAG_FULL; }   // not yet at its fixed point: run again, everything dirty
+    return target;
+}
+__device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, TileLds& L) {
+    uint32_t flag;
+    const int target = activation_target(res, tile, g, &flag);
     if (target >= 0 && atomicMax(&flags_next[target], flag) == 0u) L.pend[atomicAdd(&L.npend, 1u)] = uint32_t(target);
 }
 // ---- schedule 1: rounds, ONE launch per round.  Workgroups pull the tiles of the current round's list from a device
@@ -659,6 +669,7 @@ template <class Body>
 __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_cur,
                                              uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next, unsigned pull_max, const TileGeom& g,
                                              TileLds& L, Body body) {
+    const int chain_max = g.chain_max;
     const unsigned nact = unsigned(count[0]);
     const uint32_t entry0 = list[blockIdx.x];          // for a small round (below); fetched together with the count: gridDim.x <= number of tiles
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
@@ -686,10 +697,32 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
         if (first >= nact) break;
         const unsigned last = first + pull < nact ? first + pull : nact;
         for (unsigned it = first; it < last; it++) {
-            const int tile = fixed ? int(entry0) : int(list[it]);
+            int tile = fixed ? int(entry0) : int(list[it]);
             const bool full = flags_cur[tile] >= FLAG_FULL;
-            const int res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
+            int res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
             if (threadIdx.x == 0) flags_cur[tile] = 0u;
+            // A SOLO round (one active tile in the whole raster: the tail of every dependency sweep is one chain of such rounds, the
+            // longest flow path crossing one tile per round) hands over inside the launch: while an activation activates exactly one
+            // tile, this workgroup - the only one running - goes on into it, instead of a list append, the end of the kernel, the next
+            // launch and its count -> list -> flag -> data chain of dependent loads (~15 us per tile crossing).  Nobody else reads or
+            // writes during a solo round, so the only ordering needed is this workgroup's own stores before its next loads.
+            if (nact == 1u && chain_max > 0) {
+                for (int hop = 0; hop < chain_max && (res & (RES_CHANGED | RES_CAPPED)); hop++) {
+                    uint32_t flag;
+                    const int target = activation_target(res, tile, g, &flag);
+                    if (threadIdx.x < 64) {
+                        const unsigned long long b = __ballot(target >= 0);
+                        if (target >= 0 && (b & (b - 1ull)) == 0ull) L.chain = target | (flag >= FLAG_FULL ? int(0x80000000u) : 0);
+                        if (threadIdx.x == 0 && (b == 0ull || (b & (b - 1ull)) != 0ull)) L.chain = -1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // this lane's write-back has landed, its cached lines are dropped
+                    __syncthreads();
+                    const int ch = L.chain;
+                    if (ch == -1) break;
+                    tile = ch & 0x7fffffff;
+                    res = body(tile, ch < 0);   // (its first barrier comes after every lane has read L.chain)
+                }
+            }
             if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, L);
         }
     }
@@ -968,7 +1001,7 @@ struct RoundRunner {
             r_enq = 0;
         }
         const int slot = n_enq & 1;
-        uint64_t* hs = h + slot * 64;
+        uint64_t* hs = h + slot * TDX_MAIL_RUN_SLOT;
         const int r = r_enq, parity = parity_enq;   // (shadow the collected state inside this function)
         const bool timed = ctx->kernel_timing && s == ctx->stream;
         // the tail of a relaxation: a small grid launches faster (any grid size is correct, the cursor covers the list)
@@ -1005,7 +1038,7 @@ struct RoundRunner {
     }
     void collect() {   // the oldest batch in flight; its counts must have arrived (wait_oldest() or a synchronised stream)
         const int slot = n_col & 1, nb = fl_batch[slot];
-        const uint64_t* hs = h + slot * 64;
+        const uint64_t* hs = h + slot * TDX_MAIL_RUN_SLOT;
         for (int b = 0; b < nb; b++) {
             if (hs[b] == 0) { done = true; break; }
             last_count = hs[b];
@@ -1049,7 +1082,7 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     }
     TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + 128, nullptr);
+    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail + TDX_MAIL_RUN_A, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + TDX_MAIL_RUN_B, nullptr);
     B.ev_base = 2;
     A.batch_max = B.batch_max = RoundRunner<Op>::pipelined_batch_max();
     int rc = A.start();
@@ -1091,7 +1124,7 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     static const bool force_rounds = getenv("TDX_RELAX_ASYNC") == nullptr;
     unsigned long long* dbg = nullptr;
     if (debug) {
-        dbg = reinterpret_cast<unsigned long long*>(ctx->d_mail) + 32;
+        dbg = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_DBG_RELAX;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 128, s));
     }
     int64_t rounds = 0, launches = 0;
@@ -1105,7 +1138,7 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
         need_rounds = gave_up;
     }
     if (need_rounds) {
-        RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail, dbg);
+        RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail + TDX_MAIL_RUN_A, dbg);
         run.print_counts = debug_level > 0;
         if (debug_level == 2) fprintf(stderr, "\nrounds(%d tiles):", ntiles);
         int rc = run.drive();

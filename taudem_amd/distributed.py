@@ -173,6 +173,72 @@ class RcclStripComm:
             self._h = None
 
 
+class _GroupComm:
+    """The tdx_comm of one rank of a StripGroup (owned by the group)."""
+
+    def __init__(self, ptr, backend):
+        self._ptr, self.backend = ptr, backend
+
+    def ptr(self):
+        return self._ptr
+
+
+class StripGroup:
+    """N row strips driven from ONE process: the library's own rank group (tdx_group_create, include/taudem_amd.h) - one context and
+    one tdx_comm per rank; ranks that each have a device talk over RCCL, ranks that share a device over the in-process peer transport
+    (host barriers + device copies).  `run(fn)` calls fn(rank, ctx, comm) on one thread per rank (the C calls release the GIL) and
+    returns the results in rank order.  This is what `tool --gpus N` does in C++ (tool_strips.hpp); here it serves the tests and
+    bench.py's functional many-strips-on-one-GPU runs."""
+
+    def __init__(self, size: int, nx: int, devices=None):
+        from .api import Context
+
+        self._lib = _lib.load()
+        self.size, self.nx = int(size), int(nx)
+        devs = list(devices) if devices is not None else [0] * self.size
+        arr = (C.c_int32 * self.size)(*devs)
+        g = C.c_void_p()
+        check(self._lib.tdx_group_create(self.size, arr, self.nx, C.byref(g)))
+        self._g = g
+        self.transport = self._lib.tdx_group_transport(g).decode()
+        self.contexts = [Context.borrow(self._lib.tdx_group_context(g, r), devs[r]) for r in range(self.size)]
+        self.comms = [_GroupComm(C.c_void_p(self._lib.tdx_group_comm(g, r)), self.transport) for r in range(self.size)]
+
+    def run(self, fn):
+        import threading
+
+        out, err = [None] * self.size, []
+
+        def main(r):
+            try:
+                out[r] = fn(r, self.contexts[r], self.comms[r])
+            except BaseException as e:   # noqa: BLE001 - reported below; the other ranks would wait for this one forever
+                import traceback
+                err.append((r, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+
+        th = [threading.Thread(target=main, args=(r,), daemon=True) for r in range(self.size)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise RuntimeError("StripGroup rank(s) failed:\n" + "\n".join(f"[rank {r}] {m}" for r, m in sorted(err)))
+        return out
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for c in self.contexts:
+                c.close()
+            self._lib.tdx_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def _tptr(t, dtype, shape, name):
     import torch
 
