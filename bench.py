@@ -15,6 +15,15 @@ resident in HBM (generated on the device by tdx_synth_dem_dev).
           carries the timing barrier.  TDX_BENCH_BACKEND=gloo: host-staged Python transport (several ranks may share a GPU;
           functional check only).
 --nx/--ny set the TOTAL raster explicitly (ny rows are split over the ranks).  Rank 0 prints ONE JSON line.
+
+Beside the pipeline, the N = 1 line carries (outside the timed region, one step each, `--no-extras` skips them)
+  config3        BASELINE.json configs[2]: DinfFlowDir + AreaDinf on a 32768 x 32768 DEM (ms, Mcells/s, the accumulation sweeps' roofline)
+  config5_strip  BASELINE.json configs[4] as ONE GPU sees it: DinfDecayAccum with weights, decay multipliers and 64 outlets on a
+                 65536 x 8192 strip
+and `--workload decay` times configs[4] itself: DinfDecayAccum -wg -o on ONE raster of 65536 columns x 8192*N rows in row strips
+(the D-infinity angles come from PitRemove -> DinfFlowDir on the same strips, outside the timed region).
+`--in-process` (N > 1): the N strips are N rank threads of THIS process on the library's own rank group (tdx_group: RCCL when every
+rank has a GPU, peer copies when ranks share one - how eight 65536 x 8192 strips run on one 288 GB GPU); functional check, no torchrun.
 """
 import argparse
 import json
@@ -66,6 +75,9 @@ def parse():
     ap.add_argument("--ny", type=int, default=0, help="rows of the whole raster (split over the ranks)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="edge length of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=("d8", "decay"), default="d8", help="d8: PitRemove->D8FlowDir->AreaD8 (the metric); decay: DinfDecayAccum -wg -o on strips")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the config3 / config5_strip legs after the timed region")
+    ap.add_argument("--in-process", action="store_true", help="N > 1: rank threads of this process (tdx_group) instead of one process per rank")
     return ap.parse_args()
 
 
@@ -150,8 +162,237 @@ def cpu_baseline(sample_n, seed):
             "sample": f"{sample_n}x{sample_n} synthetic DEM seed {seed}: C restatement (oracle/taudem_oracle.c), 1 thread, {secs:.2f} s"}
 
 
+# ---- BASELINE.json configs[4] / configs[2] legs -------------------------------------------------------------------------------------
+DECAY_BYTES_PER_CELL = 16    # dinfdecayaccum ang 4 + dm 4 + dsca 4, + 4 with weights
+AREADINF_BYTES_PER_CELL = 8  # ang 4 + sca 4
+
+
+def hashed_uniform(torch, device, nx, y0, nrows, salt, lo, hi, out):
+    """out[r, c] = U[lo, hi) as a function of (global row y0 + r, column c, salt) only - the same raster whatever the partition.
+    (32-bit integer mix carried in int64 lanes, in chunks of rows so that the temporaries stay small.)"""
+    cols = torch.arange(nx, device=device, dtype=torch.int64).view(1, -1) * 0x85EBCA77
+    for r0 in range(0, nrows, 1024):
+        r1 = min(nrows, r0 + 1024)
+        x = (torch.arange(y0 + r0, y0 + r1, device=device, dtype=torch.int64).view(-1, 1) * 0x9E3779B1 + cols + salt) & 0xFFFFFFFF
+        x = ((x ^ (x >> 15)) * 0x2C1B3C6D) & 0xFFFFFFFF
+        x = ((x ^ (x >> 12)) * 0x297A2D39) & 0xFFFFFFFF
+        x = x ^ (x >> 15)
+        out[r0:r1] = (lo + (hi - lo) * ((x >> 8).to(torch.float32) * (1.0 / 16777216.0))).to(torch.float32)
+
+
+class DecayStrip:
+    """BASELINE.json configs[4] on one strip: synthetic DEM -> PitRemove -> DinfFlowDir (outside the timed region), weights ~ U[0,1),
+    decay multipliers ~ U[0.9,1) (SURVEY.md 8d iii), outlets on the highest-accumulation cell of each block of an 8 x 8 lattice over
+    the WHOLE raster (8d iv: up to 64 outlets; a block's rows lie in one strip, so every rank finds its own outlets - the upstream
+    closure then crosses the strips through the halo exchange).  step() = DinfDecayAccum -wg -o."""
+
+    def __init__(self, torch, ctx, comm, nx, ny, y0, nyl, seed, T):
+        from taudem_amd.distributed import StripPipeline
+        self.pipe = StripPipeline(ctx, comm, nx, nyl)
+        dev = torch.device(f"cuda:{ctx.device}")
+        dem = self.pipe.empty(torch.float32)
+        ctx.synth_dem((nyl, nx), seed=seed, x0=0, y0=y0, base_wavelength=T.synth_base_wavelength(max(nx, ny)), out=dem[1:nyl + 1])
+        fel, _ = self.pipe.pitremove(dem, -9999.0)
+        self.ang, slp, self.flowdir_stats = self.pipe.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+        del dem, fel
+        sca, self.areadinf_stats = self.pipe.areadinf(self.ang, dx=30.0, dy=30.0, out=slp)
+        # outlets: per lattice block the owned cell with the largest unweighted D-infinity area
+        bh, bw = max(1, ny // 8), max(1, nx // 8)
+        ox, oy = [], []
+        for by in range(8):
+            g0, g1 = by * bh, (ny if by == 7 else (by + 1) * bh)
+            if g0 < y0 or g1 > y0 + nyl:
+                continue                       # another rank's block (blocks nest in strips for 1, 2, 4, 8 ranks)
+            for bx in range(8):
+                c0, c1 = bx * bw, (nx if bx == 7 else (bx + 1) * bw)
+                blk = sca[1 + g0 - y0:1 + g1 - y0, c0:c1]
+                k = int(torch.argmax(blk))
+                oy.append(g0 - y0 + 1 + k // (c1 - c0))       # strip-array row
+                ox.append(c0 + k % (c1 - c0))
+        self.outlets = (ox, oy)
+        self.w = sca                            # the area raster is not needed any more: reuse it for the weights
+        hashed_uniform(torch, dev, nx, y0, nyl, 0x1234567 + seed, 0.0, 1.0, self.w[1:nyl + 1])
+        self.dm = self.pipe.empty(torch.float32)
+        hashed_uniform(torch, dev, nx, y0, nyl, 0x7654321 + seed, 0.9, 1.0, self.dm[1:nyl + 1])
+        self.out = self.pipe.empty(torch.float32)
+        self.nyl = nyl
+
+    def step(self):
+        _, st = self.pipe.dinfdecayaccum(self.ang, self.dm, weights=self.w, outlets=self.outlets, out=self.out)
+        return st
+
+    def evaluated_cells(self, torch):
+        return int((self.out[1:self.nyl + 1] != -3.402823466e38).sum())
+
+
+def config3_leg(torch, ctx, seed):
+    """BASELINE.json configs[2]: DinfFlowDir + AreaDinf on a 32768 x 32768 synthetic DEM, one step after one warm-up step."""
+    n = 32768
+    dem = ctx.synth_dem(n, seed=seed)
+    fel = ctx.pitremove(dem, -9999.0)
+    ang, slp, sca = dem, torch.empty_like(fel), torch.empty_like(fel)   # (the raw surface is not needed any more)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, s1 = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0, out=(ang, slp), stats=True)
+        _, s2 = ctx.areadinf(ang, dx=30.0, dy=30.0, out=sca, stats=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+    cells = float(n) * n
+    sweep_ms, sweep_launches = s2["ms_accum"], max(1, s2["launches_accum"])
+    achieved = AREADINF_BYTES_PER_CELL * cells / (sweep_ms * 1e-3) / 1e9
+    return {"workload": f"{n}x{n} synthetic fractal DEM (seed {seed}, pit-filled), DinfFlowDir + AreaDinf in HBM on one GPU; parity at this size: "
+                        "tests/test_gpu_fullsize.py::test_dinf_config3_at_32768 (sweep verifier + the restatement's linear-time checks)",
+            "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "dinfflowdir_ms": s1["ms_total"], "areadinf_ms": s2["ms_total"],
+            "dinfflowdir_classes_ms": {k: s1["ms_" + k] for k in ("stencil", "bfs", "flatdir", "misc")},
+            "areadinf_classes_ms": {k: s2["ms_" + k] for k in ("stencil", "accum")}, "areadinf_rounds": s2["rounds"],
+            "roofline": {"bound": "hbm", "kernel": "areadinf: dsweep32::sweep_kernel (bulk rounds) + dsweep64::sweep_kernel (tail)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "launches": sweep_launches,
+                         "avg_launch_ms": sweep_ms / sweep_launches, "algorithmic_bytes_per_cell": AREADINF_BYTES_PER_CELL,
+                         "note": "dependency sweep: bound by the longest flow path (tile crossings x in-tile chain), not by bandwidth"}}
+
+
+def config5_strip_leg(torch, ctx, seed, T):
+    """BASELINE.json configs[4] as one GPU sees it: DinfDecayAccum -wg -o on a 65536 x 8192 raster (no neighbours)."""
+    nx, ny = 65536, 8192
+    job = DecayStrip(torch, ctx, None, nx, ny, 0, ny, seed, T)
+    job.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = job.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    cells = float(nx) * ny
+    return {"workload": f"{nx}x{ny} strip of the synthetic DEM (seed {seed}): DinfDecayAccum with weights, decay multipliers and {len(job.outlets[0])} outlets "
+                        "(highest D-infinity area per block of an 8x8 lattice), in HBM on one GPU",
+            "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "rounds": st["rounds"], "cells_in_the_outlets_catchments": job.evaluated_cells(torch),
+            "classes_ms": {k: st["ms_" + k] for k in ("stencil", "bfs", "accum", "misc")},
+            "algorithmic_gb_per_s": DECAY_BYTES_PER_CELL * cells / (ms * 1e-3) / 1e9}
+
+
+def decay_line(world, nx, ny, args, ms_per_step, st, comm_info, job_cells_evaluated, functional):
+    total = float(nx) * float(ny)
+    out = {"metric": "Mcells/s (DinfDecayAccum -wg -o)", "value": total / ms_per_step / 1e3, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"{nx} columns x {ny} rows synthetic fractal DEM (seed {args.seed}) in {world} row strip(s): DinfDecayAccum with weights, decay "
+                                  "multipliers and up to 64 outlets (BASELINE.json configs[4] at 8 strips of 65536 x 8192)", "nx": nx, "ny": ny,
+                      "total_cells": int(total), "cells_in_the_outlets_catchments": job_cells_evaluated},
+           "rank0_classes_ms": {k: st["ms_" + k] for k in ("stencil", "bfs", "accum", "misc")}, "rank0_rounds": st["rounds"], "outer_rounds": st["cells_evaluated"]}
+    if comm_info:
+        out["comm"] = comm_info
+    if functional:
+        out["functional_only"] = "ranks share GPUs: a check of the strip protocol at this size, not a throughput figure"
+    return out
+
+
+def run_in_process(args):
+    """N strips as N rank threads of this process (taudem_amd.distributed.StripGroup): the library's own rank group."""
+    import threading
+
+    import torch
+
+    import taudem_amd as T
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+
+    world = args.gpus
+    ndev = torch.cuda.device_count()
+    nx, ny = (args.nx or args.ny or 65536), (args.ny or args.nx or 8192 * world)
+    if args.size:
+        nx, ny = args.size, args.size * world
+    devices = [r % ndev for r in range(world)]
+    parts = partition_rows(ny, world)
+    bar = threading.Barrier(world)
+    lib = T.load()
+
+    def counters(c):
+        import ctypes as C
+        e, a = C.c_int64(), C.c_int64()
+        lib.tdx_context_comm_counters(c._h, C.byref(e), C.byref(a))
+        return e.value, a.value
+
+    with StripGroup(world, nx, devices) as grp:
+        def rank_main(r, c, comm):
+            torch.cuda.set_device(devices[r])
+            y0, y1 = parts[r]
+            nyl = y1 - y0
+            res = {}
+            if args.workload == "decay":
+                job = DecayStrip(torch, c, comm, nx, ny, y0, nyl, args.seed, T)
+                step = job.step
+            else:
+                pipe = StripPipeline(c, comm, nx, nyl)
+                dem = pipe.empty(torch.float32)
+                c.synth_dem((nyl, nx), seed=args.seed, x0=0, y0=y0, base_wavelength=T.synth_base_wavelength(max(nx, ny)), out=dem[1:nyl + 1])
+                fel, p, sd8, ad8 = pipe.empty(torch.float32), pipe.empty(torch.int16), pipe.empty(torch.float32), pipe.empty(torch.float32)
+                marks = []
+
+                def step():
+                    c0 = counters(c)
+                    _, s1 = pipe.pitremove(dem, -9999.0, out=fel)
+                    c1 = counters(c)
+                    _, _, s2 = pipe.d8flowdir(fel, -3.0e38, 30.0, 30.0, out=(p, sd8))
+                    c2 = counters(c)
+                    _, s3 = pipe.aread8(p, -32768, contcheck=False, out=ad8)   # (no edge contamination: every cell with a direction gets its count)
+                    c3 = counters(c)
+                    marks.append([(b[0] - a[0], b[1] - a[1]) for a, b in ((c0, c1), (c1, c2), (c2, c3))])
+                    return s1, s2, s3
+            for _ in range(args.warmup):
+                step()
+            bar.wait(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                st = step()
+            torch.cuda.synchronize(); bar.wait()
+            res["elapsed"] = time.perf_counter() - t0
+            res["stats"] = st
+            if args.workload == "decay":
+                res["evaluated"] = job.evaluated_cells(torch)
+                res["outlets"] = len(job.outlets[0])
+                res["counters"] = counters(c)
+            else:
+                res["marks"] = marks[-1]
+                # conservation of AreaD8 on this strip (src/aread8.cpp:231-256): every owned cell with a direction is counted exactly once at the
+                # cells that drain out of the raster or into a cell without direction - checked through the global count of evaluated cells
+                own = ad8[1:nyl + 1]
+                res["ad8_max"] = float(own.max())
+                res["ad8_evaluated"] = int((own >= 1).sum())
+                res["p_valid"] = int(((p[1:nyl + 1] >= 1) & (p[1:nyl + 1] <= 8)).sum())
+            return res
+        res = grp.run(rank_main)
+        transport = grp.transport
+    elapsed = max(r["elapsed"] for r in res)
+    ms = elapsed / args.steps * 1e3
+    functional = len(set(devices)) < world
+    if args.workload == "decay":
+        e, a = res[0]["counters"]
+        line = decay_line(world, nx, ny, args, ms, res[0]["stats"], {"transport": transport + " (in-process rank group)", "rank0_exchanges_total": e,
+                                                                     "rank0_allreduces_total": a, "outlets": sum(r["outlets"] for r in res)},
+                          sum(r["evaluated"] for r in res), functional)
+    else:
+        total = float(nx) * float(ny)
+        s1, s2, s3 = res[0]["stats"]
+        last = res[0]["marks"]
+        evaluated, valid = sum(r["ad8_evaluated"] for r in res), sum(r["p_valid"] for r in res)
+        line = {"metric": "Mcells/s (PitRemove->D8FlowDir->AreaD8 pipeline)", "value": total / ms / 1e3, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{nx} columns x {ny} rows synthetic fractal DEM (seed {args.seed}) row-partitioned into {world} strips of {nx} x {ny // world} "
+                                       f"(+ halo rows) on {len(set(devices))} GPU(s), PitRemove->D8FlowDir->AreaD8 in HBM", "nx": nx, "ny": ny, "total_cells": int(total)},
+                "stage_ms_per_step_rank0": {"pitremove": s1["ms_total"], "d8flowdir": s2["ms_total"], "aread8": s3["ms_total"]},
+                "comm": {"transport": transport + " (in-process rank group)",
+                         "exchanges_per_step": {"pitremove": last[0][0], "d8flowdir": last[1][0], "aread8": last[2][0]},
+                         "allreduces_per_step": {"pitremove": last[0][1], "d8flowdir": last[1][1], "aread8": last[2][1]}},
+                "checks": {"ad8_cells_evaluated": evaluated, "cells_with_direction": valid, "every_directed_cell_evaluated": evaluated == valid,
+                           "ad8_max": max(r["ad8_max"] for r in res)}}
+        if functional:
+            line["functional_only"] = "ranks share GPUs: a check of the strip protocol at this size, not a throughput figure"
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.in_process and args.gpus > 1:
+        return run_in_process(args)
     import torch
     import torch.distributed as dist
 
@@ -187,6 +428,46 @@ def main():
         nx, ny = 65536, 8192 * world          # 65536 x 8192 strips; world = 8: BASELINE.json configs[3] (65536 x 65536)
     ctx = T.Context(dev)
     device = torch.device(f"cuda:{dev}")
+
+    if args.workload == "decay":
+        # BASELINE.json configs[4]: DinfDecayAccum -wg -o on row strips (one rank per GPU; world = 1: one raster, no neighbours)
+        if not (args.nx or args.ny or args.size):
+            nx, ny = 65536, 8192 * world
+        y0, y1 = partition_rows(ny, world)[rank]
+        comm = None if world == 1 else (RcclStripComm(ctx, nx) if backend == "nccl" else StripComm(nx, device=dev))
+        job = DecayStrip(torch, ctx, comm, nx, ny, y0, y1 - y0, args.seed, T)
+
+        def sync():
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            job.step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = job.step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        evaluated, outlets = job.evaluated_cells(torch), len(job.outlets[0])
+        if dist.is_initialized():
+            t = torch.tensor([elapsed, float(evaluated), float(outlets)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+            elapsed, evaluated, outlets = float(t[0]), int(t[1]), int(t[2])
+        info = None
+        if comm is not None:
+            info = {"transport": getattr(comm, "backend", backend), "rank0_exchanges_total": comm.exchanges, "rank0_allreduces_total": comm.allreduces, "outlets": outlets}
+        line = json.dumps(decay_line(world, nx, ny, args, elapsed / args.steps * 1e3, st, info, evaluated, backend != "nccl" and world > 1))
+        sys.stdout.flush()
+        if dist.is_initialized():
+            dist.barrier()
+        if rank == 0:
+            print(line, flush=True)
+        if dist.is_initialized():
+            sys.stderr.flush()
+            os._exit(0)
+        return
 
     force_strips = os.environ.get("TDX_BENCH_FORCE_STRIPS") == "1"   # the strip path (and its transport) with one rank
     if force_strips and not dist.is_initialized():
@@ -335,6 +616,17 @@ def main():
                            "allreduces_per_step": {"pitremove": last[0][1], "d8flowdir": last[1][1], "aread8": last[2][1]}}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.seed)
+        if world == 1 and comm is None and not args.no_extras and not (args.size or args.nx or args.ny):
+            # the other single-GPU configurations of BASELINE.json, one step each, outside the timed region (an error in one of them must
+            # not cost the line of record)
+            del dem, fel, p, sd8, ad8
+            torch.cuda.empty_cache()
+            for key, leg in (("config3", lambda: config3_leg(torch, ctx, args.seed)), ("config5_strip", lambda: config5_strip_leg(torch, ctx, args.seed, T))):
+                try:
+                    out[key] = leg()
+                except Exception as e:   # noqa: BLE001
+                    out[key] = {"error": f"{e.__class__.__name__}: {e}"}
+                torch.cuda.empty_cache()
         line = json.dumps(out)
     # The JSON line is the LAST thing on stdout: whatever any rank or the C runtimes (RCCL prints a version banner
     # through C stdio) have buffered goes out first, and the ranks leave without running teardown code that prints.

@@ -93,6 +93,8 @@ const char* tdx_version(void);
  * with HIP events (TDX_K_TILEK in tdx_stats) - two event records per launch, so it is off unless asked for. */
 int tdx_context_set_option(tdx_context* ctx, const char* name, int64_t value);
 int tdx_device_count(void);
+/* halo exchanges and all-reduces this context has taken part in since it was created (strip runs; 0 on a single strip) */
+void tdx_context_comm_counters(const tdx_context* ctx, int64_t* exchanges, int64_t* allreduces);
 
 /* device memory helpers so that callers without a HIP binding (ctypes, cgo ...) can stage data */
 int tdx_device_alloc(tdx_context* ctx, uint64_t bytes, void** dptr);

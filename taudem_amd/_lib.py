@@ -179,6 +179,7 @@ _SIGNATURES = {
     "tdx_rccl_comm_counters": (None, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "tdx_rccl_comm_destroy": (None, [_P]),
     "tdx_rccl_selftest": (C.c_int, [_P]),
+    "tdx_context_comm_counters": (None, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tdx_group_create": (C.c_int, [C.c_int32, _P, _I64, C.POINTER(_P)]),
     "tdx_group_context": (_P, [_P, C.c_int32]),
     "tdx_group_comm": (_P, [_P, C.c_int32]),

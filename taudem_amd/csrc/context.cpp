@@ -96,6 +96,11 @@ int tdx_context_set_option(tdx_context* c, const char* name, int64_t value) {
     return tdx_fail(c, TDX_ERR_ARG, std::string("unknown option ") + name);
 }
 
+void tdx_context_comm_counters(const tdx_context* c, int64_t* exchanges, int64_t* allreduces) {
+    if (exchanges) *exchanges = c ? c->comm_exchanges_total : 0;
+    if (allreduces) *allreduces = c ? c->comm_allreduces_total : 0;
+}
+
 int tdx_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

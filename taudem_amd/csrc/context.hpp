@@ -60,6 +60,7 @@ struct tdx_context {
     const char* stage = "";                   // tool stage of the running call ("pitremove", "d8flowdir" ...)
     int comm_rank = 0, comm_size = 1;
     int64_t comm_exchanges = 0, comm_allreduces = 0;   // of the running call
+    int64_t comm_exchanges_total = 0, comm_allreduces_total = 0;   // since the context was created (tdx_context_comm_counters)
 
     hipEvent_t get_event();
     void begin_call(tdx_stats* st);

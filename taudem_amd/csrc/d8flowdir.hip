@@ -32,16 +32,24 @@ constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-t
 // One lane walks down a column segment keeping the 3x3 window in registers.  A wave covers 62 output columns: lanes 0 and 63
 // only carry the columns beside them, so the west / east neighbours of a row are DPP lane shifts of the ONE value each lane
 // loads per row (v_mov_b32_dpp wave_shr:1 / wave_shl:1) - a third of the load instructions and of the L1 traffic of three
-// overlapping row loads per lane.  Besides p and sd8 it appends the flat cells to `qlist` with ONE atomic per block.
+// overlapping row loads per lane.
+// Flat cells (no positive slope) leave ONE BIT each: lane (x, band of 16 rows) stores its 16-bit row mask to flatbits[band][x].
+// (Round 2 appended them to the flat queue here, with one returning atomic per block on ONE counter: ~45 000 same-address atomics at
+// ~90 M/s were 0.5 ms of the kernel's 0.95 ms, and every block ended on three barriers waiting for its slot.  The queue is now built
+// from the bit masks by two small kernels and a block scan - no atomics anywhere: flat_count_kernel / flat_list_kernel below.)
+// Nodata tests: each lane tests the 18 values it loaded once and keeps them as a bit mask; the neighbours' flags are lane shifts of
+// the mask (two per 16 rows instead of nine tests per cell).  A cell on the edge of the raster needs no test of its own: a neighbour
+// outside the raster reads as nodata (src/linearpart.h:470-483), which makes the cell contaminated just like src/d8.cpp:383-386 does.
 constexpr int SLOPE_COLS = 62;
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
-                                                       float* __restrict__ SD8, uint32_t* __restrict__ qlist, unsigned long long* __restrict__ nflat) {
+                                                       float* __restrict__ SD8, uint16_t* __restrict__ flatbits) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int lx = threadIdx.x & 63;
     const int x = blockIdx.x * SLOPE_COLS - 1 + lx;
-    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
+    const int band = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * 4 + int(threadIdx.x >> 6));
+    const int ybase = y_own0 + band * SLOPE_ROWS;
     const bool mine = lx >= 1 && lx <= SLOPE_COLS && x < nx;
     const bool inx = x >= 0 && x < nx;
     const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
@@ -52,11 +60,13 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
         const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
         z[j] = Z[size_t(yc) * size_t(nx) + size_t(xc)];
     }
+    unsigned nd = 0;   // bit j: window row j of this column is nodata or outside the raster
 #pragma unroll
     for (int j = 0; j < SLOPE_ROWS + 2; j++) {
         const int y = ybase - 1 + j;
-        if (!inx || y < 0 || y >= ny) z[j] = nodata;   // outside the raster reads as nodata (src/linearpart.h:470-483)
+        if (!inx || y < 0 || y >= ny || is_nodata_f(z[j], nodata)) nd |= 1u << j;
     }
+    const unsigned nd3 = nd | lane_left(nd, 0x3FFFFu) | lane_right(nd, 0x3FFFFu);   // this column or one beside it (a missing lane: outside)
     unsigned flatmask = 0;
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
@@ -70,39 +80,107 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
             int16_t p = TDX_P_NODATA;
             float sd = -1.0f;
             const float z0 = c1;
-            const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
-            if (!edge && !is_nodata_f(z0, nodata)) {
-                const bool con = is_nodata_f(n0, nodata) || is_nodata_f(n1, nodata) || is_nodata_f(n2, nodata) || is_nodata_f(c0, nodata) ||
-                                 is_nodata_f(c2, nodata) || is_nodata_f(s0, nodata) || is_nodata_f(s1, nodata) || is_nodata_f(s2, nodata);
-                if (!con) {
-                    const double* f = fact + size_t(y) * 9;
-                    // fact[j][k]: 1/dx for E,W; 1/dy for N,S; 1/diag for the diagonals (src/d8.cpp:375)
-                    const double fE = f[1], fN = f[3], fD = f[2];
-                    float smax = 0.f;
-                    int dir = 0;
-                    // candidate order 1,3,5,7 then 2,4,6,8; strict '>' keeps the first maximum (src/d8.cpp:113-148).
-                    // calcSlope re-evaluates elevDiff*fact[j][dir] = the winning slope itself; dir == 0 -> 0.
+            if (((nd3 >> r) & 7u) == 0u) {   // the cell and its eight neighbours hold data
+                const double* f = fact + size_t(y) * 9;
+                // fact[j][k]: 1/dx for E,W; 1/dy for N,S; 1/diag for the diagonals (src/d8.cpp:375)
+                const double fE = f[1], fN = f[3], fD = f[2];
+                float smax = 0.f;
+                int dir = 0;
+                // candidate order 1,3,5,7 then 2,4,6,8; strict '>' keeps the first maximum (src/d8.cpp:113-148).
+                // calcSlope re-evaluates elevDiff*fact[j][dir] = the winning slope itself; dir == 0 -> 0.
 #define TDX_D8_TRY(K, F, ZN)                                           \
     {                                                                  \
         const float slope = (float)((F) * (double)(z0 - (ZN)));        \
         if (slope > smax) { smax = slope; dir = K; }                   \
     }
-                    TDX_D8_TRY(1, fE, c2) TDX_D8_TRY(3, fN, n1) TDX_D8_TRY(5, fE, c0) TDX_D8_TRY(7, fN, s1)
-                    TDX_D8_TRY(2, fD, n2) TDX_D8_TRY(4, fD, n0) TDX_D8_TRY(6, fD, s0) TDX_D8_TRY(8, fD, s2)
+                TDX_D8_TRY(1, fE, c2) TDX_D8_TRY(3, fN, n1) TDX_D8_TRY(5, fE, c0) TDX_D8_TRY(7, fN, s1)
+                TDX_D8_TRY(2, fD, n2) TDX_D8_TRY(4, fD, n0) TDX_D8_TRY(6, fD, s0) TDX_D8_TRY(8, fD, s2)
 #undef TDX_D8_TRY
-                    p = int16_t(dir);
-                    if (dir == 0) flatmask |= (1u << r);
-                    sd = smax;
-                }
+                p = int16_t(dir);
+                if (dir == 0) flatmask |= (1u << r);
+                sd = smax;
             }
             P[idx] = p;
             if (SD8) SD8[idx] = sd;
         }
     }
-    unsigned long long pos = block_reserve(unsigned(__popc(flatmask)), nflat);
+    if (mine) flatbits[size_t(band) * size_t(nx) + size_t(x)] = uint16_t(flatmask);
+}
+
+// ---- the flat queue from the bit masks: count per block of 2048 masks, scan the block sums, write the cells (no atomics) ----
+constexpr int FLATQ_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void flat_count_kernel(const uint16_t* __restrict__ bits, size_t nmasks, unsigned* __restrict__ blocksum) {
+    const size_t base = size_t(blockIdx.x) * FLATQ_PER_BLOCK + threadIdx.x;
+    unsigned c = 0;
 #pragma unroll
-    for (int r = 0; r < SLOPE_ROWS; r++)
-        if (flatmask & (1u << r)) qlist[pos++] = uint32_t(size_t(ybase + r) * size_t(nx) + size_t(x));
+    for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
+        const size_t m = base + size_t(i) * 256;
+        if (m < nmasks) c += unsigned(__popc(unsigned(bits[m])));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    __shared__ unsigned sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+// exclusive scan of the block sums in place (one workgroup; a strip has at most a few tens of thousands of blocks); *total = their sum
+__global__ __launch_bounds__(1024) void flat_scan_kernel(unsigned* __restrict__ blocksum, unsigned nblocks, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long sw[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 1024) {
+        const unsigned i = b0 + threadIdx.x;
+        const unsigned long long own = i < nblocks ? blocksum[i] : 0u;
+        unsigned long long v = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long t = __shfl_up(v, off, 64);
+            if (int(threadIdx.x & 63) >= off) v += t;
+        }
+        if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = v;
+        __syncthreads();
+        unsigned long long wave_off = carry;
+        for (unsigned w = 0; w < (threadIdx.x >> 6); w++) wave_off += sw[w];
+        // offsets are 32-bit: a strip has fewer than 2^32 cells
+        if (i < nblocks) blocksum[i] = unsigned(wave_off + v - own);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wave_off + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void flat_list_kernel(const uint16_t* __restrict__ bits, size_t nmasks, int nx, int y_own0, const unsigned* __restrict__ blockoff,
+                                                        uint32_t* __restrict__ list) {
+    const size_t base = size_t(blockIdx.x) * FLATQ_PER_BLOCK + threadIdx.x;
+    unsigned mk[FLATQ_PER_BLOCK / 256];
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
+        const size_t m = base + size_t(i) * 256;
+        mk[i] = m < nmasks ? unsigned(bits[m]) : 0u;
+        c += unsigned(__popc(mk[i]));
+    }
+    unsigned v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off, 64);
+        if (int(threadIdx.x & 63) >= off) v += t;
+    }
+    __shared__ unsigned sw[4];
+    if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned pos = blockoff[blockIdx.x] + v - c;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) pos += sw[w];
+#pragma unroll
+    for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
+        if (!mk[i]) continue;
+        const size_t m = base + size_t(i) * 256;
+        const unsigned band = unsigned(m / size_t(nx)), x = unsigned(m - size_t(band) * size_t(nx));
+        const size_t c0 = size_t(y_own0 + int(band) * SLOPE_ROWS) * size_t(nx) + size_t(x);
+        for (unsigned b = mk[i]; b; b &= b - 1u) list[pos++] = uint32_t(c0 + size_t(__ffs(int(b)) - 1) * size_t(nx));
+    }
 }
 
 // D8 dontCross (src/d8.cpp:54-100) for an interior cell at linear index c
@@ -391,11 +469,24 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    // one bit per owned cell: bands of 16 rows x nx columns of 16-bit row masks (the slope pass's lane = one mask)
+    const int nband = ((st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS)) * 4;
+    const size_t nmasks = size_t(nband) * size_t(inx);
+    const unsigned nqblocks = unsigned((nmasks + FLATQ_PER_BLOCK - 1) / FLATQ_PER_BLOCK);
+    uint16_t* flatbits = static_cast<uint16_t*>(ctx->scratch(TDX_S_N, nmasks * 2));
+    unsigned* blocksum = static_cast<unsigned*>(ctx->scratch(TDX_S_O, size_t(nqblocks) * 4));
+    if (!flatbits || !blocksum) return TDX_ERR_NOMEM;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + SLOPE_COLS - 1) / SLOPE_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
-        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, qlist, d_cnt);
+        dim3 grid((inx + SLOPE_COLS - 1) / SLOPE_COLS, unsigned(nband / 4));
+        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
         if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    {
+        TdxSpan sp(ctx, TDX_K_MISC);
+        hipLaunchKernelGGL(flat_count_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, blocksum);
+        hipLaunchKernelGGL(flat_scan_kernel, dim3(1), dim3(1024), 0, s, blocksum, nqblocks, d_cnt);
+        hipLaunchKernelGGL(flat_list_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, inx, st.y0, blocksum, qlist);
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));

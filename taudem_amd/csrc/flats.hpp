@@ -115,7 +115,8 @@ struct LevelOpT {
     static __device__ __forceinline__ void cell_decode(uint8_t m, int& cst, unsigned& mask) { cst = 0; mask = m; }
     static __device__ __forceinline__ int apply(int, int own, int m) {
         int t = m + INC;
-        if (sizeof(S) == 2 && INC) t = t < LVL_SAT ? t : LVL_SAT;
+        // a real level beyond the int16 range saturates; inf() + 1 (no neighbour reached yet) stays above every value
+        if (sizeof(S) == 2 && INC) t = unsigned(t - LVL_SAT) < unsigned(inf() - LVL_SAT) ? LVL_SAT : t;
         return t < own ? t : own;
     }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }

@@ -109,7 +109,7 @@ static inline int strip_pre_exchange_sync(tdx_context* ctx, const Strip& st) {
 // one collective and ONE synchronisation; otherwise device -> host, synchronise, host all-reduce.
 static inline int strip_allreduce_device(tdx_context* ctx, const Strip& st, unsigned long long* d_v, int count, int op, int64_t* host_out) {
     hipStream_t s = ctx->stream;
-    if (st.multi()) ctx->comm_allreduces++;
+    if (st.multi()) { ctx->comm_allreduces++; ctx->comm_allreduces_total++; }
     if (st.multi() && st.comm->allreduce_dev) {
         if (st.comm->allreduce_dev(st.comm->user, reinterpret_cast<int64_t*>(d_v), count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce_dev failed");
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
@@ -127,7 +127,7 @@ static inline int strip_allreduce_device(tdx_context* ctx, const Strip& st, unsi
 
 static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v, int count, int op) {
     if (!st.multi()) return TDX_OK;
-    ctx->comm_allreduces++;
+    ctx->comm_allreduces++; ctx->comm_allreduces_total++;
     if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     return TDX_OK;
 }
@@ -152,7 +152,7 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, arr + size_t(st.y0) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, arr + size_t(st.y1 - 1) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
-    ctx->comm_exchanges++;
+    ctx->comm_exchanges++; ctx->comm_exchanges_total++;
     if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (!tile_flags && !nchanged) {
         if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y0 - 1) * nx, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
@@ -195,7 +195,7 @@ static inline int strip_exchange_buffers(tdx_context* ctx, const Strip& st, cons
     if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_up, up_src, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, down_src, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
-    ctx->comm_exchanges++;
+    ctx->comm_exchanges++; ctx->comm_exchanges_total++;
     if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (st.up && up_dst != c->recv_up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(up_dst, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down && down_dst != c->recv_down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(down_dst, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));

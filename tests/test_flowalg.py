@@ -220,10 +220,11 @@ def test_gpu_limited_vs_oracle_larger(ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle):
+def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle, monkeypatch):
     """A raster large enough (3100 x 2900 = 8 827 tiles of 32 x 32 > TDX_D8_BULK_UNTIL) that the generic dependency sweep starts on 32 x 32
     tiles and hands over to 64 x 64 tiles: every tool built on it, forward and reverse, bit for bit against the restatement.  (The
     directions come from the restatement's FlowDir tools so that both sides sweep the same graph.)"""
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")   # every sweep is re-checked cell by cell against its contributors' final records
     rng = np.random.default_rng(2024)
     shape = (3100, 2900)
     dem = oracle.synth_dem(shape, 61)
@@ -270,9 +271,10 @@ def test_every_sweep_tool_on_both_tile_geometries(ctx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.slow
-def test_sweep_tools_three_strips_equal_one_gpu_at_size(ctx, oracle, tmp_path):
+def test_sweep_tools_three_strips_equal_one_gpu_at_size(ctx, oracle, tmp_path, monkeypatch):
     """3100 x 2900 again, through files and `--gpus 3`: the strip protocol of the generic sweep (record rows exchanged as bit patterns, tiles
     re-activated by changed halo cells, forward and reverse) must reproduce the one-GPU rasters bit for bit."""
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")   # (inherited by the tools: the verifier runs on every strip)
     rng = np.random.default_rng(77)
     shape = (3100, 2900)
     dem = oracle.synth_dem(shape, 62)

@@ -74,17 +74,30 @@ def test_properties_at_16384(ctx, monkeypatch):
     assert amax > 2 ** 24      # the exact re-evaluation path was exercised
 
 
-def _dinf_props(ctx, n, seed, monkeypatch):
+def _dinf_props(ctx, n, seed, monkeypatch, oracle=None):
     """D-infinity at full size: angles in range, every interior cell resolved, the tile dependency sweep and the atomic pull walk
-    (two independent schedules) agree bit for bit on sca, and flow is conserved at the raster's rim within float32 rounding."""
+    (two independent schedules) agree bit for bit on sca, and flow is conserved at the raster's rim within float32 rounding.
+    Every sweep runs under TDX_SWEEP_VERIFY=1 (a cell that does not follow from its contributors' final values fails the call).
+    With `oracle`: the restatement's linear-time checkers pin the rasters to the reference's per-cell expressions on the host -
+    the first pass of setdir() on every cell it gives a direction (src/dinf.cpp:549-593), area()'s loop body on every cell
+    (src/areadinf.cpp:187-217; by induction over the dependency order that IS the raster the restatement would produce)."""
     import math
 
     import torch
 
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
     dem = ctx.synth_dem(n, seed=seed)
     fel = ctx.pitremove(dem, -9999.0)
     del dem
     ang, slp, st = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    if oracle is not None:
+        bad, first, flats = oracle.dinf_first_pass_check(fel.cpu().numpy(), ang.cpu().numpy(), slp.cpu().numpy(), dx=30.0, dy=30.0)
+        assert bad == 0, f"{bad} cells differ from the first pass of setdir(); first at row {first // n} column {first % n}"
+        assert flats == st["flats_initial"], (flats, st["flats_initial"])
+        sca_c = ctx.areadinf(ang, dx=30.0, dy=30.0, contcheck=True)      # the tool's default mode
+        bad, first = oracle.areadinf_check(ang.cpu().numpy(), sca_c.cpu().numpy(), dx=30.0, dy=30.0, contcheck=True)
+        assert bad == 0, f"contcheck: {bad} cells do not follow from area()'s expression; first at row {first // n} column {first % n}"
+        del sca_c
     del fel
     assert st["flats_left"] == 0
     inner = ang[1:-1, 1:-1]
@@ -98,7 +111,11 @@ def _dinf_props(ctx, n, seed, monkeypatch):
     sca_w = ctx.areadinf(ang, dx=30.0, dy=30.0, contcheck=False)
     monkeypatch.delenv("TDX_DINF_WALK")
     assert torch.equal(sca_t.view(torch.int32), sca_w.view(torch.int32)), "tile dependency sweep and pull walk differ"
+    del sca_w
     assert bool((sca_t[1:-1, 1:-1] >= 30.0).all()), "an interior cell was never evaluated"
+    if oracle is not None:
+        bad, first = oracle.areadinf_check(ang.cpu().numpy(), sca_t.cpu().numpy(), dx=30.0, dy=30.0, contcheck=False)
+        assert bad == 0, f"{bad} cells do not follow from area()'s expression; first at row {first // n} column {first % n}"
     # conservation: what leaves through the nodata ring = every interior cell's own dx (float32 sums along the trunks round)
     k_d1 = [0, 1, 1, 0, -1, -1, -1, 0, 1]
     k_d2 = [0, 0, -1, -1, -1, 0, 1, 1, 1]
@@ -119,9 +136,72 @@ def _dinf_props(ctx, n, seed, monkeypatch):
     assert abs(total - want) <= 2e-3 * want, (total, want)
 
 
-def test_dinf_properties_small(ctx, monkeypatch):
-    _dinf_props(ctx, 700, 3, monkeypatch)
+def test_dinf_properties_small(ctx, oracle, monkeypatch):
+    _dinf_props(ctx, 700, 3, monkeypatch, oracle)
+    # the checkers agree with the restatement itself where it runs in a moment - and they do notice a single wrong bit
+    dem = oracle.synth_dem(500, 9)
+    fel = oracle.pitremove(dem, -9999.0)
+    ang, slp, _ = oracle.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    sca = oracle.areadinf(ang, dx=30.0, dy=30.0)
+    assert oracle.areadinf_check(ang, sca, dx=30.0, dy=30.0)[0] == 0
+    assert oracle.dinf_first_pass_check(fel, ang, slp, dx=30.0, dy=30.0)[0] == 0
+    sca[250, 250] = np.nextafter(sca[250, 250], np.float32(1e30))
+    assert oracle.areadinf_check(ang, sca, dx=30.0, dy=30.0)[0] >= 1
 
 
-def test_dinf_properties_at_16384(ctx, monkeypatch):
-    _dinf_props(ctx, 16384, 1234, monkeypatch)
+def test_dinf_properties_at_16384(ctx, oracle, monkeypatch):
+    _dinf_props(ctx, 16384, 1234, monkeypatch, oracle)
+
+
+def _host_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:   # no psutil: assume the box is as large as every MI355X host seen so far
+        return 1024.0
+
+
+def test_dinf_config3_at_32768(ctx, oracle, monkeypatch):
+    """BASELINE.json configs[2] at its own size (1.07 G cells, 4 x the tiles and twice the rounds of 16384^2): the properties, the sweep
+    verifier, and the linear-time host checks of ang / slp / sca against the restatement's expressions."""
+    if _host_gb() < 48:
+        pytest.skip("needs ~40 GB of host memory for the linear-time checks")
+    _dinf_props(ctx, 32768, 1234, monkeypatch, oracle)
+
+
+def test_dinf_config3_three_strips_equal_one(ctx, monkeypatch):
+    """32768^2 as three row strips (in-process rank group, peer transport: three contexts on this GPU) reproduces the one-strip
+    rasters of DinfFlowDir and AreaDinf bit for bit - the strip protocol at configs[2]'s size, under the sweep verifier."""
+    import torch
+
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+    import taudem_amd as T
+
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
+    n, size = 32768, 3
+    dem = ctx.synth_dem(n, seed=1234)
+    fel1 = ctx.pitremove(dem, -9999.0)
+    del dem
+    ang1, slp1 = ctx.dinfflowdir(fel1, -3.0e38, 30.0, 30.0)
+    sca1 = ctx.areadinf(ang1, dx=30.0, dy=30.0)
+    parts = partition_rows(n, size)
+    wl = T.synth_base_wavelength(n)
+    with StripGroup(size, n) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            nyl = y1 - y0
+            pipe = StripPipeline(c, comm, n, nyl)
+            d = pipe.empty(torch.float32)
+            c.synth_dem((nyl, n), seed=1234, x0=0, y0=y0, base_wavelength=wl, out=d[1:nyl + 1])
+            fel, _ = pipe.pitremove(d, -9999.0)
+            del d
+            ang, slp, _ = pipe.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+            sca, _ = pipe.areadinf(ang, dx=30.0, dy=30.0)
+            torch.cuda.synchronize()
+            ok = {k: bool(torch.equal(a[1:nyl + 1].view(torch.int32), b[y0:y1].view(torch.int32)))
+                  for k, a, b in (("fel", fel, fel1), ("ang", ang, ang1), ("slp", slp, slp1), ("sca", sca, sca1))}
+            return ok
+        res = grp.run(rank_main)
+        assert grp.transport == "peer"
+    for r, ok in enumerate(res):
+        assert all(ok.values()), f"strip {r} of {size} differs from the one-strip run: {ok}"

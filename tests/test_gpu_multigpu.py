@@ -146,3 +146,24 @@ def test_bench_strip_path_with_native_rccl_comm():
     """The strip path of bench.py on one rank with the native RCCL communicator (ncclCommInitRank on this GPU)."""
     out = _bench(["--nx", "1024", "--ny", "512", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"], {"TDX_BENCH_FORCE_STRIPS": "1"})
     assert out["comm"]["transport"] == "rccl-native" and out["value"] > 0
+
+
+@pytest.mark.parametrize("workload", ["d8", "decay"])
+def test_bench_in_process_rank_group(workload):
+    """`bench.py --gpus 3 --in-process`: three strips as three rank threads of one process on the library's own rank group (peer transport on a
+    one-GPU box) - the launcher of the eight-strips-on-one-GPU functional runs (profiles/r03*_8strips_*.json), at a size that takes a second."""
+    out = _bench(["--gpus", "3", "--in-process", "--workload", workload, "--nx", "640", "--ny", "768", "--steps", "1", "--warmup", "0"], {})
+    assert out["n_gpus"] == 3 and out["value"] > 0 and "peer" in out["comm"]["transport"]
+    if workload == "d8":
+        assert out["checks"]["every_directed_cell_evaluated"] and out["comm"]["exchanges_per_step"]["aread8"] > 0
+    else:
+        assert out["config"]["cells_in_the_outlets_catchments"] > 0 and out["comm"]["outlets"] == 64
+
+
+def test_bench_decay_workload_two_ranks_gloo():
+    """BASELINE.json configs[4]'s launcher (`bench.py --gpus N --workload decay`, one process per rank) with two ranks sharing the GPU over gloo;
+    the same raster through one rank must evaluate the same number of cells."""
+    two = _bench(["--gpus", "2", "--workload", "decay", "--nx", "512", "--ny", "512", "--steps", "1", "--warmup", "0"], {"TDX_BENCH_BACKEND": "gloo"})
+    one = _bench(["--workload", "decay", "--nx", "512", "--ny", "512", "--steps", "1", "--warmup", "0"], {})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["cells_in_the_outlets_catchments"] == one["config"]["cells_in_the_outlets_catchments"] > 0
