@@ -290,6 +290,8 @@ int tdx_group_create(int32_t size, const int32_t* devices, int64_t nx, tdx_group
 tdx_context* tdx_group_context(tdx_group* g, int32_t rank);
 const tdx_comm* tdx_group_comm(tdx_group* g, int32_t rank);
 const char* tdx_group_transport(const tdx_group* g);   /* "rccl" | "peer" */
+/* a rank failed outside a collective: the other ranks' collectives fail at once instead of waiting for it (then destroy the group) */
+void tdx_group_abort(tdx_group* g);
 void tdx_group_destroy(tdx_group* g);
 
 /* Strip variants of the device entry points (comm == NULL or comm->size == 1: a single strip whose halo

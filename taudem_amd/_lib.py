@@ -184,6 +184,7 @@ _SIGNATURES = {
     "tdx_group_context": (_P, [_P, C.c_int32]),
     "tdx_group_comm": (_P, [_P, C.c_int32]),
     "tdx_group_transport": (C.c_char_p, [_P]),
+    "tdx_group_abort": (None, [_P]),
     "tdx_group_destroy": (None, [_P]),
 }
 

@@ -43,6 +43,7 @@ __device__ __forceinline__ double inflow_prop(const float* __restrict__ ANG, con
     const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
     const float an = ANG[n];
     if (is_nodata_f(an, nodata)) { *missing = true; return -1.; }
+    if (an == ANG_SINK) *missing = true;   // an outlet on a cell without angle: a sink for itself, still "no angle" for the contamination test beside it
     *nidx = n;
     return prop_dev(an, (k + 4) % 8, rows[yn].a2);
 }
@@ -248,10 +249,12 @@ __device__ __forceinline__ unsigned long long dinf_walk(Alg alg, const float* __
             tv[t] = prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1;
             tn[t] = tv[t] ? size_t(yn) * size_t(nx) + size_t(xn) : 0;
         }
-        // both decrements are in flight together: one atomic round trip per cell, not one per downslope neighbour
+        // both decrements are in flight together: one atomic round trip per cell, not one per downslope neighbour.  Release / acquire:
+        // the value stored above is visible to whoever observes the decrement, and the lane that takes a counter to zero sees the values of
+        // every other contributor (the hand-over of the HIP memory model; the re-read of a pending pattern below stays as a second line)
         int32_t old[2] = {0, 0};
-        if (tv[0]) old[0] = __hip_atomic_fetch_sub(&cnt[tn[0]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tv[1]) old[1] = __hip_atomic_fetch_sub(&cnt[tn[1]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tv[0]) old[0] = __hip_atomic_fetch_sub(&cnt[tn[0]], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (tv[1]) old[1] = __hip_atomic_fetch_sub(&cnt[tn[1]], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         // what the next hop needs from its cell (read-only during the sweep) travels with the atomics, not after them
         float pang[2] = {0.f, 0.f};
         unsigned pinf[2] = {0u, 0u};
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void dinf_halo_kernel(Alg alg, const float* __
                 const int xn = x + d1(k), yn = yh + d2(k);
                 if (prop_dev(ang, k, a2) > 0.0 && xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
                     const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t old = __hip_atomic_fetch_sub(&cnt[n], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                     if (old == 1) dinf_walk(alg, ANG, rows, nx, y_own0, y_own1, info, contcheck, cnt, OUT, ovf, ovf_count, ovf_cap, n);
                 }
             }
@@ -395,7 +398,8 @@ __global__ __launch_bounds__(256) void setup_in_kernel(const uint8_t* __restrict
     unsigned inf = 0;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
-        if (c[k] == DINF_CODE_NODATA) { inf |= 0x100u; continue; }
+        if (dinf_code_missing(c[k])) inf |= 0x100u;          // (a sink on a cell without angle: missing for the contamination test, sends nothing)
+        if (c[k] == DINF_CODE_NODATA) continue;
         const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
         const int via = dinf_code_sends(c[k], kk == 0 ? 8 : kk);
         if (via) inf |= 1u << (k - 1);

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "context.hpp"
@@ -57,6 +58,11 @@ struct Raster {
 };
 
 // tiffIO constructor + CreateNewPartition prints + read (src/tiffIO.cpp:54-183, src/createpart.h:49-87)
+// Reads rows [y0, y1) of an open raster into the full-size host array `base`.
+static bool read_rows(tdx::TiffReader& rd, tdx::DType type, void* base, int64_t nx, int64_t y0, int64_t y1) {
+    return rd.read_window(0, y0, nx, y1 - y0, type, static_cast<char*>(base) + size_t(y0) * size_t(nx) * tdx::dtype_size(type));
+}
+
 int load_raster(const char* path, tdx::DType type, Raster& r) {
     tdx::TiffReader rd;
     if (!rd.open(path)) {
@@ -70,22 +76,44 @@ int load_raster(const char* path, tdx::DType type, Raster& r) {
     else printf("Input file %s has geographic coordinate system.\n", path);
     const size_t n = size_t(r.info.nx) * size_t(r.info.ny);
     printf("Nodata value input to create partition from file: %lf\n", r.info.nodata);
-    bool ok;
+    void* base;
     if (type == tdx::DType::F32) {
         printf("Nodata value recast to float used in partition raster: %f\n", (float)r.info.nodata);
         r.f.resize(n);
-        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.f.data());
+        base = r.f.data();
     } else if (type == tdx::DType::I32) {
         printf("Nodata value recast to int32_t used in partition raster: %d\n", (int32_t)r.info.nodata);
         r.l.resize(n);
-        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.l.data());
+        base = r.l.data();
     } else {
         printf("Nodata value recast to int16_t used in partition raster: %d\n", (int16_t)r.info.nodata);
         r.s.resize(n);
-        ok = rd.read_window(0, 0, r.info.nx, r.info.ny, type, r.s.data());
+        base = r.s.data();
     }
     fflush(stdout);
-    if (!ok) { printf("Error opening file %s.\n", path); g_tdx_thread_error = rd.error(); return TDX_ERR_FILE; }
+    // With --gpus N every rank reads its OWN rows - the strip partition of the compute (src/linearpart.h:133-134), each through its own
+    // reader on the file, like the ranks of the reference (src/tiffIO.cpp:186-290) - instead of one thread decoding a 17 GB raster.
+    const int nrd = int(std::min<int64_t>(std::min(tool_gpus(), 64), r.info.ny));
+    bool ok = true;
+    std::string err;
+    if (nrd <= 1) {
+        ok = read_rows(rd, type, base, r.info.nx, 0, r.info.ny);
+        if (!ok) err = rd.error();
+    } else {
+        rd.close();
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(static_cast<size_t>(nrd));
+        const int64_t rows = r.info.ny / nrd;
+        for (int k = 0; k < nrd; k++)
+            th.emplace_back([&, k] {
+                tdx::TiffReader mine;
+                const int64_t y0 = int64_t(k) * rows, y1 = (k == nrd - 1) ? r.info.ny : int64_t(k + 1) * rows;
+                if (!mine.open(path) || !read_rows(mine, type, base, r.info.nx, y0, y1)) errs[size_t(k)] = mine.error().empty() ? "read failed" : mine.error();
+            });
+        for (auto& t : th) t.join();
+        for (const std::string& e : errs) if (!e.empty()) { ok = false; err = e; break; }
+    }
+    if (!ok) { printf("Error opening file %s.\n", path); g_tdx_thread_error = err; return TDX_ERR_FILE; }
     return TDX_OK;
 }
 
@@ -181,7 +209,7 @@ int tdx_tool_gridnet(const char* pfile, const char* plenfile, const char* tlenfi
     std::vector<float> plen(n), tlen(n);
     std::vector<int16_t> gord(n);
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), p.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             int16_t* d_p = j.strip<int16_t>(p.s.data());
@@ -236,7 +264,7 @@ int tdx_tool_d8flowpathextremeup(const char* pfile, const char* safile, const ch
     const double readt = now_s();
     std::vector<float> ssa(p.s.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), p.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             int16_t* d_p = j.strip<int16_t>(p.s.data());
@@ -307,7 +335,7 @@ int tdx_tool_dinfupdependence(const char* angfile, const char* dgfile, const cha
     const double readt = now_s();
     std::vector<float> dep(ang.f.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());
@@ -356,7 +384,7 @@ int tdx_tool_dinfconclimaccum(const char* angfile, const char* ctptfile, const c
     const double readt = now_s();
     std::vector<float> out(ang.f.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());
@@ -415,7 +443,7 @@ int tdx_tool_dinftranslimaccum(const char* angfile, const char* tsupfile, const 
     const double readt = now_s();
     std::vector<float> tla(ang.f.size()), dep(ang.f.size()), cso(usec ? ang.f.size() : 0);
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());
@@ -475,7 +503,7 @@ int tdx_tool_dinfrevaccum(const char* angfile, const char* wgfile, const char* r
     const size_t n = ang.f.size();
     std::vector<float> racc(n), dmax(n);
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());
@@ -532,7 +560,7 @@ int tdx_tool_pitremove(const char* demfile, const char* felfile, const char* /*s
     if (verbose) { printf("Header read\nData read\n"); if (use_mask) printf("Process: 0, Using depression mask data...\n"); fflush(stdout); }
     std::vector<float> fel(dem.f.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), dem.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_dem = j.strip<float>(dem.f.data());
@@ -580,7 +608,7 @@ int tdx_tool_d8flowdir(const char* demfile, const char* pointfile, const char* s
     std::vector<int16_t> p(n);
     std::vector<float> sd8(n);
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), dem.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_fel = j.strip<float>(dem.f.data());
@@ -638,7 +666,7 @@ int tdx_tool_aread8(const char* pfile, const char* afile, const char* datasrc, c
     const double readt = now_s();
     std::vector<float> a(p.s.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), p.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), p.info.nx, p.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             int16_t* d_p = j.strip<int16_t>(p.s.data());
@@ -679,7 +707,7 @@ int tdx_tool_dinfflowdir(const char* demfile, const char* angfile, const char* s
     const size_t n = dem.f.size();
     std::vector<float> ang(n), slp(n);
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), dem.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), dem.info.nx, dem.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_fel = j.strip<float>(dem.f.data());
@@ -731,7 +759,7 @@ int tdx_tool_areadinf(const char* angfile, const char* scafile, const char* data
     const double readt = now_s();
     std::vector<float> sca(ang.f.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());
@@ -783,7 +811,7 @@ int tdx_tool_dinfdecayaccum(const char* angfile, const char* adecfile, const cha
     const double readt = now_s();
     std::vector<float> out(ang.f.size());
     tdx_stats st;
-    const int nproc = tool_gpus();
+    const int nproc = int(std::min<int64_t>(tool_gpus(), ang.info.ny));   // (at least one row per rank: the count that is printed is the count that ran)
     if (nproc > 1) {
         rc = toolstrips::run(nproc, tool_device(), ang.info.nx, ang.info.ny, &st, [&](toolstrips::RankJob& j, tdx_stats* s) {
             float* d_ang = j.strip<float>(ang.f.data());

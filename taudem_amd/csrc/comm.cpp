@@ -33,6 +33,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -54,7 +55,7 @@ RcclApi load_rccl() {
 #define TDX_SYM(name)                                                                  \
     a.name = reinterpret_cast<decltype(a.name)>(dlsym(h, "nccl" #name));              \
     if (!a.name) { a.err = "librccl lacks nccl" #name; return a; }
-    TDX_SYM(GetUniqueId) TDX_SYM(CommInitRank) TDX_SYM(CommInitAll) TDX_SYM(CommDestroy) TDX_SYM(Send) TDX_SYM(Recv) TDX_SYM(AllReduce)
+    TDX_SYM(GetUniqueId) TDX_SYM(CommInitRank) TDX_SYM(CommInitAll) TDX_SYM(CommDestroy) TDX_SYM(CommAbort) TDX_SYM(Send) TDX_SYM(Recv) TDX_SYM(AllReduce)
     TDX_SYM(GroupStart) TDX_SYM(GroupEnd) TDX_SYM(GetErrorString)
 #undef TDX_SYM
     a.ok = true;
@@ -81,15 +82,23 @@ public:
     bool wait() {
         static const double limit_s = getenv("TDX_COMM_TIMEOUT") ? atof(getenv("TDX_COMM_TIMEOUT")) : 600.0;
         std::unique_lock<std::mutex> lk(m_);
+        if (aborted_) return false;
         const unsigned gen = gen_;
         if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); return true; }
-        return cv_.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen_ != gen; });
+        return cv_.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen_ != gen || aborted_; }) && !aborted_;
+    }
+    // a rank has failed: everybody waiting here, now or later, gets `false` at once instead of waiting for a rank that will not come
+    void abort() {
+        std::lock_guard<std::mutex> lk(m_);
+        aborted_ = true;
+        cv_.notify_all();
     }
 private:
     std::mutex m_;
     std::condition_variable cv_;
     int n_, count_ = 0;
     unsigned gen_ = 0;
+    bool aborted_ = false;
 };
 
 constexpr int RED_MAX = 16;
@@ -368,6 +377,15 @@ extern "C" const tdx_comm* tdx_group_comm(tdx_group* g, int32_t rank) {
     return g->transport == "rccl" ? &g->rc[size_t(rank)]->c : &g->pr[size_t(rank)].c;
 }
 extern "C" const char* tdx_group_transport(const tdx_group* g) { return g ? g->transport.c_str() : ""; }
+// A rank of the group has failed outside a collective (allocation, input ...): the other ranks must not wait for it.  Peer transport:
+// every barrier wait, pending or future, fails at once; RCCL: the communicators are aborted, so that enqueued and future operations
+// end in an error instead of waiting for a partner.  The group can only be destroyed afterwards.
+extern "C" void tdx_group_abort(tdx_group* g) {
+    if (!g) return;
+    if (g->bar) g->bar->abort();
+    for (tdx_rccl_comm* r : g->rc)
+        if (r && r->comm) { rccl().CommAbort(r->comm); r->comm = nullptr; }
+}
 extern "C" void tdx_group_destroy(tdx_group* g) {
     if (!g) return;
     for (tdx_rccl_comm* r : g->rc) tdx_rccl_comm_destroy(r);

@@ -41,35 +41,41 @@ constexpr int SLOPE_ROWS = 16;   // rows per lane: a 64 x 64 cell tile per 256-t
 // the mask (two per 16 rows instead of nine tests per cell).  A cell on the edge of the raster needs no test of its own: a neighbour
 // outside the raster reads as nodata (src/linearpart.h:470-483), which makes the cell contaminated just like src/d8.cpp:383-386 does.
 constexpr int SLOPE_COLS = 62;
+using flatmask_t = uint32_t;    // one bit per row of a lane's segment
+// SLOPE_SEG = rows per lane: 32 (34 loads for 32 rows: 6 % overlap; the default) or 16 (12.5 %; TDX_SLOPE_SEG=16, A/B hook)
+template <int SLOPE_SEG>
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
-                                                       float* __restrict__ SD8, uint16_t* __restrict__ flatbits) {
+                                                       float* __restrict__ SD8, flatmask_t* __restrict__ flatbits) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int lx = threadIdx.x & 63;
     const int x = blockIdx.x * SLOPE_COLS - 1 + lx;
     const int band = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * 4 + int(threadIdx.x >> 6));
-    const int ybase = y_own0 + band * SLOPE_ROWS;
+    const int ybase = y_own0 + band * SLOPE_SEG;
     const bool mine = lx >= 1 && lx <= SLOPE_COLS && x < nx;
     const bool inx = x >= 0 && x < nx;
     const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
     // all 18 row loads of the lane are issued back to back (rows clamped into the array; validity applied afterwards)
-    float z[SLOPE_ROWS + 2];
+    float z[SLOPE_SEG + 2];
 #pragma unroll
-    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+    for (int j = 0; j < SLOPE_SEG + 2; j++) {
         const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
         z[j] = Z[size_t(yc) * size_t(nx) + size_t(xc)];
     }
-    unsigned nd = 0;   // bit j: window row j of this column is nodata or outside the raster
+    unsigned long long nd = 0;   // bit j: window row j of this column is nodata or outside the raster
 #pragma unroll
-    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+    for (int j = 0; j < SLOPE_SEG + 2; j++) {
         const int y = ybase - 1 + j;
-        if (!inx || y < 0 || y >= ny || is_nodata_f(z[j], nodata)) nd |= 1u << j;
+        if (!inx || y < 0 || y >= ny || is_nodata_f(z[j], nodata)) nd |= 1ull << j;
     }
-    const unsigned nd3 = nd | lane_left(nd, 0x3FFFFu) | lane_right(nd, 0x3FFFFu);   // this column or one beside it (a missing lane: outside)
-    unsigned flatmask = 0;
+    // this column or one beside it (two 32-bit halves travel through the lane shifts; what a missing lane would hold does not matter:
+    // lanes 0 and 63 are not output lanes)
+    const unsigned ndlo = unsigned(nd), ndhi = unsigned(nd >> 32);
+    const unsigned long long nd3 = nd | ((unsigned long long)(lane_left(ndhi, 0u) | lane_right(ndhi, 0u)) << 32) | (unsigned long long)(lane_left(ndlo, 0u) | lane_right(ndlo, 0u));
+    flatmask_t flatmask = 0;
 #pragma unroll
-    for (int r = 0; r < SLOPE_ROWS; r++) {
+    for (int r = 0; r < SLOPE_SEG; r++) {
         const int y = ybase + r;
         const float n1 = z[r], c1 = z[r + 1], s1 = z[r + 2];
         const float n0 = lane_left(n1, nodata), n2 = lane_right(n1, nodata);
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
             int16_t p = TDX_P_NODATA;
             float sd = -1.0f;
             const float z0 = c1;
-            if (((nd3 >> r) & 7u) == 0u) {   // the cell and its eight neighbours hold data
+            if (((nd3 >> r) & 7ull) == 0ull) {   // the cell and its eight neighbours hold data
                 const double* f = fact + size_t(y) * 9;
                 // fact[j][k]: 1/dx for E,W; 1/dy for N,S; 1/diag for the diagonals (src/d8.cpp:375)
                 const double fE = f[1], fN = f[3], fD = f[2];
@@ -104,18 +110,18 @@ __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__
             if (SD8) SD8[idx] = sd;
         }
     }
-    if (mine) flatbits[size_t(band) * size_t(nx) + size_t(x)] = uint16_t(flatmask);
+    if (mine) flatbits[size_t(band) * size_t(nx) + size_t(x)] = flatmask;
 }
 
 // ---- the flat queue from the bit masks: count per block of 2048 masks, scan the block sums, write the cells (no atomics) ----
 constexpr int FLATQ_PER_BLOCK = 2048;
-__global__ __launch_bounds__(256) void flat_count_kernel(const uint16_t* __restrict__ bits, size_t nmasks, unsigned* __restrict__ blocksum) {
+__global__ __launch_bounds__(256) void flat_count_kernel(const flatmask_t* __restrict__ bits, size_t nmasks, unsigned* __restrict__ blocksum) {
     const size_t base = size_t(blockIdx.x) * FLATQ_PER_BLOCK + threadIdx.x;
     unsigned c = 0;
 #pragma unroll
     for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
         const size_t m = base + size_t(i) * 256;
-        if (m < nmasks) c += unsigned(__popc(unsigned(bits[m])));
+        if (m < nmasks) c += unsigned(__popc(bits[m]));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(1024) void flat_scan_kernel(unsigned* __restrict__ 
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ __launch_bounds__(256) void flat_list_kernel(const uint16_t* __restrict__ bits, size_t nmasks, int nx, int y_own0, const unsigned* __restrict__ blockoff,
+__global__ __launch_bounds__(256) void flat_list_kernel(const flatmask_t* __restrict__ bits, size_t nmasks, int nx, int y_own0, int seg, const unsigned* __restrict__ blockoff,
                                                         uint32_t* __restrict__ list) {
     const size_t base = size_t(blockIdx.x) * FLATQ_PER_BLOCK + threadIdx.x;
     unsigned mk[FLATQ_PER_BLOCK / 256];
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void flat_list_kernel(const uint16_t* __restri
 #pragma unroll
     for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
         const size_t m = base + size_t(i) * 256;
-        mk[i] = m < nmasks ? unsigned(bits[m]) : 0u;
+        mk[i] = m < nmasks ? bits[m] : 0u;
         c += unsigned(__popc(mk[i]));
     }
     unsigned v = c;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void flat_list_kernel(const uint16_t* __restri
         if (!mk[i]) continue;
         const size_t m = base + size_t(i) * 256;
         const unsigned band = unsigned(m / size_t(nx)), x = unsigned(m - size_t(band) * size_t(nx));
-        const size_t c0 = size_t(y_own0 + int(band) * SLOPE_ROWS) * size_t(nx) + size_t(x);
+        const size_t c0 = size_t(y_own0 + int(band) * seg) * size_t(nx) + size_t(x);
         for (unsigned b = mk[i]; b; b &= b - 1u) list[pos++] = uint32_t(c0 + size_t(__ffs(int(b)) - 1) * size_t(nx));
     }
 }
@@ -469,24 +475,25 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    // one bit per owned cell: bands of 16 rows x nx columns of 16-bit row masks (the slope pass's lane = one mask)
-    const int nband = ((st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS)) * 4;
+    // one bit per owned cell: bands of SLOPE_SEG rows x nx columns of row masks (the slope pass's lane = one mask)
+    static const int seg = (getenv("TDX_SLOPE_SEG") && atoi(getenv("TDX_SLOPE_SEG")) == 16) ? 16 : 32;   // rows per lane of the slope pass
+    const int nband = ((st.y1 - st.y0 + 4 * seg - 1) / (4 * seg)) * 4;
     const size_t nmasks = size_t(nband) * size_t(inx);
     const unsigned nqblocks = unsigned((nmasks + FLATQ_PER_BLOCK - 1) / FLATQ_PER_BLOCK);
-    uint16_t* flatbits = static_cast<uint16_t*>(ctx->scratch(TDX_S_N, nmasks * 2));
+    flatmask_t* flatbits = static_cast<flatmask_t*>(ctx->scratch(TDX_S_N, nmasks * sizeof(flatmask_t)));
     unsigned* blocksum = static_cast<unsigned*>(ctx->scratch(TDX_S_O, size_t(nqblocks) * 4));
     if (!flatbits || !blocksum) return TDX_ERR_NOMEM;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         dim3 grid((inx + SLOPE_COLS - 1) / SLOPE_COLS, unsigned(nband / 4));
-        hipLaunchKernelGGL(d8_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
+        if (seg == 16) hipLaunchKernelGGL(d8_slope_kernel<16>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
+        else hipLaunchKernelGGL(d8_slope_kernel<32>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     {
         TdxSpan sp(ctx, TDX_K_MISC);
         hipLaunchKernelGGL(flat_count_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, blocksum);
         hipLaunchKernelGGL(flat_scan_kernel, dim3(1), dim3(1024), 0, s, blocksum, nqblocks, d_cnt);
-        hipLaunchKernelGGL(flat_list_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, inx, st.y0, blocksum, qlist);
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -496,6 +503,15 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     if (rc != TDX_OK) return rc;
     if (stats) { stats->flats_initial = total; stats->flats_left = total; }
 
+    // The first queue as a LIST is only built when something will read it: a dense queue (more than 1/16 of the strip; a third of the
+    // raster at BASELINE.json configs[1]) is classified, evaluated (level statistics) and re-directed by streaming passes, and the marker
+    // reset of a later iteration rewrites the whole strip anyway (flats_reset_markers_after).  The choice is this rank's own: nothing that
+    // is exchanged depends on it.
+    const bool have_list = nq <= n / 16;
+    if (total > 0 && nq > 0 && have_list) {
+        TdxSpan sp(ctx, TDX_K_MISC);
+        hipLaunchKernelGGL(flat_list_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, inx, st.y0, seg, blocksum, qlist);
+    }
     if (total > 0) {
         rc = strip_exchange<int16_t>(ctx, st, d_p, TDX_P_NODATA);
         if (rc != TDX_OK) return rc;
@@ -525,7 +541,8 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq);
                 if (rc != TDX_OK) return rc;
             }
-            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
+            // (the first queue of a dense strip exists as bit masks only: no list)
+            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);

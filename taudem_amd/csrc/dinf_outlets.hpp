@@ -8,7 +8,6 @@
 #include "dinf_prop.hpp"
 #include "strips.hpp"
 
-constexpr float TDX_ANG_OUTSIDE = 100.0f, TDX_ANG_SINK = 200.0f;
 
 // d_rows: per array row {atan2(dy, dx), dx}.  On return *ang_use points at the re-coded angles (scratch slot TDX_S_P, all rows).
 int dinf_outlet_recode(tdx_context* ctx, const Strip& st, const float* d_ang, float ang_nodata, const RowProp* d_rows, const int32_t* outlet_x,

@@ -51,12 +51,18 @@ __device__ __forceinline__ int dinf_sector(float ang, double a2) {   // number o
 // s1 % 8 + 1.  Whether neighbour k drains into a cell - prop(angle_n, (k + 4) % 8) > 0, evaluated eight times per cell by
 // initNeighborDinfup (src/commonLib.cpp:99-131) - is therefore a property of the NEIGHBOUR's own two proportions: pass 1 computes
 // them once per cell (two fp64 divisions instead of ten) and leaves this byte, pass 2 is a byte stencil.
-//   0xFF: no angle (nodata)      else [0:3) s1 - 1, [3] prop(s1) > 0, [4] prop(s1 % 8 + 1) > 0, [5] the cell participates
-constexpr unsigned DINF_CODE_NODATA = 0xFFu, DINF_CODE_P1 = 8u, DINF_CODE_P2 = 16u, DINF_CODE_PART = 32u;
+//   0xFF: no angle (nodata)      else [0:3) s1 - 1, [3] prop(s1) > 0, [4] prop(s1 % 8 + 1) > 0, [5] the cell participates,
+//   [6] the cell has no angle in the ORIGINAL raster: an outlet placed on such a cell takes part as a pure sink (TDX_ANG_SINK, outlets
+//       mode), but its neighbours still see a cell without angle - the reference's contamination tests read the original angles
+//       (src/areadinf.cpp:196-199, src/DinfConcLimAccum.cpp:243, src/DinfTransLimAccum.cpp:246)
+constexpr unsigned DINF_CODE_NODATA = 0xFFu, DINF_CODE_P1 = 8u, DINF_CODE_P2 = 16u, DINF_CODE_PART = 32u, DINF_CODE_NOANGLE = 64u;
+constexpr float TDX_ANG_OUTSIDE = 100.0f, TDX_ANG_SINK = 200.0f;   // re-coded angles of outlets mode (dinf_outlets.hpp)
+// the neighbour with code `c` counts as "missing" for the contamination test of a cell beside it
+__device__ __forceinline__ bool dinf_code_missing(unsigned c) { return c == DINF_CODE_NODATA || (c & DINF_CODE_NOANGLE) != 0u; }
 __device__ __forceinline__ unsigned dinf_code(float ang, bool nodata, bool participates, double a2, double* p1, double* p2) {
     *p1 = 0.; *p2 = 0.;
     if (nodata) return DINF_CODE_NODATA;
-    unsigned c = 0;
+    unsigned c = ang == TDX_ANG_SINK ? DINF_CODE_NOANGLE : 0u;
     if (participates) {
         c |= DINF_CODE_PART;
         const int s1 = dinf_sector(ang, a2);

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void fwd_setup_kernel(const uint8_t* __restric
     unsigned inf = 0;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
-        if (c[k] == DINF_CODE_NODATA) { inf |= d8sweep::INFO_CON; continue; }
+        if (dinf_code_missing(c[k])) inf |= d8sweep::INFO_CON;   // (a sink on a cell without angle: missing for the contamination test, sends nothing)
+        if (c[k] == DINF_CODE_NODATA) continue;
         const int kk = (k + 4) % 8;
         if (dinf_code_sends(c[k], kk == 0 ? 8 : kk)) inf |= 1u << (k - 1);   // `float p > 0` of src/commonLib.cpp:99 == the sender's own proportion > 0
     }

@@ -164,6 +164,48 @@ static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* 
     }
 }
 
+// the same three numbers from a pass over the owned rows (cells outside the queue hold -1 in both fields): for a dense queue, where
+// reading two int16 per cell costs less than building and gathering through a list of a third of the raster
+static __global__ __launch_bounds__(256) void flat_stats_stream_kernel(const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq, size_t first, size_t count,
+                                                                       unsigned long long* __restrict__ out) {
+    const size_t base = first + size_t(blockIdx.x) * (256 * 16) + size_t(threadIdx.x);
+    int ml = 0, mr = 0;
+    unsigned unv = 0;
+    lvl_t l[16], r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {   // all loads first (clamped), a wave reads 128 contiguous bytes of each field per step
+        const size_t c = base + size_t(i) * 256, cc = c < first + count ? c : first + count - 1;
+        l[i] = lvl[cc]; r[i] = rq[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (base + size_t(i) * 256 < first + count) {
+            ml = l[i] > ml ? int(l[i]) : ml;
+            mr = r[i] > mr ? int(r[i]) : mr;
+            unv += unsigned(l[i] == 0);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int a = __shfl_xor(ml, off, 64), b = __shfl_xor(mr, off, 64);
+        const unsigned u = __shfl_xor(unv, off, 64);
+        ml = a > ml ? a : ml;
+        mr = b > mr ? b : mr;
+        unv += u;
+    }
+    __shared__ int s_ml[4], s_mr[4];
+    __shared__ unsigned s_unv[4];
+    const int w = int(threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) { s_ml[w] = ml; s_mr[w] = mr; s_unv[w] = unv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) { ml = s_ml[i] > ml ? s_ml[i] : ml; mr = s_mr[i] > mr ? s_mr[i] : mr; unv += s_unv[i]; }
+        if ((unsigned long long)ml > __hip_atomic_load(out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + 0, (unsigned long long)ml);
+        if (unv) atomicAdd(out + 1, (unsigned long long)unv);
+        if ((unsigned long long)mr > __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + 2, (unsigned long long)mr);
+    }
+}
+
 static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
                                                       lvl_t* __restrict__ rq) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
@@ -274,7 +316,8 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 // Runs classification + both level relaxations for the flat queue `qlist` (cells of this strip); on return
 // lvl/rq hold the levels (halo rows included) and *out the sweep counts of the reference's loops.
 // `stream_classify` (optional): replaces the marker reset + list-based classification by one streaming pass over the
-// whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags.
+// whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags; qlist may then be null (no list was
+// built for a dense queue): the level statistics come from a pass over the owned rows instead.
 using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags)>;
 template <class Traits>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
@@ -331,7 +374,11 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         if (rc != TDX_OK) return rc;
     }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    if (nq) hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
+    if (nq && qlist) hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
+    else if (nq) {   // no list (dense first queue of D8FlowDir): one pass over the owned rows
+        const size_t first = size_t(st.y0) * size_t(nx), count = size_t(st.y1 - st.y0) * size_t(nx);
+        hipLaunchKernelGGL(flatk::flat_stats_stream_kernel, dim3(tdx_blocks_for(count, 256 * 16)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
+    }
     rc = flats_read_counters(ctx, 3);
     if (rc != TDX_OK) return rc;
     int64_t mx[2] = {int64_t(ctx->h_mail[0]), int64_t(ctx->h_mail[2])}, unvisited = int64_t(ctx->h_mail[1]);

@@ -126,6 +126,7 @@ struct TileLds {   // LDS of one workgroup
     unsigned long long base;
     unsigned npend;                   // tiles activated by this workgroup and not yet appended to the next round's list
     int chain;                        // solo rounds: the one tile this activation hands over to (bit 31: with FLAG_FULL), -1 = none / several
+    uint32_t pulled[PULL_MAX];        // the list entries of the current pull (fetched together: one memory latency per pull, not one per tile)
     uint32_t pend[PULL_MAX * 9];
 };
 
@@ -696,8 +697,12 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
         if (threadIdx.x == 0) L.npend = 0u;   // the next push comes after the first barrier of the next tile
         if (first >= nact) break;
         const unsigned last = first + pull < nact ? first + pull : nact;
+        if (!fixed) {
+            if (threadIdx.x < last - first) L.pulled[threadIdx.x] = list[first + threadIdx.x];
+            __syncthreads();
+        }
         for (unsigned it = first; it < last; it++) {
-            int tile = fixed ? int(entry0) : int(list[it]);
+            int tile = fixed ? int(entry0) : int(L.pulled[it - first]);
             const bool full = flags_cur[tile] >= FLAG_FULL;
             int res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
             if (threadIdx.x == 0) flags_cur[tile] = 0u;
@@ -966,6 +971,7 @@ struct RoundRunner {
     int batch_max = 64;                  // drive() / the pair lower it: with two batches in flight a whole batch of empty rounds follows the last one
     bool done = false;
     int64_t rounds = 0, launches = 0;
+    bool short_tail = getenv("TDX_RELAX_LONG_TAIL") == nullptr;   // (A/B hook)
     unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
     // another tile kernel on the same schedule (tile_dep.hpp): launches one round; empty = the relaxation kernel of `op`
     std::function<void(unsigned grid, hipStream_t st, const uint32_t* list, unsigned long long* count, uint32_t* flags_cur, uint32_t* flags_next,
@@ -1030,6 +1036,10 @@ struct RoundRunner {
         parity_enq = (parity_enq + batch) & 1;
         n_enq++;
         if (batch < batch_max) batch = std::min(2 * batch, batch_max);
+        // Two batches are in flight, so a whole batch of empty rounds (4.5 us each) follows the last productive one.  Once the rounds are
+        // down to a handful of tiles the end is near (a lone front is followed inside ONE launch: round_driver's solo hand-over), and
+        // short batches cost nothing there: the host has the counts of batch k long before batch k + 1 is through.
+        if (short_tail && rounds > 0 && last_count <= 8ull) batch = std::min(batch, 4);
         return TDX_OK;
     }
     int wait_oldest() {   // the oldest batch in flight has finished and its counts are on the host

@@ -4,6 +4,7 @@
 // copies when ranks share a device), and gathers the owned rows back into the host raster that is written to the file.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -68,6 +69,7 @@ int run(int ngpus, int base_device, int64_t nx, int64_t ny, tdx_stats* stats0, F
     if (rc != TDX_OK) return rc;
     if (getenv("TAUDEM_AMD_STATS")) fprintf(stderr, "taudem_amd: %d strips over %d device(s), transport %s\n", size, std::min(size, ndev), tdx_group_transport(g));
     std::vector<int> rcs(static_cast<size_t>(size), 0);
+    std::atomic<bool> failed{false};
     std::vector<tdx_stats> sts;
     sts.resize(static_cast<size_t>(size));
     std::vector<std::thread> th;
@@ -83,14 +85,17 @@ int run(int ngpus, int base_device, int64_t nx, int64_t ny, tdx_stats* stats0, F
             int e = hipSetDevice(job.ctx->device) == hipSuccess ? body(job, &sts[size_t(r)]) : TDX_ERR_HIP;
             rcs[size_t(r)] = e;
             if (e != TDX_OK && size > 1) {
-                fprintf(stderr, "taudem_amd: rank %d failed (%d): %s\n", r, e, tdx_last_error(job.ctx));
-                fflush(stdout); fflush(stderr);
-                _Exit(e & 0xff ? e & 0xff : 1);
+                // The other ranks may be waiting for this one in a collective: the group is aborted, so that their waits fail at once and
+                // every rank RETURNS its error (the caller may be a Python process or the reference's main on the shim - it must not be
+                // killed under its feet, which is what _Exit() here used to do).  The first rank to fail reports.
+                if (!failed.exchange(true)) fprintf(stderr, "taudem_amd: rank %d of %d failed (%d): %s\n", r, size, e, tdx_last_error(job.ctx));
+                tdx_group_abort(g);
             }
         });
     }
     for (auto& t : th) t.join();
-    for (int r = 0; r < size; r++) if (rcs[size_t(r)] != TDX_OK) { rc = rcs[size_t(r)]; break; }
+    // the error that started it, not the "collective failed" of a rank that was merely waiting for the failed one
+    for (int r = 0; r < size; r++) if (rcs[size_t(r)] != TDX_OK && (rc == TDX_OK || rc == TDX_ERR_HIP)) rc = rcs[size_t(r)];
     if (stats0) {
         *stats0 = sts[0];
         for (int r = 1; r < size; r++) {

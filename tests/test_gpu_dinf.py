@@ -91,3 +91,44 @@ def test_dinf_repeatability(ctx, oracle):
     s0 = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0)
     for _ in range(3):
         assert bits_equal(ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0), s0)
+
+
+def test_outlet_on_a_cell_without_angle(ctx, oracle, monkeypatch):
+    """An outlet placed on a cell that has no angle (here: on the rim of a nodata hole, where streams end) takes part as a pure sink, and
+    its neighbours are still contaminated by it - the reference's contamination tests read the ORIGINAL angle raster (src/areadinf.cpp:196-199,
+    src/DinfConcLimAccum.cpp:243, src/DinfTransLimAccum.cpp:246).  Sweep, walk and restatement agree bit for bit with and without -nc."""
+    rng = np.random.default_rng(31)
+    shape = (420, 380)
+    dem = oracle.synth_dem(shape, 23)
+    dem[150:190, 120:200] = -9999.0
+    fel = oracle.pitremove(dem, -9999.0)
+    ang, _, _ = oracle.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    nd = ang == ANG_ND
+    # cells without angle that have a neighbour draining into them: the first few along the hole's rim, plus ordinary outlets
+    cand = []
+    for y in range(149, 192):
+        for x in range(119, 202):
+            if nd[y, x] and not nd[y - 1:y + 2, x - 1:x + 2].all():
+                cand.append((x, y))
+    assert len(cand) > 20
+    pick = [cand[i] for i in (0, 7, 19, len(cand) // 2, len(cand) - 3)]
+    ox = np.array([p[0] for p in pick] + [300, 50], dtype=np.int32)
+    oy = np.array([p[1] for p in pick] + [400, 60], dtype=np.int32)
+    w = rng.random(shape, dtype=np.float32)
+    dm = (0.9 + 0.1 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+    for cc in (True, False):
+        want = oracle.areadinf(ang, float(ANG_ND), 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        got = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"sca -o on cells without angle, contcheck={cc}")
+        monkeypatch.setenv("TDX_DINF_WALK", "1")
+        got = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        monkeypatch.delenv("TDX_DINF_WALK")
+        assert bits_equal(got, want), describe_diff(got, want, f"sca (walk) -o on cells without angle, contcheck={cc}")
+        want = oracle.dinfdecayaccum(ang, dm, float(ANG_ND), -9999.0, 30.0, 30.0, contcheck=cc, outlets=(ox, oy))
+        got = ctx.dinfdecayaccum(ang, dm, float(ANG_ND), -9999.0, 30.0, 30.0, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"dsca -o on cells without angle, contcheck={cc}")
+        q = (0.5 + rng.random(shape, dtype=np.float32)).astype(np.float32)
+        dg = (rng.random(shape) < 0.01).astype(np.int16)
+        want = oracle.dinfconclimaccum(ang, dm, dg, q, csol=1.5, dx=30.0, dy=30.0, contcheck=cc, outlets=(ox, oy))
+        got = ctx.dinfconclimaccum(ang, dm, dg, q, csol=1.5, dx=30.0, dy=30.0, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"ctpt -o on cells without angle, contcheck={cc}")

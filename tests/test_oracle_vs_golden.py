@@ -30,6 +30,19 @@ def test_d8flowdir(g, oracle):
     assert f"All slopes evaluated. {st['flats_initial']} flats to resolve." in str(g["d8_stderr"])
 
 
+def test_flat_resolution_literal_loops(g, oracle, monkeypatch):
+    """ORC_PLAIN=1: the reference's literal whole-queue sweeps of resolveflats (src/d8.cpp:523-558,606-638; src/dinf.cpp:650-787) instead of
+    the active-list form the restatement uses by default (oracle/taudem_oracle.c: fast_incfall / fast_incrise) - both must give the
+    reference's rasters, so the fast form that produced the 8192^2 / 16384^2 digests is pinned to the literal one."""
+    monkeypatch.setenv("ORC_PLAIN", "1")
+    p, sd8, _ = oracle.d8flowdir(g["fel"], -3.0e38, g["dxc"], g["dyc"])
+    assert bits_equal(p, g["p"]), describe_diff(p, g["p"], "p (literal loops)")
+    assert bits_equal(sd8, g["sd8"]), describe_diff(sd8, g["sd8"], "sd8 (literal loops)")
+    ang, slp, _ = oracle.dinfflowdir(g["fel"], -3.0e38, g["dxc"], g["dyc"])
+    assert bits_equal(ang, g["ang"]), describe_diff(ang, g["ang"], "ang (literal loops)")
+    assert bits_equal(slp, g["slp"]), describe_diff(slp, g["slp"], "slp (literal loops)")
+
+
 @pytest.mark.parametrize("key,kw", [("ad8", {}), ("ad8_nc", {"contcheck": False}), ("ad8_w", {"w": True}), ("ad8_w_nc", {"w": True, "contcheck": False}),
                                     ("ad8_outlets", {"o": True}), ("ad8_outlets_nc", {"o": True, "contcheck": False})])
 def test_aread8(g, oracle, key, kw):
