@@ -150,10 +150,10 @@ def test_bench_strip_path_with_native_rccl_comm():
 
 @pytest.mark.parametrize("workload", ["d8", "decay"])
 def test_bench_in_process_rank_group(workload):
-    """`bench.py --gpus 3 --in-process`: three strips as three rank threads of one process on the library's own rank group (peer transport on a
+    """`bench.py --gpus 4 --in-process`: four strips as four rank threads of one process on the library's own rank group (peer transport on a
     one-GPU box) - the launcher of the eight-strips-on-one-GPU functional runs (profiles/r03*_8strips_*.json), at a size that takes a second."""
-    out = _bench(["--gpus", "3", "--in-process", "--workload", workload, "--nx", "640", "--ny", "768", "--steps", "1", "--warmup", "0"], {})
-    assert out["n_gpus"] == 3 and out["value"] > 0 and "peer" in out["comm"]["transport"]
+    out = _bench(["--gpus", "4", "--in-process", "--workload", workload, "--nx", "640", "--ny", "768", "--steps", "1", "--warmup", "0"], {})
+    assert out["n_gpus"] == 4 and out["value"] > 0 and "peer" in out["comm"]["transport"]
     if workload == "d8":
         assert out["checks"]["every_directed_cell_evaluated"] and out["comm"]["exchanges_per_step"]["aread8"] > 0
     else:
