@@ -633,7 +633,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         static const bool dbg_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
         static const bool dbg_cycles = dbg_rounds && atoi(getenv("TDX_DEBUG_ROUNDS")) == 1;
         // the bulk phase ends when a round has at most this many active 32 x 32 tiles (0: no bulk phase)
-        static const unsigned long long bulk_until = getenv("TDX_DINF_BULK_UNTIL") ? strtoull(getenv("TDX_DINF_BULK_UNTIL"), nullptr, 10) : 6000ull;
+        static const unsigned long long bulk_until = getenv("TDX_DINF_BULK_UNTIL") ? strtoull(getenv("TDX_DINF_BULK_UNTIL"), nullptr, 10) : 400ull;
         unsigned long long* dbg = dbg_cycles ? reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_DBG_SWEEP : nullptr;
         auto launch = [&](bool small, const tilek::TileGeom& gg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur,
                           uint32_t* fnext, uint32_t* lnext, unsigned pull_max) {

@@ -703,30 +703,31 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
         }
         for (unsigned it = first; it < last; it++) {
             int tile = fixed ? int(entry0) : int(L.pulled[it - first]);
-            const bool full = flags_cur[tile] >= FLAG_FULL;
-            int res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
-            if (threadIdx.x == 0) flags_cur[tile] = 0u;
+            bool full = flags_cur[tile] >= FLAG_FULL;
+            int res;
             // A SOLO round (one active tile in the whole raster: the tail of every dependency sweep is one chain of such rounds, the
             // longest flow path crossing one tile per round) hands over inside the launch: while an activation activates exactly one
             // tile, this workgroup - the only one running - goes on into it, instead of a list append, the end of the kernel, the next
-            // launch and its count -> list -> flag -> data chain of dependent loads (~15 us per tile crossing).  Nobody else reads or
-            // writes during a solo round, so the only ordering needed is this workgroup's own stores before its next loads.
-            if (nact == 1u && chain_max > 0) {
-                for (int hop = 0; hop < chain_max && (res & (RES_CHANGED | RES_CAPPED)); hop++) {
-                    uint32_t flag;
-                    const int target = activation_target(res, tile, g, &flag);
-                    if (threadIdx.x < 64) {
-                        const unsigned long long b = __ballot(target >= 0);
-                        if (target >= 0 && (b & (b - 1ull)) == 0ull) L.chain = target | (flag >= FLAG_FULL ? int(0x80000000u) : 0);
-                        if (threadIdx.x == 0 && (b == 0ull || (b & (b - 1ull)) != 0ull)) L.chain = -1;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // this lane's write-back has landed, its cached lines are dropped
-                    __syncthreads();
-                    const int ch = L.chain;
-                    if (ch == -1) break;
-                    tile = ch & 0x7fffffff;
-                    res = body(tile, ch < 0);   // (its first barrier comes after every lane has read L.chain)
+            // launch and its count -> list -> flag -> data chain of dependent loads.  Nobody else reads or writes during a solo round, so
+            // the only ordering needed is this workgroup's own stores before its next loads.  (ONE call site of body(): a second inlined
+            // copy of a tile kernel changes its register allocation - the D-infinity decay sweep fell from 4 to 3 waves per SIMD.)
+            for (int hop = 0;; hop++) {
+                res = body(tile, full);   // (ends with a barrier: every lane has read the flag)
+                if (hop == 0 && threadIdx.x == 0) flags_cur[tile] = 0u;
+                if (nact != 1u || hop >= chain_max || !(res & (RES_CHANGED | RES_CAPPED))) break;
+                uint32_t flag;
+                const int target = activation_target(res, tile, g, &flag);
+                if (threadIdx.x < 64) {
+                    const unsigned long long bal = __ballot(target >= 0);
+                    if (target >= 0 && (bal & (bal - 1ull)) == 0ull) L.chain = target | (flag >= FLAG_FULL ? int(0x80000000u) : 0);
+                    if (threadIdx.x == 0 && (bal == 0ull || (bal & (bal - 1ull)) != 0ull)) L.chain = -1;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // this lane's write-back has landed, its cached lines are dropped
+                __syncthreads();
+                const int ch = L.chain;
+                if (ch == -1) break;
+                tile = ch & 0x7fffffff;   // (the next body()'s first barrier comes after every lane has read L.chain)
+                full = ch < 0;
             }
             if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, L);
         }
