@@ -107,6 +107,7 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
     static constexpr int kBulkSweeps = BULK_SWEEPS;
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;     // rounds run on 32 x 32 tiles until this few are active (measured at 16384^2: 6000 -> 16 is 2-3 % faster for every forward tool)
+    static constexpr int kMinWaves32 = 4;
     // cells whose pending count includes this one: the cell it drains to
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     int mode;            // 0 sum, 1 max, 2 min
@@ -147,6 +148,7 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr int kBulkSweeps = BULK_SWEEPS;
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
+    static constexpr int kMinWaves32 = 5;
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
     static __host__ __device__ __forceinline__ float4 outside() { const int m1 = -1; float z; memcpy(&z, &m1, 4); return make_float4(-1.0f, -1.0f, z, 0.f); }
@@ -387,8 +389,12 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     return res;
 }
 
-template <class Alg, int TSZ>
-__global__ __launch_bounds__(Dim<TSZ>::NT) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+// MINW: waves per SIMD the register allocation is held to (= 256-thread tiles per CU of the 32 x 32 geometry; policy constant kMinWaves32):
+// 4 is what the kernels take by themselves (107-117 VGPRs); 5 (<= 102 VGPRs) puts a fifth tile on a CU where the LDS allows it - measured
+// per policy at 16384^2 (profiles/r03k_*): GridNet 64.0 -> 60.0 ms (3 spilled registers), DinfUpDependence 381 -> 376 ms (2), DinfRevAccum
+// slower (10 spills), the limited accumulations are LDS-bound at 4 tiles, weighted AreaD8 / ExtremeUp need 88 VGPRs anyway
+template <class Alg, int TSZ, int MINW = 4>
+__global__ __launch_bounds__(Dim<TSZ>::NT, MINW) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
                                                    unsigned pull_max, Arrays<Alg> A) {
     __shared__ Lds<Alg, TSZ> S;
@@ -596,7 +602,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
         runner.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
                                    unsigned pull_max) {
-            if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
+            if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32, Alg::kMinWaves32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
             else hipLaunchKernelGGL((sweep_kernel<Alg, 64>), dim3(grid), dim3(Dim<64>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
         };
         int rcl = runner.start();
