@@ -18,6 +18,7 @@ resident in HBM (generated on the device by tdx_synth_dem_dev).
 
 Beside the pipeline, the N = 1 line carries (outside the timed region, one step each, `--no-extras` skips them)
   config3        BASELINE.json configs[2]: DinfFlowDir + AreaDinf on a 32768 x 32768 DEM (ms, Mcells/s, the accumulation sweeps' roofline)
+  config4_strip  BASELINE.json configs[3] as ONE GPU sees it: the pipeline on a 65536 x 8192 strip (no neighbours)
   config5_strip  BASELINE.json configs[4] as ONE GPU sees it: DinfDecayAccum with weights, decay multipliers and 64 outlets on a
                  65536 x 8192 strip
 and `--workload decay` times configs[4] itself: DinfDecayAccum -wg -o on ONE raster of 65536 columns x 8192*N rows in row strips
@@ -268,6 +269,29 @@ def config5_strip_leg(torch, ctx, seed, T):
             "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "rounds": st["rounds"], "cells_in_the_outlets_catchments": job.evaluated_cells(torch),
             "classes_ms": {k: st["ms_" + k] for k in ("stencil", "bfs", "accum", "misc")},
             "algorithmic_gb_per_s": DECAY_BYTES_PER_CELL * cells / (ms * 1e-3) / 1e9}
+
+
+def config4_strip_leg(torch, ctx, seed, T):
+    """BASELINE.json configs[3] as one GPU sees it: PitRemove -> D8FlowDir -> AreaD8 on ONE 65536 x 8192 strip of the 65536 x 65536 DEM (the generator
+    is called with the whole raster's wavelength; no neighbours, so the halo exchanges and votes of the 8-GPU run are not in this number)."""
+    nx, ny = 65536, 8192
+    dem = ctx.synth_dem((ny, nx), seed=seed, base_wavelength=T.synth_base_wavelength(65536))
+    fel = torch.empty_like(dem)
+    p = torch.empty((ny, nx), dtype=torch.int16, device=dem.device)
+    sd8, ad8 = torch.empty_like(dem), torch.empty_like(dem)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, s1 = ctx.pitremove(dem, -9999.0, out=fel, stats=True)
+        _, _, s2 = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, out=(p, sd8), stats=True)
+        _, s3 = ctx.aread8(p, -32768, out=ad8, stats=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+    cells = float(nx) * ny
+    return {"workload": f"{nx}x{ny} strip (rows 0..8191 of the 65536x65536 synthetic DEM, seed {seed}): PitRemove->D8FlowDir->AreaD8 in HBM on one GPU, no neighbours",
+            "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "stage_ms": {"pitremove": s1["ms_total"], "d8flowdir": s2["ms_total"], "aread8": s3["ms_total"]},
+            "flats_initial": s2["flats_initial"], "levels_fall": s2["levels_fall"], "pit_rounds": s1["rounds"],
+            "note": "8 such strips = configs[3]; their exchange / all-reduce counts per stage: profiles/r03c_8strips_65536_d8.json"}
 
 
 def decay_line(world, nx, ny, args, ms_per_step, st, comm_info, job_cells_evaluated, functional):
@@ -621,7 +645,8 @@ def main():
             # not cost the line of record)
             del dem, fel, p, sd8, ad8
             torch.cuda.empty_cache()
-            for key, leg in (("config3", lambda: config3_leg(torch, ctx, args.seed)), ("config5_strip", lambda: config5_strip_leg(torch, ctx, args.seed, T))):
+            for key, leg in (("config3", lambda: config3_leg(torch, ctx, args.seed)), ("config4_strip", lambda: config4_strip_leg(torch, ctx, args.seed, T)),
+                             ("config5_strip", lambda: config5_strip_leg(torch, ctx, args.seed, T))):
                 try:
                     out[key] = leg()
                 except Exception as e:   # noqa: BLE001

@@ -205,32 +205,46 @@ __device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, siz
 // level-1/2 seeds of incfall, the seeds of incrise and both eligibility masks are a function of the 3x3 windows of
 // Z and P.  Every owned cell gets its markers (lvl / rq: -1 outside the queue) and masks; lanes walk 16-row column
 // segments with both windows in registers (6 row loads per output row).  Semantics: flatk::classify_kernel.
+// (62-column window like d8_slope_kernel: a lane loads ONE value per row and array, the west / east neighbours are lane shifts; the 2 x 18 row
+// loads of a lane are issued back to back.  The first version read three overlapping cells per row and array inside the row loop: 1.36 ms.)
+constexpr int CLS_COLS = 62;
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
                                                                  int y_own0, int y_own1, int tiles_x, lvl_t* __restrict__ lvl,
                                                                  lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
                                                                  uint32_t* __restrict__ tile_flags) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS;
-    const bool colok = x < nx;
-    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    auto ldrow = [&](int y, float& a, float& b, float& c, int16_t& pa, int16_t& pb, int16_t& pc) {
-        if (y >= 0 && y < ny) {
-            const float* r = Z + size_t(y) * size_t(nx);
-            const int16_t* q = P + size_t(y) * size_t(nx);
-            a = r[xm]; b = r[xc]; c = r[xp];
-            pa = q[xm]; pb = q[xc]; pc = q[xp];
-        } else { a = b = c = 0.f; pa = pb = pc = TDX_P_NODATA; }
-    };
-    float zn0, zn1, zn2, zc0, zc1, zc2, zs0, zs1, zs2;
-    int16_t pn0, pn1, pn2, pc0, pc1, pc2, ps0, ps1, ps2;
-    ldrow(ybase - 1, zn0, zn1, zn2, pn0, pn1, pn2);
-    ldrow(ybase, zc0, zc1, zc2, pc0, pc1, pc2);
+    using tilek::lane_left;
+    using tilek::lane_right;
+    const int lx = threadIdx.x & 63;
+    const int x = blockIdx.x * CLS_COLS - 1 + lx;
+    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
+    const bool mine = lx >= 1 && lx <= CLS_COLS && x < nx;
+    const bool inx = x >= 0 && x < nx;
+    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+    float z[SLOPE_ROWS + 2];
+    int pw[SLOPE_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        const size_t o = size_t(yc) * size_t(nx) + size_t(xc);
+        z[j] = Z[o];
+        pw[j] = P[o];
+    }
+#pragma unroll
+    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
+        const int y = ybase - 1 + j;
+        if (!inx || y < 0 || y >= ny) { z[j] = 0.f; pw[j] = TDX_P_NODATA; }   // (never looked at from a flat cell: flat cells are interior cells)
+    }
     int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
-        ldrow(y + 1, zs0, zs1, zs2, ps0, ps1, ps2);
-        if (colok && y < y_own1) {
+        const float zn1 = z[r], zc1 = z[r + 1], zs1 = z[r + 2];
+        const int pn1 = pw[r], pc1 = pw[r + 1], ps1 = pw[r + 2];
+        const float zn0 = lane_left(zn1, 0.f), zn2 = lane_right(zn1, 0.f), zc0 = lane_left(zc1, 0.f), zc2 = lane_right(zc1, 0.f);
+        const float zs0 = lane_left(zs1, 0.f), zs2 = lane_right(zs1, 0.f);
+        const int pn0 = lane_left(pn1, 0), pn2 = lane_right(pn1, 0), pc0 = lane_left(pc1, 0), pc2 = lane_right(pc1, 0);
+        const int ps0 = lane_left(ps1, 0), ps2 = lane_right(ps1, 0);
+        if (mine && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
             lvl_t l = -1, q = -1;
             unsigned fm = 0, rm = 0;
@@ -270,8 +284,6 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
             fmask[idx] = uint8_t(fm);
             rmask[idx] = uint8_t(rm);
         }
-        zn0 = zc0; zn1 = zc1; zn2 = zc2; pn0 = pc0; pn1 = pc1; pn2 = pc2;
-        zc0 = zs0; zc1 = zs1; zc2 = zs2; pc0 = ps0; pc1 = ps1; pc2 = ps2;
     }
     if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
     if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
@@ -533,7 +545,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             D8Traits tr{d_p};
             const float* zc = zcur;
             const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags) {
-                const dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                const dim3 grid((st.nx + CLS_COLS - 1) / CLS_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                 hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
                                    rmask, tile_flags);
             };
