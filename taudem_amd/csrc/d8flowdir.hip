@@ -211,7 +211,7 @@ constexpr int CLS_COLS = 62;
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
                                                                  int y_own0, int y_own1, int tiles_x, lvl_t* __restrict__ lvl,
                                                                  lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                                 uint32_t* __restrict__ tile_flags) {
+                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int lx = threadIdx.x & 63;
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
         if (!inx || y < 0 || y >= ny) { z[j] = 0.f; pw[j] = TDX_P_NODATA; }   // (never looked at from a flat cell: flat cells are interior cells)
     }
     int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
+    int masked_row = -1;                  // ... a flat cell whose incfall mask shuts out an in-queue neighbour (flatk::LevelPlainT)
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
@@ -274,9 +275,10 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
 #undef TDX_CLS
                 l = low ? 1 : (quirk ? 2 : 0);
                 q = higher ? 1 : 0;
+                const int tr = y / tilek::TS;
+                if (!low && fm != rm) masked_row = tr;
                 if (low) fm = 0;       // a level-1 cell can never improve
                 if (higher) rm = 0;
-                const int tr = y / tilek::TS;
                 if (flag_row0 < 0) flag_row0 = tr; else if (tr != flag_row0) flag_row1 = tr;
             }
             lvl[idx] = l;
@@ -287,6 +289,10 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
     }
     if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
     if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    if (masked_row >= 0) {   // rare (dontCross at a lake shore): all the tile rows this lane touched, a superset is harmless
+        tile_masked[flag_row0 * tiles_x + x / tilek::TS] = 1;
+        if (flag_row1 >= 0) tile_masked[flag_row1 * tiles_x + x / tilek::TS] = 1;
+    }
 }
 
 struct D8Traits {
@@ -544,10 +550,10 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             FlatLevels fl;
             D8Traits tr{d_p};
             const float* zc = zcur;
-            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags) {
+            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked) {
                 const dim3 grid((st.nx + CLS_COLS - 1) / CLS_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                 hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
-                                   rmask, tile_flags);
+                                   rmask, tile_flags, tile_masked);
             };
             if (sparse) {
                 rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq);

@@ -59,7 +59,7 @@ template <class Traits>
 __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* __restrict__ Z, int nx, int tiles_x,
                                                        const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
                                                        lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                       uint32_t* __restrict__ tile_flags) {
+                                                       uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * CLASSIFY_ITEMS) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < CLASSIFY_ITEMS; i++) {
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
             fmask[c] = uint8_t(low ? 0u : fm);     // a level-1 cell can never improve
             rmask[c] = uint8_t(higher ? 0u : rm);
             const unsigned y = unsigned(c / size_t(nx)), x = unsigned(c - size_t(y) * size_t(nx));
-            tile_flags[(y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS] = tilek::FLAG_FULL;
+            const unsigned tile = (y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS;
+            tile_flags[tile] = tilek::FLAG_FULL;
+            if (!low && fm != rm) tile_masked[tile] = 1;   // an in-queue neighbour that incfall must not read: no plain tile (see LevelPlainT)
         }
     }
 }
@@ -99,12 +101,45 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
 // HBM (the values in registers are 32-bit either way): int16 for the two level fields, where a candidate level saturates at LVL_SAT -
 // the fixed point of the saturating operator is min(level, LVL_SAT) per cell, i.e. the exact field whenever every level fits, and
 // flats_bfs turns a saturated maximum into the error the reference's overflowing int16 counters stand for; int32 for the plain marks.
+//
+// PLAIN tiles.  A neighbour that a level-field mask excludes is, almost always, a cell outside the queue - which holds +inf for good - so the masked
+// minimum equals the minimum over all eight neighbours and the mask only says WHETHER the cell may move.  (incrise: always - its mask is
+// "neighbour in the queue".  incfall: unless an in-queue neighbour is shut out by dontCross or by a different elevation; the classification
+// marks the tiles that own such a cell in TM.)  Unmarked tiles run LevelPlainT: the nine-way minimum as min3 + six DPP-fused v_min_i32, the lock
+// as one v_med3_i32 - 12 VALU instructions per 64-cell row instead of 38 - and the int16 saturation moves to the store (the fixed point of
+// "saturate when stored" is the same min(level, LVL_SAT): a stored LVL_SAT never improves a neighbour below LVL_SAT).
+template <class S>
+struct LevelPlainT {
+    using T = int;
+    static constexpr int kUniform = 8;
+    S* G;
+    const uint8_t* M;
+    static __device__ __forceinline__ int inf() { return 0x3fffffff; }
+    using Raw = S;
+    using CellRaw = uint8_t;
+    __device__ __forceinline__ S load_raw(size_t idx) const { return G[idx]; }
+    static __device__ __forceinline__ int decode(S g) { return g > 0 ? int(g) : inf(); }
+    __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = S(sizeof(S) == 2 && v > LVL_SAT ? LVL_SAT : v); }
+    __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
+    static __device__ __forceinline__ void cell_decode(uint8_t m, int& lock, unsigned& mask) { lock = m ? 0 : inf(); mask = m; }
+    // The constant of a cell is 0 where it may move and THE VALUE IT WAS LOADED WITH where it may not (mask 0: seeds, cells outside the queue,
+    // cells of other strips): median(m + 1, 0, own) = min(m + 1, own) (both positive), median(m + 1, own, own) = own.
+    static __device__ __forceinline__ int cell_floor(int lock, int v) { return lock == 0 ? 0 : v; }
+    static __device__ __forceinline__ int apply(int lock, int own, int m) { return tilek::med3_raw(m + 1, lock, own); }
+    static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
+};
+
 template <int INC, class S>   // INC 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
 struct LevelOpT {
     using T = int;
     static constexpr int kUniform = 0;
     S* G;
     const uint8_t* M;
+    const uint8_t* TM = nullptr;   // INC 1 only: per tile, 1 = a cell of the tile needs its mask (null: no tile does)
+    static constexpr bool kHasPlain = INC == 1;
+    using Plain = LevelPlainT<S>;
+    __device__ __forceinline__ Plain plain() const { return Plain{G, M}; }
+    __device__ __forceinline__ bool tile_masked(int tile) const { return TM != nullptr && TM[tile] != 0; }
     static __device__ __forceinline__ int inf() { return 0x3fffffff; }
     using Raw = S;
     using CellRaw = uint8_t;
@@ -119,6 +154,7 @@ struct LevelOpT {
         if (sizeof(S) == 2 && INC) t = unsigned(t - LVL_SAT) < unsigned(inf() - LVL_SAT) ? LVL_SAT : t;
         return t < own ? t : own;
     }
+    static __device__ __forceinline__ int cell_floor(int cst, int) { return cst; }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
 };
 using LevelOp = LevelOpT<1, lvl_t>;
@@ -301,9 +337,11 @@ static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const lv
 // of once per level).
 template <class Op = flatk::LevelOp>
 static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, typename Op::Raw* field, const uint8_t* mask, tilek::Sched sc,
-                                    int64_t* rounds, int64_t* launches) {
+                                    int64_t* rounds, int64_t* launches, const uint8_t* tile_masked = nullptr) {
+    Op op{field, mask};
+    if constexpr (Op::kHasPlain) op.TM = tile_masked;
     for (;;) {
-        int rc = tile_relax_run(ctx, Op{field, mask}, geom, sc, rounds, launches);
+        int rc = tile_relax_run(ctx, op, geom, sc, rounds, launches);
         if (rc != TDX_OK) return rc;
         if (!st.multi()) return TDX_OK;
         int64_t changed = 0;
@@ -318,7 +356,7 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 // `stream_classify` (optional): replaces the marker reset + list-based classification by one streaming pass over the
 // whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags; qlist may then be null (no list was
 // built for a dense queue): the level statistics come from a pass over the owned rows instead.
-using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags)>;
+using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked)>;
 template <class Traits>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
                      FlatBuffers b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr) {
@@ -330,21 +368,27 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     uint8_t* fmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_E, n));
     uint8_t* rmask = static_cast<uint8_t*>(ctx->scratch(TDX_S_F, n));
-    uint32_t* flags0 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ntiles) * 4 * 2));
+    uint32_t* flags0 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, size_t(ntiles) * 4 * 2 + size_t(ntiles)));
     uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(ntiles) * 4 * tilek::SCHED_LIST_WORDS));
     unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_K, size_t(tilek::COUNT_RING) * 16));
     if (!fmask || !rmask || !flags0 || !list || !counts) return TDX_ERR_NOMEM;
     uint32_t* flags = flags0 + ntiles;
+    uint8_t* tmask = reinterpret_cast<uint8_t*>(flags0 + 2 * size_t(ntiles));   // incfall: tiles that are not plain
+    const char* e_masked = getenv("TDX_FLATS_MASKED");   // A/B and test hook (read per call): 1 = every tile on the masked form, 2 = the first half of the tiles
+    const bool no_plain = e_masked && e_masked[0] == '1';
+    const bool half_plain = e_masked && e_masked[0] == '2';
     TdxSpan sp(ctx, TDX_K_BFS);
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     TDX_HIP_CHECK(ctx, hipMemsetAsync(flags0, 0, size_t(ntiles) * 4, s));
-    if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0);
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(tmask, no_plain ? 1 : 0, size_t(ntiles), s));
+    if (half_plain) TDX_HIP_CHECK(ctx, hipMemsetAsync(tmask, 1, size_t(ntiles + 1) / 2, s));
+    if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask);
     else {
         TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
         TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
         if (nq)
             hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
-                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0);
+                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask);
     }
     int rc = strip_exchange<lvl_t>(ctx, st, b.lvl, lvl_t(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;
@@ -360,17 +404,17 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         uint32_t* listB = flagsB + ntiles;
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flagsB, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = tile_relax_run_pair(ctx, flatk::LevelOp{b.lvl, fmask}, tilek::Sched{flags, list, counts}, flatk::LevelOp{b.rq, rmask},
-                                 tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
+        rc = tile_relax_run_pair(ctx, flatk::LevelOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
+                                 flatk::LevelOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
         if (rc != TDX_OK) return rc;
     } else {
         // ---- incfall ----
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches);
+        rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches, tmask);
         if (rc != TDX_OK) return rc;
         // ---- incrise ----
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches);
+        rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
         if (rc != TDX_OK) return rc;
     }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));

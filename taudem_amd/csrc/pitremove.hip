@@ -132,10 +132,11 @@ struct PitOp {
     __device__ __forceinline__ void store(size_t idx, float v) const { W[idx] = v; }
     __device__ __forceinline__ float cell_raw(size_t idx) const { return Z[idx]; }
     static __device__ __forceinline__ void cell_decode(float z, float& cst, unsigned& mask) { cst = z; mask = (NBR == 4) ? 0x55u : 0xFFu; }
-    static __device__ __forceinline__ float apply(float z, float w, float m) {
-        const float t = tilek::max_raw(z, tilek::min_raw(w, m));   // computed unconditionally: a select, not a branch
-        return (w > z) ? t : w;
-    }
+    // A cell that is settled when the tile is loaded (w <= z: seeds, nodata cells with their marker value) never moves: its floor becomes
+    // its own value.  For all others w > z >= ... holds for the whole activation (values only decrease, never below z), so
+    // (w > z ? max(z, min(w, m)) : w) is the median of (z, w, m): ONE v_med3_f32 per cell and sweep.
+    static __device__ __forceinline__ float cell_floor(float z, float w) { return (w > z) ? z : w; }
+    static __device__ __forceinline__ float apply(float z, float w, float m) { return tilek::med3_raw(z, w, m); }
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
 };
 

@@ -101,6 +101,8 @@ __device__ __forceinline__ T uniform_min(bool fourway, T e, T ne, T n, T nw, T w
 //   void store(size_t idx, T v) const;   changed cell
 //   CellRaw cell_raw(size_t idx) const; static void cell_decode(CellRaw, T& cst, unsigned& mask);
 //                                        per-cell constant + neighbour mask (0 = never updated)
+//   static T cell_floor(T cst, T v);     register tiles only: the constant apply() gets, given the value v the cell is loaded with
+//                                        (lets an operator fold "a settled cell never moves" into the constant)
 //   static T apply(T cst, T own, T m);   new value (must be <= own)
 //   static bool settled(T cst, T v);     v can never decrease again
 //   static constexpr int kUniform;       0: per-cell masks; 8 / 4: every updatable cell looks at all 8 / the 4 cardinal neighbours
@@ -428,14 +430,42 @@ __device__ __forceinline__ float min_with_side_lanes3(float acc, float a, float 
     return acc;
 }
 
+// the same for 32-bit integers (v_min_i32 is a VOP2 instruction, so it takes the DPP modifier as well)
+__device__ __forceinline__ int min_with_side_lanes(int acc, int x) {
+    asm("s_nop 1\n\tv_min_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(x));
+    return acc;
+}
+__device__ __forceinline__ int min_with_side_lanes3(int acc, int a, int c, int b) {
+    asm("s_nop 1\n\t"
+        "v_min_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %0, %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_i32_dpp %0, %2, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %0, %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_i32_dpp %0, %3, %0 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(a), "v"(c), "v"(b));
+    return acc;
+}
+// median of three as ONE instruction: with lock in {0, inf} and cand, own > 0 this is "own if locked, else min(cand, own)"
+__device__ __forceinline__ float med3_raw(float a, float b, float c) {
+    float d;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int med3_raw(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // Minimum over the 8 (4) neighbours of one row of cells.  a / c / b: this column in the row above / this row / the row
 // below; hm: precomputed minimum over this row's neighbours in the halo column (lanes 0 and 63; +inf elsewhere).
 template <class Op>
 __device__ __forceinline__ typename Op::T reg_row_min(unsigned m8, typename Op::T a, typename Op::T c, typename Op::T b, typename Op::T hm,
                                                       ShiftRegs<typename Op::T>& s) {
     using T = typename Op::T;
-    if constexpr (std::is_same<T, float>::value && Op::kUniform != 0) {   // 7 (3) instructions instead of 6 + 4 (2 + 2)
-        const float acc = min3_raw(a, b, hm);
+    if constexpr (Op::kUniform != 0) {   // 7 (3) instructions instead of 6 + 4 (2 + 2)
+        const T acc = min3_raw(a, b, hm);
         return Op::kUniform == 8 ? min_with_side_lanes3(acc, a, c, b) : min_with_side_lanes(acc, c);
     }
     s.lc = lane_left(c, s.lc);
@@ -519,9 +549,9 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         T c = Op::inf();
         unsigned m = 0;
         if (col_ok && gy >= g.y_own0 && gy < g.y_own1) Op::cell_decode(craw[r], c, m);
-        cst[r] = c;
-        mk[r >> 2] |= (m & 0xFFu) << (8 * (r & 3));
         if (m && !Op::settled(c, v[r])) live |= 1u << r;
+        cst[r] = Op::cell_floor(c, v[r]);
+        mk[r >> 2] |= (m & 0xFFu) << (8 * (r & 3));
     }
     const T edge_row = edge_ok ? Op::decode(raw_edge) : Op::inf();
     if (tid < 2 * LH) sSide[(tid & 1) * LH + (tid >> 1)] = side_ok ? Op::decode(raw_side) : Op::inf();
@@ -734,6 +764,11 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
     }
 }
 
+template <class Op, class = void>
+struct has_plain : std::false_type {};
+template <class Op>
+struct has_plain<Op, std::enable_if_t<Op::kHasPlain>> : std::true_type {};
+
 template <class Op, bool REG>
 __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                     uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
@@ -743,6 +778,9 @@ __global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const
     __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
     __shared__ TileLds L;
     round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
+        if constexpr (REG && has_plain<Op>::value) {   // tiles whose masks only say "may move" take the uniform form of the operator (flats.hpp)
+            if (!__builtin_amdgcn_readfirstlane(int(op.tile_masked(tile)))) return relax_tile_reg(op.plain(), g, tile, sV, L, dbg);
+        }
         return REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);
     });
 }
@@ -1002,6 +1040,11 @@ struct RoundRunner {
     }
     int enqueue() {   // at most two batches may be in flight
         using namespace tilek;
+        // A monotone relaxation ends; a schedule that does not is a defect (an operator that raises a value, a torn activation flag), and a
+        // silent endless loop is the worst way to report it: generous bound (a front can wind through a tile a few dozen times), then an error.
+        static const long long round_cap = getenv("TDX_RELAX_MAX_ROUNDS") ? atoll(getenv("TDX_RELAX_MAX_ROUNDS")) : 0;
+        if (rounds > (round_cap > 0 ? round_cap : 64ll * ntiles + 65536ll))
+            return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no fixed point after " + std::to_string(rounds) + " rounds (" + std::to_string(ntiles) + " tiles)");
         if (batch > ring_len - 2) batch = ring_len - 2;
         if (r_enq + batch + 1 > ring_len) {   // counts[r + batch] (written by the batch's last round) must be inside the ring
             hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, sc.counts, r_enq);
