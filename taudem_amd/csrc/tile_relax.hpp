@@ -494,6 +494,16 @@ __device__ __forceinline__ typename Op::T halo_min(unsigned m8, bool left, bool 
                 : min3_raw(keep_if_bit(m8, 1, ha, inf), keep_if_bit(m8, 0, hc, inf), keep_if_bit(m8, 7, hb, inf));
 }
 
+// bitwise OR over the 64 lanes of a wave (uniform result): four row_shr steps leave a row's OR in its lane 15, then four lane reads
+__device__ __forceinline__ unsigned wave_or(unsigned x) {
+    int y = int(x);
+    y |= __builtin_amdgcn_update_dpp(0, y, 0x111, 0xf, 0xf, true);   // row_shr:1 (lanes without a source read 0)
+    y |= __builtin_amdgcn_update_dpp(0, y, 0x112, 0xf, 0xf, true);   // row_shr:2
+    y |= __builtin_amdgcn_update_dpp(0, y, 0x114, 0xf, 0xf, true);   // row_shr:4
+    y |= __builtin_amdgcn_update_dpp(0, y, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return unsigned(__builtin_amdgcn_readlane(y, 15) | __builtin_amdgcn_readlane(y, 31) | __builtin_amdgcn_readlane(y, 47) | __builtin_amdgcn_readlane(y, 63));
+}
+
 // Same contract as relax_tile (sV must hold REG_LDS_WORDS words).
 template <class Op>
 __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, int tile, typename Op::T* sV, TileLds& L, unsigned long long* __restrict__ dbg) {
@@ -579,36 +589,51 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         const int cur = iter & 1;
         const T up = (wv == 0) ? edge_row : sRow[((cur * NWAVE + wv - 1) * 2 + 1) * TS + lx];
         const T dn = (wv == NWAVE - 1) ? edge_row : sRow[((cur * NWAVE + wv + 1) * 2 + 0) * TS + lx];
-        unsigned chg_rows = 0;   // wave-uniform: rows in which some cell moved in this sweep
-        if ((iter & 1) == 0) {   // downward: a row that moved pulls in the next one in the same sweep
+        // Rows are swept in groups of four, from the first group with a dirty row to the end of the band, and a group is straight-line
+        // code: no per-row "did anybody move" test.  (The per-row form - skip a clean row, pull in the next row when this one moved - put
+        // a VALU compare -> VCC -> scalar compare -> branch chain between any two rows: ~185 cycles per row for 12 VALU instructions.)
+        // What moved is collected per lane and reduced to the wave-uniform row mask once per sweep.
+        unsigned chg_lane = 0;   // rows of this lane that moved in this sweep
+        const unsigned gm = ((rows & 0x000Fu) ? 1u : 0u) | ((rows & 0x00F0u) ? 2u : 0u) | ((rows & 0x0F00u) ? 4u : 0u) | ((rows & 0xF000u) ? 8u : 0u);
+        if ((iter & 1) == 0) {   // downward: a row that moved hands its value to the next one in the same sweep
+            bool go = false;
 #pragma unroll
-            for (int r = 0; r < RPW; r++) {
-                if (!((rows >> r) & 1u)) continue;
-                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
-                unsigned m8 = mask_at(mk, r);
-                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
-                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
-                const T wn = Op::apply(cst[r], c, m);
-                const bool ch = wn != c;
-                v[r] = wn;
-                if (ch) moved |= 1u << r;
-                if (__ballot(ch) != 0ull) { chg_rows |= 1u << r; rows |= (2u << r) & rows_live; }
+            for (int gq = 0; gq < RPW / 4; gq++) {
+                go = go || ((gm >> gq) & 1u);
+                if (!go) continue;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = 4 * gq + q;
+                    const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                    unsigned m8 = mask_at(mk, r);
+                    if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
+                    const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                    const T wn = Op::apply(cst[r], c, m);
+                    chg_lane |= (wn != c) ? (1u << r) : 0u;
+                    v[r] = wn;
+                }
             }
         } else {                 // upward
+            bool go = false;
 #pragma unroll
-            for (int r = RPW - 1; r >= 0; r--) {
-                if (!((rows >> r) & 1u)) continue;
-                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
-                unsigned m8 = mask_at(mk, r);
-                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
-                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
-                const T wn = Op::apply(cst[r], c, m);
-                const bool ch = wn != c;
-                v[r] = wn;
-                if (ch) moved |= 1u << r;
-                if (__ballot(ch) != 0ull) { chg_rows |= 1u << r; rows |= ((1u << r) >> 1) & rows_live; }
+            for (int gq = RPW / 4 - 1; gq >= 0; gq--) {
+                go = go || ((gm >> gq) & 1u);
+                if (!go) continue;
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    const int r = 4 * gq + q;
+                    const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                    unsigned m8 = mask_at(mk, r);
+                    if (Op::kUniform == 0) asm volatile("" : "+v"(m8));
+                    const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                    const T wn = Op::apply(cst[r], c, m);
+                    chg_lane |= (wn != c) ? (1u << r) : 0u;
+                    v[r] = wn;
+                }
             }
         }
+        moved |= chg_lane;
+        const unsigned chg_rows = wave_or(chg_lane);   // wave-uniform: rows in which some cell moved in this sweep
         // publish this band's boundary rows for the next sweep (other parity: a slow wave may still be reading this one)
         sRow[(((cur ^ 1) * NWAVE + wv) * 2 + 0) * TS + lx] = v[0];
         sRow[(((cur ^ 1) * NWAVE + wv) * 2 + 1) * TS + lx] = v[RPW - 1];
