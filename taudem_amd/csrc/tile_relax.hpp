@@ -494,6 +494,17 @@ __device__ __forceinline__ typename Op::T halo_min(unsigned m8, bool left, bool 
                 : min3_raw(keep_if_bit(m8, 1, ha, inf), keep_if_bit(m8, 0, hc, inf), keep_if_bit(m8, 7, hb, inf));
 }
 
+// x = 2 * x + (a != b): compare + add-with-carry, two VALU instructions per row for "which rows of this lane moved"
+template <class T>
+__device__ __forceinline__ unsigned shift_in_ne(unsigned x, T a, T b) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    if constexpr (std::is_same<T, float>::value)
+        asm("v_cmp_neq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(a), "v"(b) : "vcc");
+    else
+        asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(a), "v"(b) : "vcc");
+    return x;
+}
+
 // bitwise OR over the 64 lanes of a wave (uniform result): four row_shr steps leave a row's OR in its lane 15, then four lane reads
 __device__ __forceinline__ unsigned wave_or(unsigned x) {
     int y = int(x);
@@ -589,47 +600,35 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         const int cur = iter & 1;
         const T up = (wv == 0) ? edge_row : sRow[((cur * NWAVE + wv - 1) * 2 + 1) * TS + lx];
         const T dn = (wv == NWAVE - 1) ? edge_row : sRow[((cur * NWAVE + wv + 1) * 2 + 0) * TS + lx];
-        // Rows are swept in groups of four, from the first group with a dirty row to the end of the band, and a group is straight-line
-        // code: no per-row "did anybody move" test.  (The per-row form - skip a clean row, pull in the next row when this one moved - put
-        // a VALU compare -> VCC -> scalar compare -> branch chain between any two rows: ~185 cycles per row for 12 VALU instructions.)
-        // What moved is collected per lane and reduced to the wave-uniform row mask once per sweep.
+        // A band with a dirty row is swept whole, as straight-line code: no per-row "did anybody move" test.  (The per-row form - skip a
+        // clean row, pull in the next row when this one moved - put a VALU compare -> VCC -> scalar compare -> branch chain between any two
+        // rows: ~185 cycles per row for 12 VALU instructions; sweeping from the first dirty group of four rows was no faster than this.)
+        // What moved is collected per lane - compare + add-with-carry shift the row's bit in - and reduced to the wave-uniform row mask
+        // once per sweep.  10 VALU instructions per row for the uniform operators.
         unsigned chg_lane = 0;   // rows of this lane that moved in this sweep
-        const unsigned gm = ((rows & 0x000Fu) ? 1u : 0u) | ((rows & 0x00F0u) ? 2u : 0u) | ((rows & 0x0F00u) ? 4u : 0u) | ((rows & 0xF000u) ? 8u : 0u);
-        if ((iter & 1) == 0) {   // downward: a row that moved hands its value to the next one in the same sweep
-            bool go = false;
+        if (rows == 0u) {
+        } else if ((iter & 1) == 0) {   // downward: a row that moved hands its value to the next one in the same sweep
 #pragma unroll
-            for (int gq = 0; gq < RPW / 4; gq++) {
-                go = go || ((gm >> gq) & 1u);
-                if (!go) continue;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int r = 4 * gq + q;
-                    const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
-                    unsigned m8 = mask_at(mk, r);
-                    if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
-                    const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
-                    const T wn = Op::apply(cst[r], c, m);
-                    chg_lane |= (wn != c) ? (1u << r) : 0u;
-                    v[r] = wn;
-                }
+            for (int r = 0; r < RPW; r++) {
+                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                unsigned m8 = mask_at(mk, r);
+                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));   // keeps the per-row mask arithmetic inside the sweep loop (128 hoisted conditions spill)
+                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                const T wn = Op::apply(cst[r], c, m);
+                chg_lane = shift_in_ne(chg_lane, wn, c);
+                v[r] = wn;
             }
-        } else {                 // upward
-            bool go = false;
+            chg_lane = __builtin_bitreverse32(chg_lane) >> (32 - RPW);   // row 0 was shifted in first
+        } else {                        // upward (row RPW - 1 is shifted in first: bit r = row r)
 #pragma unroll
-            for (int gq = RPW / 4 - 1; gq >= 0; gq--) {
-                go = go || ((gm >> gq) & 1u);
-                if (!go) continue;
-#pragma unroll
-                for (int q = 3; q >= 0; q--) {
-                    const int r = 4 * gq + q;
-                    const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
-                    unsigned m8 = mask_at(mk, r);
-                    if (Op::kUniform == 0) asm volatile("" : "+v"(m8));
-                    const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
-                    const T wn = Op::apply(cst[r], c, m);
-                    chg_lane |= (wn != c) ? (1u << r) : 0u;
-                    v[r] = wn;
-                }
+            for (int r = RPW - 1; r >= 0; r--) {
+                const T a = r ? v[r ? r - 1 : 0] : up, c = v[r], b = (r < RPW - 1) ? v[r < RPW - 1 ? r + 1 : r] : dn;
+                unsigned m8 = mask_at(mk, r);
+                if (Op::kUniform == 0) asm volatile("" : "+v"(m8));
+                const T m = reg_row_min<Op>(m8, a, c, b, hm[r], sh);
+                const T wn = Op::apply(cst[r], c, m);
+                chg_lane = shift_in_ne(chg_lane, wn, c);
+                v[r] = wn;
             }
         }
         moved |= chg_lane;
@@ -1109,6 +1108,8 @@ struct RoundRunner {
         // down to a handful of tiles the end is near (a lone front is followed inside ONE launch: round_driver's solo hand-over), and
         // short batches cost nothing there: the host has the counts of batch k long before batch k + 1 is through.
         if (short_tail && rounds > 0 && last_count <= 8ull) batch = std::min(batch, 4);
+        static const int tail_batch = getenv("TDX_RELAX_TAIL_BATCH") ? std::max(2, atoi(getenv("TDX_RELAX_TAIL_BATCH"))) : 0;   // (A/B hook)
+        if (tail_batch && rounds > 0 && last_count <= 256ull) batch = std::min(batch, tail_batch);
         return TDX_OK;
     }
     int wait_oldest() {   // the oldest batch in flight has finished and its counts are on the host
