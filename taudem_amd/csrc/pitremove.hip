@@ -122,6 +122,7 @@ template <int NBR>   // 8, or 4 for the -4way flag (k = 1,3,5,7)
 struct PitOp {
     using T = float;
     static constexpr int kUniform = NBR;
+    static constexpr int kWaves = 5;   // 96 VGPRs without spills: five tiles per CU (the bulk rounds stream tiles, one more in flight is worth 1 %)
     const float* Z;
     float* W;
     static __device__ __forceinline__ float inf() { return FLT_MAX; }

@@ -788,13 +788,18 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
     }
 }
 
+// waves per SIMD (= workgroups per CU) a relaxation kernel is compiled for: Op::kWaves, 4 (128 VGPRs) unless the operator says otherwise
+template <class Op, class = void>
+struct relax_waves : std::integral_constant<int, 4> {};
+template <class Op>
+struct relax_waves<Op, std::void_t<decltype(Op::kWaves)>> : std::integral_constant<int, Op::kWaves> {};
 template <class Op, class = void>
 struct has_plain : std::false_type {};
 template <class Op>
 struct has_plain<Op, std::enable_if_t<Op::kHasPlain>> : std::true_type {};
 
 template <class Op, bool REG>
-__global__ __launch_bounds__(NTHR, 4) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+__global__ __launch_bounds__(NTHR, relax_waves<Op>::value) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                     uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
                                                     uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg) {
     using T = typename Op::T;
