@@ -7,7 +7,8 @@
 // (the minimax-path surface), so ANY schedule that runs to convergence yields
 // the same bits.  Schedule used here:
 //
-//   * pit_seed_kernel    streaming 3x3 stencil: Z -> W0                 (src/flood.cpp:243-271)
+//   * pit_seed_kernel    streaming 3x3 stencil: Z -> W0                 (src/flood.cpp:243-271); with the coarse-to-fine start: Z -> first
+//                        coarse level, and later Z + relaxed coarse level -> start surface
 //   * tilek::relax_kernel<PitOp>  the tile relaxation engine of tile_relax.hpp: one workgroup per
 //                        ACTIVE 64x64 tile, W tile + halo in LDS, Z in registers, chaotic in-LDS
 //                        relaxation to the tile-local fixed point, write-back of changed cells; tiles
@@ -25,9 +26,17 @@ namespace {
 
 // Seed surface (src/flood.cpp:243-271).  A 256-thread block covers 64 columns x 64 rows; each lane walks a 16-row
 // column segment with the 3x3 window of nodata flags in registers: 3 coalesced row loads per output row.
+// MODE 0: W0 (FLT_MAX where the cell is not a seed).  The coarse-to-fine start (below) runs the pass twice instead, with nothing written in
+// between: MODE 1 only reduces the seed surface to the first coarse level (per 8 x 8 block of the owned rows: Zc = largest valid
+// elevation, Wc = Zc if the block holds a seed cell, else FLT_MAX; TDX_FEL_NODATA for a block without valid cells - what
+// pit_coarsen_kernel derives from Z and W0), MODE 2 writes the start surface itself, W = seed ? z : Wc[block] (what pit_prolong_kernel
+// makes of W0).  6.7 GB of traffic for seed + coarsen + prolong become 3 GB.
 constexpr int SEED_ROWS = 16;
+constexpr int SEED_CF = 8;   // = CF below
+template <int MODE>
 __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__ Z, const int16_t* __restrict__ mask,
-                                                       float* __restrict__ W, int nx, int ny, int y_own0, int y_own1, float nodata, int step) {
+                                                       float* __restrict__ W, int nx, int ny, int y_own0, int y_own1, float nodata, int step,
+                                                       float* __restrict__ Zc, float* __restrict__ Wc, int nxc, int nyc) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ybase = y_own0 + blockIdx.y * (4 * SEED_ROWS) + (threadIdx.x >> 6) * SEED_ROWS;
     const bool colok = x < nx;
@@ -44,6 +53,10 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     bool n0, n1, n2, c0, c1, c2, s0, s1, s2;
     ldrow(ybase - 1, zn, n0, n1, n2);
     ldrow(ybase, zc, c0, c1, c2);
+    float bmax[SEED_ROWS / SEED_CF];   // MODE 1: this lane's column of each block row it crosses
+    bool bany[SEED_ROWS / SEED_CF], bseed[SEED_ROWS / SEED_CF];
+#pragma unroll
+    for (int q = 0; q < SEED_ROWS / SEED_CF; q++) { bmax[q] = -FLT_MAX; bany[q] = false; bseed[q] = false; }
 #pragma unroll
     for (int r = 0; r < SEED_ROWS; r++) {
         const int y = ybase + r;
@@ -58,12 +71,39 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
                 const bool con = (step == 2) ? (c2 || n1 || c0 || s1) : (c2 || n2 || n1 || n0 || c0 || s0 || s1 || s2);
                 w = con ? zc : FLT_MAX;
             }
-            W[idx] = w;
+            if (MODE == 0) W[idx] = w;
+            if (MODE == 1 && !c1) {
+                bany[r / SEED_CF] = true;
+                bmax[r / SEED_CF] = fmaxf(bmax[r / SEED_CF], zc);
+                if (w != FLT_MAX) bseed[r / SEED_CF] = true;
+            }
+            if (MODE == 2) {
+                if (w == FLT_MAX) w = Wc[size_t((y - y_own0) / SEED_CF) * size_t(nxc) + size_t(x / SEED_CF)];
+                W[idx] = w;
+            }
         }
         zn = zc; n0 = c0; n1 = c1; n2 = c2;
         zc = zs; c0 = s0; c1 = s1; c2 = s2;
     }
     (void)zn;
+    if (MODE == 1) {   // the 8 lanes of a block column (aligned: 64 columns per wave), then one store per block
+#pragma unroll
+        for (int q = 0; q < SEED_ROWS / SEED_CF; q++) {
+            float m = bmax[q];
+            int fl = (bany[q] ? 1 : 0) | (bseed[q] ? 2 : 0);
+#pragma unroll
+            for (int off = 1; off < SEED_CF; off <<= 1) {
+                m = fmaxf(m, __shfl_xor(m, off, 64));
+                fl |= __shfl_xor(fl, off, 64);
+            }
+            const int yc = (ybase - y_own0) / SEED_CF + q, xcb = x / SEED_CF;
+            if ((threadIdx.x & (SEED_CF - 1)) == 0 && xcb < nxc && yc < nyc) {
+                const size_t c = size_t(yc) * size_t(nxc) + size_t(xcb);
+                Zc[c] = (fl & 1) ? m : TDX_FEL_NODATA;
+                Wc[c] = (fl & 1) ? ((fl & 2) ? m : FLT_MAX) : TDX_FEL_NODATA;
+            }
+        }
+    }
 }
 
 // ---- coarse-to-fine start surface ------------------------------------------------------------------------------
@@ -74,6 +114,7 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
 // cells are 8-connected to each other or to a seed next to the block's nodata cells), hence W*(c) <= Wc*(block(c)).
 // Used for the 8-neighbour fill of a single strip; recursive.
 constexpr int CF = 8;
+static_assert(CF == SEED_CF, "pit_seed_kernel reduces to the first coarse level");
 __global__ __launch_bounds__(256) void pit_coarsen_kernel(const float* __restrict__ Z, const float* __restrict__ W0, int nx, int ny, int nxc, int nyc,
                                                           float* __restrict__ Zc, float* __restrict__ Wc) {
     const int xc = blockIdx.x * 64 + (threadIdx.x & 63), yc = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -185,24 +226,47 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     strip_mark(ctx, st, "pitremove");
     int rc = strip_exchange<float>(ctx, st, d_dem, dem_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
-    {
-        TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
-        hipLaunchKernelGGL(pit_seed_kernel, grid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, fourway ? 2 : 1);
-        if (stats) stats->launches[TDX_K_STENCIL]++;
-    }
-    rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // seed surface halo rows
-    if (rc != TDX_OK) return rc;
     int64_t rounds = 0, launches = 0, outer = 0;
-    {
-        TdxSpan sp(ctx, TDX_K_RELAX);
-        const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;   // (test hook: read per call)
-        if (!fourway && !no_coarse) {
-            // on the OWNED rows of the strip: paths that leave the strip are ignored, which only loosens the bound
-            const size_t off = size_t(st.y0) * size_t(st.nx);
-            rc = pit_coarse_start(ctx, d_dem + off, d_fel + off, st.nx, st.y1 - st.y0, tilek::Sched{flags, list, counts}, 0, &rounds, &launches);
+    const dim3 sgrid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
+    const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;   // (test hook: read per call)
+    const int nyo = st.y1 - st.y0;   // the coarse-to-fine start works on the OWNED rows: paths that leave the strip are ignored, which only loosens the bound
+    if (!fourway && !no_coarse && size_t(st.nx) * size_t(nyo) >= (size_t(1) << 18)) {
+        // seed surface -> first coarse level -> (coarser levels, relaxed coarse to fine) -> start surface, without a W0 in between
+        const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
+        const size_t nc = size_t(nxc) * size_t(nyc);
+        float* Zc = static_cast<float*>(ctx->scratch(TDX_S_D, nc * 4));
+        float* Wc = static_cast<float*>(ctx->scratch(TDX_S_E, nc * 4));
+        if (!Zc || !Wc) return TDX_ERR_NOMEM;
+        {
+            TdxSpan sp(ctx, TDX_K_STENCIL);
+            hipLaunchKernelGGL(pit_seed_kernel<1>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc);
+            if (stats) stats->launches[TDX_K_STENCIL]++;
+        }
+        {
+            TdxSpan sp(ctx, TDX_K_RELAX);
+            rc = pit_coarse_start(ctx, Zc, Wc, nxc, nyc, tilek::Sched{flags, list, counts}, 1, &rounds, &launches);
+            if (rc != TDX_OK) return rc;
+            const tilek::TileGeom gc = tilek::make_geom(nxc, nyc, 0, nyc);
+            const int ntc = gc.tiles_x * gc.tiles_y;
+            hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntc), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntc));
+            rc = tile_relax_run(ctx, PitOp<8>{Zc, Wc}, gc, tilek::Sched{flags, list, counts}, &rounds, &launches);
             if (rc != TDX_OK) return rc;
         }
+        {
+            TdxSpan sp(ctx, TDX_K_STENCIL);
+            hipLaunchKernelGGL(pit_seed_kernel<2>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc);
+            if (stats) stats->launches[TDX_K_STENCIL]++;
+        }
+    } else {
+        TdxSpan sp(ctx, TDX_K_STENCIL);
+        hipLaunchKernelGGL(pit_seed_kernel<0>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, fourway ? 2 : 1,
+                           static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, 0);
+        if (stats) stats->launches[TDX_K_STENCIL]++;
+    }
+    rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // start surface halo rows
+    if (rc != TDX_OK) return rc;
+    {
+        TdxSpan sp(ctx, TDX_K_RELAX);
         // round 0: every tile is active
         hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
         for (;;) {
