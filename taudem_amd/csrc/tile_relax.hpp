@@ -723,26 +723,27 @@ __device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeo
 template <class Body>
 __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_cur,
                                              uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next, unsigned pull_max, const TileGeom& g,
-                                             TileLds& L, Body body) {
+                                             TileLds& L, Body body, unsigned bid, unsigned nblocks) {
+    // bid / nblocks: this workgroup's index among the workgroups of THIS schedule (a launch can carry two: relax_pair_kernel)
     const int chain_max = g.chain_max;
     const unsigned nact = unsigned(count[0]);
-    const uint32_t entry0 = list[blockIdx.x];          // for a small round (below); fetched together with the count: gridDim.x <= number of tiles
+    const uint32_t entry0 = list[bid];                 // for a small round (below); fetched together with the count: nblocks <= number of tiles
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
-    unsigned pull = nact / (2u * gridDim.x);
+    unsigned pull = nact / (2u * nblocks);
     pull = pull < 1u ? 1u : (pull > pull_max ? pull_max : pull);
     // A small round (the long tail of a relaxation is one dependency front crossing one tile per round) is pure latency:
     // with no more tiles than workgroups every workgroup takes the list entry of its index and the cursor is not used.
-    const bool fixed = nact <= gridDim.x;
+    const bool fixed = nact <= nblocks;
     // at most ceil(nact / pull) pulls find work: the other workgroups of the grid (sized before the round's length is
     // known) leave without touching the cursor - 2048 atomics on one address are ~20 us, as much as a whole small round
-    if (blockIdx.x * pull >= nact) return;
+    if (bid * pull >= nact) return;
     if (threadIdx.x == 0) L.npend = 0u;
     for (unsigned turn = 0;; turn++) {
         __syncthreads();   // the activations of the previous pull are all in L.pend
         const unsigned npend = L.npend;
         if (threadIdx.x == 0) {
             L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;
-            L.next = fixed ? (turn == 0u ? blockIdx.x : nact) : unsigned(atomicAdd(cursor, (unsigned long long)pull));
+            L.next = fixed ? (turn == 0u ? bid : nact) : unsigned(atomicAdd(cursor, (unsigned long long)pull));
         }
         __syncthreads();
         const unsigned first = L.next;
@@ -793,6 +794,13 @@ template <class Op, class = void>
 struct relax_waves : std::integral_constant<int, 4> {};
 template <class Op>
 struct relax_waves<Op, std::void_t<decltype(Op::kWaves)>> : std::integral_constant<int, Op::kWaves> {};
+template <class Body>
+__device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, unsigned long long* __restrict__ count, uint32_t* __restrict__ flags_cur,
+                                             uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next, unsigned pull_max, const TileGeom& g,
+                                             TileLds& L, Body body) {
+    round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, body, blockIdx.x, gridDim.x);
+}
+
 template <class Op, class = void>
 struct has_plain : std::false_type {};
 template <class Op>
@@ -812,6 +820,31 @@ __global__ __launch_bounds__(NTHR, relax_waves<Op>::value) void relax_kernel(Op 
         }
         return REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);
     });
+}
+
+// Two independent relaxations of the same operator type (the two level fields of flat resolution) in ONE launch per round: the first
+// gridA workgroups serve schedule a, the others schedule b.  The rounds of the two advance in lockstep (a schedule that has ended sees
+// empty rounds); nothing depends on two HIP streams being executed side by side.  Opt-in (TDX_FLATS_FUSED=1, flats.hpp): 0.5 ms slower at
+// 16384^2 than two streams that do overlap (profiles/r03y_*), because a fused round lasts as long as the slower field's.
+struct RoundArgs { const uint32_t* list; unsigned long long* count; uint32_t* flags_cur; uint32_t* flags_next; uint32_t* list_next; };
+template <class Op>
+__global__ __launch_bounds__(NTHR, relax_waves<Op>::value) void relax_pair_kernel(Op opA, Op opB, TileGeom g, RoundArgs a, RoundArgs b, unsigned gridA,
+                                                                                  unsigned pull_max) {
+    using T = typename Op::T;
+    static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
+    __shared__ T sV[REG_LDS_WORDS];
+    __shared__ TileLds L;
+    const bool second = blockIdx.x >= gridA;   // uniform
+    const Op op = second ? opB : opA;
+    const RoundArgs ra = second ? b : a;
+    round_driver(ra.list, ra.count, ra.flags_cur, ra.flags_next, ra.list_next, pull_max, g, L,
+                 [&](int tile, bool) {
+                     if constexpr (has_plain<Op>::value) {
+                         if (!__builtin_amdgcn_readfirstlane(int(op.tile_masked(tile)))) return relax_tile_reg(op.plain(), g, tile, sV, L, nullptr);
+                     }
+                     return relax_tile_reg(op, g, tile, sV, L, nullptr);
+                 },
+                 second ? blockIdx.x - gridA : blockIdx.x, second ? gridDim.x - gridA : gridA);
 }
 
 // ---- schedule 2: asynchronous worklist.  ONE launch: resident workgroups pop tiles from a device queue, relax
@@ -1155,6 +1188,72 @@ struct RoundRunner {
         return TDX_OK;
     }
 };
+
+// One batch of FUSED rounds for two relaxations in lockstep (relax_pair_kernel): A's batch bookkeeping leads, B's follows.
+template <class Op>
+static int enqueue_fused(RoundRunner<Op>& A, RoundRunner<Op>& B) {
+    using namespace tilek;
+    tdx_context* ctx = A.ctx;
+    hipStream_t s = A.s;
+    static const long long round_cap = getenv("TDX_RELAX_MAX_ROUNDS") ? atoll(getenv("TDX_RELAX_MAX_ROUNDS")) : 0;
+    if (std::max(A.rounds, B.rounds) > (round_cap > 0 ? round_cap : 64ll * A.ntiles + 65536ll))
+        return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no fixed point after " + std::to_string(std::max(A.rounds, B.rounds)) + " rounds (" + std::to_string(A.ntiles) + " tiles)");
+    int batch = std::min(A.batch, A.ring_len - 2);
+    if (A.r_enq + batch + 1 > A.ring_len) {   // both rings wrap together
+        hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, A.sc.counts, A.r_enq);
+        hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, B.sc.counts, B.r_enq);
+        A.r_enq = B.r_enq = 0;
+    }
+    const int slot = A.n_enq & 1, r = A.r_enq, parity = A.parity_enq;
+    auto grid_of = [](const RoundRunner<Op>& R) { return R.done ? 0u : ((R.rounds > 0 && R.last_count <= 256ull) ? R.grid_small : R.grid_full); };
+    const unsigned gA = grid_of(A), gB = grid_of(B);
+    for (int b = 0; b < batch; b++) {
+        const int p = (parity + b) & 1;
+        const RoundArgs ra{A.list_of(p), A.sc.counts + r + b, A.flags_of(p), A.flags_of(p ^ 1), A.list_of(p ^ 1)};
+        const RoundArgs rb{B.list_of(p), B.sc.counts + r + b, B.flags_of(p), B.flags_of(p ^ 1), B.list_of(p ^ 1)};
+        hipLaunchKernelGGL((relax_pair_kernel<Op>), dim3(std::max(1u, gA + gB)), dim3(NTHR), 0, s, A.op, B.op, A.g, ra, rb, gA, A.pull_max);
+    }
+    A.launches += batch;
+    A.fl_batch[slot] = B.fl_batch[slot] = batch;
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(A.h + slot * TDX_MAIL_RUN_SLOT, A.sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TDX_HIP_CHECK(ctx, hipMemcpyAsync(B.h + slot * TDX_MAIL_RUN_SLOT, B.sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    hipEvent_t& ev = ctx->ev_batch[A.ev_base + slot];
+    if (!ev) TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    TDX_HIP_CHECK(ctx, hipEventRecord(ev, s));
+    A.r_enq += batch; B.r_enq = A.r_enq;
+    A.parity_enq = B.parity_enq = (A.parity_enq + batch) & 1;
+    A.n_enq++; B.n_enq = A.n_enq;
+    A.batch = batch;
+    if (A.batch < A.batch_max) A.batch = std::min(2 * A.batch, A.batch_max);
+    const unsigned long long live = std::max(A.done ? 0ull : A.last_count, B.done ? 0ull : B.last_count);
+    if (A.short_tail && std::max(A.rounds, B.rounds) > 0 && live <= 8ull) A.batch = std::min(A.batch, 4);
+    return TDX_OK;
+}
+
+// Two independent relaxations in lockstep on ONE stream, one launch per round for both (see relax_pair_kernel).
+template <class Op>
+static int tile_relax_run_fused(tdx_context* ctx, Op opA, tilek::Sched scA, Op opB, tilek::Sched scB, tilek::TileGeom g, int64_t* rounds_out,
+                                int64_t* launches_out) {
+    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail + TDX_MAIL_RUN_A, nullptr), B(ctx, ctx->stream, opB, g, scB, ctx->h_mail + TDX_MAIL_RUN_B, nullptr);
+    A.batch_max = B.batch_max = RoundRunner<Op>::pipelined_batch_max();
+    int rc = A.start();
+    if (rc != TDX_OK) return rc;
+    rc = B.start();
+    if (rc != TDX_OK) return rc;
+    rc = enqueue_fused(A, B);
+    if (rc != TDX_OK) return rc;
+    while (!A.done || !B.done) {   // two batches in flight: the host reads one batch's counts while the next one runs
+        rc = enqueue_fused(A, B);
+        if (rc != TDX_OK) return rc;
+        rc = A.wait_oldest();
+        if (rc != TDX_OK) return rc;
+        A.collect();
+        B.collect();
+    }
+    if (rounds_out) *rounds_out += A.rounds + B.rounds;
+    if (launches_out) *launches_out += A.launches;
+    return TDX_OK;
+}
 
 // Two independent relaxations (e.g. the two level fields of flat resolution) side by side on two streams: the rounds of
 // one fill the workgroup slots the other leaves idle.  Work already enqueued on the context's stream is waited for.

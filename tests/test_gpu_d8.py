@@ -73,10 +73,10 @@ def test_round_schedule_count_ring_wraps(ctx, oracle, monkeypatch):
         assert bits_equal(p, p_o), describe_diff(p, p_o, f"p ring={ring}")
 
 
-@pytest.mark.parametrize("env", [{"TDX_RELAX_LDS": "1"}, {"TDX_RELAX_PULL": "1"}, {"TDX_RELAX_PULL": "64"}, {"TDX_FLATS_MASKED": "1"}, {"TDX_FLATS_MASKED": "2"}])
+@pytest.mark.parametrize("env", [{"TDX_RELAX_LDS": "1"}, {"TDX_RELAX_PULL": "1"}, {"TDX_RELAX_PULL": "64"}, {"TDX_FLATS_MASKED": "1"}, {"TDX_FLATS_MASKED": "2"}, {"TDX_FLATS_FUSED": "1"}])
 def test_tile_engine_variants_reach_the_same_bits(ctx, oracle, monkeypatch, env):
     """Schedule knobs of the tile engine (LDS-resident tile kernel, list entries per cursor pull, masked / plain form of the level
-    operator per tile: all tiles masked, or half of them) do not change results."""
+    operator per tile: all tiles masked, or half of them; both level fields in one launch per round) do not change results."""
     dem = oracle.synth_dem((900, 1100), 33)
     fel_o = oracle.pitremove(dem, -9999.0)
     p_o, sd8_o, _ = oracle.d8flowdir(fel_o, -3.0e38, 30.0, 30.0)
@@ -86,7 +86,7 @@ def test_tile_engine_variants_reach_the_same_bits(ctx, oracle, monkeypatch, env)
     assert bits_equal(fel, fel_o), describe_diff(fel, fel_o, f"fel {env}")
     p, sd8 = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0)
     assert bits_equal(p, p_o), describe_diff(p, p_o, f"p {env}")
-    if "TDX_FLATS_MASKED" in env:   # the D-infinity flats run on the same level fields
+    if "TDX_FLATS_MASKED" in env or "TDX_FLATS_FUSED" in env:   # the D-infinity flats run on the same level fields
         ang_o, slp_o = oracle.dinfflowdir(fel_o, -3.0e38, 30.0, 30.0)[:2]
         ang, slp = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0)[:2]
         assert bits_equal(ang, ang_o), describe_diff(ang, ang_o, f"ang {env}")
