@@ -1,4 +1,6 @@
 // C ABI for raster files (host side): thin wrappers over geotiff.cpp.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,13 +49,9 @@ static int write_common(const char* path, int dtype, const void* data, int64_t n
     if (tdx::resolve_output_name(name) != 0) { g_tdx_thread_error = "GDAL driver is not available"; return TDX_ERR_DRIVER; }
     tdx::TiffWriter wr;
     if (!wr.create(name, nx, ny, to_dt(dtype), nodata, georef, lzw != 0)) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
-    // write in slabs so LZW strips stream
-    const int64_t slab = 256;
-    const size_t rowbytes = size_t(nx) * tdx::dtype_size(to_dt(dtype));
-    for (int64_t y = 0; y < ny; y += slab) {
-        int64_t n = std::min<int64_t>(slab, ny - y);
-        if (!wr.write_rows(y, n, static_cast<const char*>(data) + size_t(y) * rowbytes)) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
-    }
+    // TAUDEM_AMD_IO_THREADS host threads encode / write the rows (default 1; the bytes of the file do not depend on it)
+    const char* e = getenv("TAUDEM_AMD_IO_THREADS");
+    if (!wr.write_all(data, e ? std::max(1, std::min(atoi(e), 64)) : 1)) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
     if (!wr.close()) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
     return TDX_OK;
 }

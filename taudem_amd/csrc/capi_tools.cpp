@@ -141,11 +141,8 @@ int save_raster(const char* path, tdx::DType type, const void* data, const tdx::
     if (fileGB > 4.0) printf("Setting BIGTIFF, File: %s, Anticipated size (GB):%.2f\n", name.c_str(), fileGB);
     tdx::TiffWriter wr;
     if (!wr.create(name, like.nx, like.ny, type, nodata, &like, want_lzw())) { printf("Error opening file %s.\n", name.c_str()); g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
-    const size_t rowbytes = size_t(like.nx) * cb;
-    for (int64_t y = 0; y < like.ny; y += 256) {
-        const int64_t nrows = std::min<int64_t>(256, like.ny - y);
-        if (!wr.write_rows(y, nrows, static_cast<const char*>(data) + size_t(y) * rowbytes)) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
-    }
+    // with --gpus N the rows are encoded / written by N host threads (each rank's rows, src/tiffIO.cpp:382-427); same bytes for any N
+    if (!wr.write_all(data, std::min(tool_gpus(), 64))) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
     if (!wr.close()) { g_tdx_thread_error = wr.error(); return TDX_ERR_FILE; }
     return TDX_OK;
 }

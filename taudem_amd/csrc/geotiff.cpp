@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 
 namespace tdx {
 
@@ -738,6 +739,63 @@ bool TiffWriter::write_rows(int64_t y0, int64_t nrows, const void* src) {
             m.stripbuf.clear();
         }
     }
+    return true;
+}
+
+bool TiffWriter::write_all(const void* src, int threads) {
+    Impl& m = *p_;
+    if (m.fd < 0) { err_ = "file not open"; return false; }
+    const size_t cb = dtype_size(m.type);
+    const uint64_t rowbytes = uint64_t(m.nx) * cb;
+    const char* s = static_cast<const char*>(src);
+    const int64_t nstrips = (m.ny + m.rps - 1) / m.rps;
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(threads, nstrips)));
+    if (!m.lzw) {
+        // the file is laid out: bands of whole strips, one per thread (pwrite on a shared descriptor; the layout tables are only read)
+        std::vector<char> failed(size_t(nt), 0);
+        auto band = [&](int k) {
+            const int64_t s0 = nstrips * k / nt, s1 = nstrips * (k + 1) / nt;
+            for (int64_t st = s0; st < s1; st++) {
+                const int64_t y = st * m.rps, n = std::min<int64_t>(m.rps, m.ny - y);
+                if (!pwrite_all(m.fd, s + uint64_t(y) * rowbytes, size_t(uint64_t(n) * rowbytes), m.offsets[size_t(st)])) { failed[size_t(k)] = 1; return; }
+            }
+        };
+        if (nt == 1) band(0);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; k++) th.emplace_back(band, k);
+            for (auto& t : th) t.join();
+        }
+        for (char f : failed) if (f) { err_ = "write error"; return false; }
+        return true;
+    }
+    if (m.next_row != 0) { err_ = "LZW output must be written top-down"; return false; }
+    // chunks of strips: encoded side by side (the encoder keeps its tables per thread), appended in order - bounded memory for any raster
+    const int64_t chunk = int64_t(nt) * 8;
+    std::vector<std::vector<unsigned char>> enc(static_cast<size_t>(std::min<int64_t>(chunk, nstrips)));
+    for (int64_t c0 = 0; c0 < nstrips; c0 += chunk) {
+        const int64_t c1 = std::min<int64_t>(nstrips, c0 + chunk);
+        auto work = [&](int k) {
+            for (int64_t st = c0 + k; st < c1; st += nt) {
+                const int64_t y = st * m.rps, n = std::min<int64_t>(m.rps, m.ny - y);
+                lzw_encode(reinterpret_cast<const unsigned char*>(s + uint64_t(y) * rowbytes), size_t(uint64_t(n) * rowbytes), enc[size_t(st - c0)]);
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; k++) th.emplace_back(work, k);
+            for (auto& t : th) t.join();
+        }
+        for (int64_t st = c0; st < c1; st++) {
+            const std::vector<unsigned char>& e = enc[size_t(st - c0)];
+            if (!pwrite_all(m.fd, e.data(), e.size(), m.data_end)) { err_ = "write error"; return false; }
+            m.offsets[size_t(st)] = m.data_end; m.counts[size_t(st)] = e.size();
+            m.data_end += e.size();
+            if (m.data_end & 1) { unsigned char z = 0; pwrite_all(m.fd, &z, 1, m.data_end); m.data_end++; }
+        }
+    }
+    m.next_row = m.ny;
     return true;
 }
 

@@ -80,6 +80,10 @@ public:
     // Re-open an uncompressed file made by create() for writing more rows.
     bool open_update(const std::string& path);
     bool write_rows(int64_t y0, int64_t nrows, const void* src);   // src: nrows*nx of `type`
+    // The whole raster (ny*nx of `type`) with up to `threads` host threads, into a file just made by create(): uncompressed files
+    // are written as row bands side by side, LZW strips are encoded side by side and appended in strip order - the bytes of the
+    // file do not depend on the thread count (src/tiffIO.cpp:382-427: every rank of the reference writes its own rows).
+    bool write_all(const void* src, int threads);
     bool close();
     const std::string& error() const { return err_; }
     DType type() const;

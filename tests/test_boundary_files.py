@@ -135,3 +135,23 @@ def test_libtiff_decodes_our_files(tmp_path, tiffx, dtype, lzw):
     assert subprocess.run([tiffx, "dump", path, raw]).returncode == 0
     b = np.fromfile(raw, dtype=dtype).reshape(ny, nx)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("lzw", [True, False])
+def test_row_bands_written_by_several_threads_give_the_same_file(tmp_path, monkeypatch, lzw):
+    """TiffWriter::write_all: strips encoded / row bands written side by side (what `--gpus N` does for the tools' outputs, like the ranks
+    of src/tiffIO.cpp:382-427) - the bytes of the file do not depend on the number of threads, and the file reads back."""
+    nx, ny = 3001, 1003   # 12 KB rows -> 87-row strips, a ragged last strip
+    a = expected(nx, ny, np.float32)
+    files = []
+    for threads in (None, "5", "64"):
+        if threads is None:
+            monkeypatch.delenv("TAUDEM_AMD_IO_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("TAUDEM_AMD_IO_THREADS", threads)
+        path = str(tmp_path / f"t{threads}.tif")
+        T.write_raster(path, a, -9999.0, geotransform=(10.0, 2.0, 0.0, 500.0, 0.0, -2.0), lzw=lzw)
+        files.append(open(path, "rb").read())
+        b, info = T.read_raster(path, np.float32)
+        assert np.array_equal(a, b)
+    assert files[0] == files[1] == files[2]
