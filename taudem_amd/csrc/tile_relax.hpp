@@ -359,8 +359,8 @@ __device__ __forceinline__ int relax_tile(const Op& op, const TileGeom& g, int t
 // LDS), the tile's left / right halo column enters as the `old` operand of the shift in lane 0 / lane 63, and a value
 // that moves is seen by the next row of the same sweep simply because it sits in a register.  LDS only carries what
 // crosses waves: the first and last row of every 16-row band (double-buffered by sweep parity) and three flags per
-// band and sweep.  Dirty tracking is per ROW and wave-uniform (a row costs the same VALU time whether 1 or 64 lanes
-// have something to do): rows in which nothing can have changed cost one scalar branch.
+// band and sweep.  Dirty tracking is per BAND and wave-uniform: a band in which nothing can have changed costs one scalar
+// branch, a dirty band is swept whole as straight-line code (see the sweep loop of relax_tile_reg for why not per row).
 constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
 template <class T>
 __device__ __forceinline__ T lane_left(T x, T edge) {    // value held by lane - 1; lane 0 gets `edge`
