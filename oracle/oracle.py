@@ -213,6 +213,40 @@ def dinfdecayaccum(ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, d
     return out
 
 
+def dinf_outlet_closure(ang, outlets, nodata=-3.402823466e38, dx=1.0, dy=1.0, threads=None):
+    """uint8 raster: 1 on the upstream closure of the outlet cells over prop() > 0 edges (the cells initNeighborDinfup puts to work with
+    useOutlets, src/commonLib.cpp:165-233), found by a parallel search."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    ny, nx = ang.shape
+    mark = np.empty((ny, nx), dtype=np.uint8)
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    f = lib().orc_dinf_outlet_closure
+    f.restype = C.c_long
+    f(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), ox, oy, C.c_int(no), C.c_int(int(threads or os.cpu_count() or 1)), _p(mark))
+    return mark
+
+
+def dinfdecayaccum_check(ang, dm, dsca, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None, threads=None):
+    """Linear-time pin of dmarea() (src/dinfdecayaccum.cpp:204-291) to a given result: returns (cells of `dsca` that are not what the loop body gives
+    for their contributors' values in `dsca` - or that hold a value although dmarea() never queues them -, index of the first one or -1, cells
+    dmarea() queues: every cell with an angle, or the outlets' upstream closure).  0 mismatches: `dsca` is the raster dinfdecayaccum() produces."""
+    ang = np.ascontiguousarray(ang, dtype=np.float32)
+    dm = np.ascontiguousarray(dm, dtype=np.float32)
+    dsca = np.ascontiguousarray(dsca, dtype=np.float32)
+    ny, nx = ang.shape
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    ox, oy, no, use, keep = _outl(outlets)
+    dxc, dyc = _f64(dx, ny), _f64(dy, ny)
+    first, queued = C.c_long(-1), C.c_long(0)
+    f = lib().orc_dinfdecayaccum_check
+    f.restype = C.c_long
+    bad = f(_p(ang), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(dm), C.c_float(dm_nodata), _p(weights), C.c_int(int(contcheck)),
+            ox, oy, C.c_int(no), C.c_int(use), _p(dsca), C.c_int(int(threads or os.cpu_count() or 1)), C.byref(first), C.byref(queued))
+    return int(bad), int(first.value), int(queued.value)
+
+
 def dinfupdependence(ang, dg, nodata=-3.402823466e38, dx=1.0, dy=1.0):
     """dep of src/DinfUpDependence.cpp (nodata -1)."""
     ang = np.ascontiguousarray(ang, dtype=np.float32)

@@ -105,3 +105,60 @@ def test_d8flowpathextremeup(name, oracle):
     assert bits_equal(a, h["xup_min_nc"]), describe_diff(a, h["xup_min_nc"], "xup_min_nc")
     a = oracle.d8flowpathextremeup(g["p"], g["sd8"], -32768, usemax=True, contcheck=False, outlets=outlets_to_indices(g))
     assert bits_equal(a, h["xup_max_outlets_nc"]), describe_diff(a, h["xup_max_outlets_nc"], "xup_max_outlets_nc")
+
+
+# ---- the linear-time DinfDecayAccum checker (oracle/taudem_oracle.c: orc_dinfdecayaccum_check) pinned to the reference's own rasters ----
+@pytest.mark.parametrize("key,kw", [("dsca", {}), ("dsca_w_nc", {"w": True, "contcheck": False}), ("dsca_outlets_nc", {"o": True, "contcheck": False})])
+def test_decay_checker_accepts_the_reference_rasters_and_nothing_else(g, oracle, key, kw):
+    """dmarea()'s loop body applied to every cell of the raster the REAL tool wrote reproduces that raster (0 mismatches), the set of queued cells
+    is the set of cells that got a value in -nc mode, and one flipped bit, one value outside the outlets' catchments or one missing value is noticed."""
+    w = g["w"] if kw.get("w") else None
+    outl = outlets_to_indices(g) if kw.get("o") else None
+    cc = kw.get("contcheck", True)
+    args = dict(nodata=-3.402823466e38, dm_nodata=-9999.0, dx=g["dxc"], dy=g["dyc"], weights=w, contcheck=cc, outlets=outl)
+    ref = np.array(g[key], copy=True)
+    bad, first, queued = oracle.dinfdecayaccum_check(g["ang"], g["dm"], ref, **args)
+    assert (bad, first) == (0, -1), f"{key}: {bad} cells of the reference's raster fail the check, first at {first}"
+    have = ref != np.float32(-3.402823466e38)
+    if not cc:
+        assert queued == int(have.sum())     # without contamination every queued cell ends with a value
+    for threads in (1, 3):                   # the closure search and the row bands give the same answer for any thread count
+        assert oracle.dinfdecayaccum_check(g["ang"], g["dm"], ref, threads=threads, **args) == (0, -1, queued)
+    ys, xs = np.nonzero(have)
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])
+    t = ref.copy()
+    t[y, x] = np.nextafter(t[y, x], np.float32(1e30))
+    assert oracle.dinfdecayaccum_check(g["ang"], g["dm"], t, **args)[0] >= 1
+    t = ref.copy()
+    t[y, x] = np.float32(-3.402823466e38)    # a cell that was never evaluated although its contributors were
+    assert oracle.dinfdecayaccum_check(g["ang"], g["dm"], t, **args)[0] >= 1
+    ys, xs = np.nonzero(~have & (g["ang"] != np.float32(-3.402823466e38)))
+    if outl is not None and len(ys):
+        t = ref.copy()
+        t[ys[0], xs[0]] = np.float32(1.0)    # a value outside the outlets' upstream closure
+        assert oracle.dinfdecayaccum_check(g["ang"], g["dm"], t, **args)[0] >= 1
+
+
+def test_decay_checker_vs_restatement_with_weights_outlets_and_contamination(oracle):
+    """The combination BASELINE.json configs[4] runs (-wg, -o, contamination check on, decay multipliers with nodata holes) at a size the restatement's
+    queue loop finishes: checker and restatement agree, and the closure is exactly the set the restatement evaluates in -nc mode."""
+    rng = np.random.default_rng(5)
+    n = 500
+    dem = oracle.synth_dem(n, 9)
+    fel = oracle.pitremove(dem, -9999.0)
+    ang, _, _ = oracle.dinfflowdir(fel, -3.0e38, 30.0, 25.0)
+    w = rng.random((n, n), dtype=np.float32)
+    dm = (0.9 + 0.1 * rng.random((n, n), dtype=np.float32)).astype(np.float32)
+    dm[100:110, 200:230] = -9999.0
+    sca = oracle.areadinf(ang, dx=30.0, dy=25.0, contcheck=False)
+    order = np.argsort(sca, axis=None)[::-1]
+    outl = (np.array([order[3] % n, order[400] % n, 250, 0], dtype=np.int32), np.array([order[3] // n, order[400] // n, 250, 17], dtype=np.int32))
+    for cc in (True, False):
+        d = oracle.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, weights=w, contcheck=cc, outlets=outl)
+        bad, first, queued = oracle.dinfdecayaccum_check(ang, dm, d, dx=30.0, dy=25.0, weights=w, contcheck=cc, outlets=outl)
+        assert (bad, first) == (0, -1)
+        if not cc:
+            mark = oracle.dinf_outlet_closure(ang, outl, dx=30.0, dy=25.0)
+            assert np.array_equal(mark != 0, d != np.float32(-3.402823466e38)) and queued == int(mark.sum())
+    d = oracle.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, contcheck=True)      # no outlets, no weights
+    assert oracle.dinfdecayaccum_check(ang, dm, d, dx=30.0, dy=25.0, contcheck=True)[:2] == (0, -1)
