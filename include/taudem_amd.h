@@ -69,6 +69,8 @@ typedef struct tdx_stats {
     int64_t levels_fall;    /* BFS levels of incfall (sum over iterations)                           */
     int64_t levels_rise;    /* BFS levels of incrise (sum over iterations)                           */
     int64_t cells_evaluated;/* aread8/areadinf/decay: cells that received a value                    */
+    int64_t levels_fall_max;/* largest incfall level of any one iteration (all strips): the level fields are int16 like the */
+    int64_t levels_rise_max;/* reference's elev2 / dn partitions (src/d8.cpp:483,486) - 32766 is the deepest flat they hold  */
 } tdx_stats;
 
 /* kernel classes for ms_kernel[] / launches[] */

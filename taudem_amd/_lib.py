@@ -40,6 +40,8 @@ class TdxStats(C.Structure):
         ("levels_fall", C.c_int64),
         ("levels_rise", C.c_int64),
         ("cells_evaluated", C.c_int64),
+        ("levels_fall_max", C.c_int64),
+        ("levels_rise_max", C.c_int64),
     ]
 
     def as_dict(self):
@@ -52,6 +54,8 @@ class TdxStats(C.Structure):
             "levels_fall": self.levels_fall,
             "levels_rise": self.levels_rise,
             "cells_evaluated": self.cells_evaluated,
+            "levels_fall_max": self.levels_fall_max,
+            "levels_rise_max": self.levels_rise_max,
         }
         for name, k in KERNEL_CLASSES.items():
             d["ms_" + name] = self.ms_kernel[k]

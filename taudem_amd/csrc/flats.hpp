@@ -444,6 +444,8 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     if (stats) {
         stats->levels_fall += L;
         stats->levels_rise += Qmax;
+        stats->levels_fall_max = std::max<int64_t>(stats->levels_fall_max, L);
+        stats->levels_rise_max = std::max<int64_t>(stats->levels_rise_max, Qmax);
         stats->launches[TDX_K_BFS] += launches + 1;
         stats->rounds += rounds_fall + rounds_rise;
     }

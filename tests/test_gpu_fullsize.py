@@ -205,3 +205,104 @@ def test_dinf_config3_three_strips_equal_one(ctx, monkeypatch):
         assert grp.transport == "peer"
     for r, ok in enumerate(res):
         assert all(ok.values()), f"strip {r} of {size} differs from the one-strip run: {ok}"
+
+
+# ---- BASELINE.json configs[4] (DinfDecayAccum -wg -o) at its own strip size, and eight strips of 65536 columns on the final engine ----
+def _decay_job(ctx, nx, ny, seed=1234):
+    import torch
+
+    import bench
+    import taudem_amd as T
+
+    return bench.DecayStrip(torch, ctx, None, nx, ny, 0, ny, seed, T)
+
+
+def test_decay_config5_strip(ctx, oracle, monkeypatch):
+    """configs[4] as one GPU of the 8-GPU run sees it - a 65536 x 8192 strip, weights, decay multipliers, 64 outlets - under the sweep
+    verifier, then EVERY cell against dmarea()'s loop body on the host (oracle.dinfdecayaccum_check, src/dinfdecayaccum.cpp:204-291): evaluated
+    cells follow from their contributors' final values bit for bit (by induction over the dependency order that IS the reference's raster),
+    and a cell holds a value iff an outlet is reachable downstream of it (the restatement's own search of the closure, src/commonLib.cpp:285-385)."""
+    if _host_gb() < 24:
+        pytest.skip("needs ~12 GB of host memory for the linear-time check")
+    import torch
+
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
+    nx, ny = 65536, 8192
+    job = _decay_job(ctx, nx, ny)
+    st = job.step()
+    torch.cuda.synchronize()
+    ox, oy = job.outlets
+    assert len(ox) == 64
+    outl = (np.array(ox, dtype=np.int32), np.array(oy, dtype=np.int32) - 1)      # strip-array rows -> raster rows
+    ang, dm, w, out = (t[1:ny + 1].cpu().numpy() for t in (job.ang, job.dm, job.w, job.out))
+    evaluated = int((out != np.float32(-3.402823466e38)).sum())
+    # (DecayStrip.step() passes the call's default cell size 1 x 1: square cells, and with -wg the cell size only enters through prop())
+    bad, first, queued = oracle.dinfdecayaccum_check(ang, dm, out, dx=1.0, dy=1.0, weights=w, contcheck=True, outlets=outl)
+    assert bad == 0, f"{bad} cells do not follow from dmarea()'s expression / closure; first at row {first // nx} column {first % nx}"
+    assert 0 < evaluated <= queued, (evaluated, queued)
+    assert evaluated == job.evaluated_cells(torch)
+    # -nc: every cell of the closure ends with a value, so the closure itself is pinned cell by cell
+    _, _ = job.pipe.dinfdecayaccum(job.ang, job.dm, weights=job.w, outlets=job.outlets, contcheck=False, out=job.out)
+    torch.cuda.synchronize()
+    out = job.out[1:ny + 1].cpu().numpy()
+    bad, first, queued_nc = oracle.dinfdecayaccum_check(ang, dm, out, dx=1.0, dy=1.0, weights=w, contcheck=False, outlets=outl)
+    assert bad == 0, f"-nc: {bad} cells differ; first at row {first // nx} column {first % nx}"
+    assert queued_nc == queued == int((out != np.float32(-3.402823466e38)).sum())
+    assert st["rounds"] > 0
+
+
+def test_eight_strips_equal_one_at_65536_columns(ctx, monkeypatch):
+    """65536 columns x 16384 rows as EIGHT row strips (in-process rank group: eight contexts and rank threads, peer transport on a one-GPU box)
+    against the one-strip run: fel, p, sd8, ad8 of the D8 pipeline and ang / dsca of DinfDecayAccum -wg -o (64 outlets, found per strip) are
+    bit-equal - the strip protocol of configs[3] / [4] (full-width rows, eight ranks, src/linearpart.h:133-134,194-219) on the engine that is
+    benchmarked, every sweep under the verifier."""
+    import torch
+
+    import bench
+    import taudem_amd as T
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
+    nx, ny, size, seed = 65536, 16384, 8, 1234
+    wl = T.synth_base_wavelength(max(nx, ny))
+    # ---- one strip: the plain single-GPU entry points ----
+    dem = ctx.synth_dem((ny, nx), seed=seed, base_wavelength=wl)
+    fel1 = ctx.pitremove(dem, -9999.0)
+    del dem
+    p1, sd81, st1 = ctx.d8flowdir(fel1, -3.0e38, 30.0, 30.0, stats=True)
+    ad81 = ctx.aread8(p1, -32768, contcheck=False)
+    one = bench.DecayStrip(torch, ctx, None, nx, ny, 0, ny, seed, T)
+    one.step()
+    torch.cuda.synchronize()
+    ang1, dsca1 = one.ang[1:ny + 1], one.out[1:ny + 1]
+    outlets1 = sorted(zip(one.outlets[0], [r - 1 for r in one.outlets[1]]))
+    parts = partition_rows(ny, size)
+    with StripGroup(size, nx) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            nyl = y1 - y0
+            pipe = StripPipeline(c, comm, nx, nyl)
+            d = pipe.empty(torch.float32)
+            c.synth_dem((nyl, nx), seed=seed, x0=0, y0=y0, base_wavelength=wl, out=d[1:nyl + 1])
+            fel, _ = pipe.pitremove(d, -9999.0)
+            del d
+            p, sd8, s2 = pipe.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+            ad8, _ = pipe.aread8(p, -32768, contcheck=False)
+            torch.cuda.synchronize()
+            ok = {k: bool(torch.equal(a[1:nyl + 1].view(torch.int16 if a.dtype == torch.int16 else torch.int32),
+                                      b[y0:y1].view(torch.int16 if b.dtype == torch.int16 else torch.int32)))
+                  for k, a, b in (("fel", fel, fel1), ("p", p, p1), ("sd8", sd8, sd81), ("ad8", ad8, ad81))}
+            del fel, p, sd8, ad8
+            job = bench.DecayStrip(torch, c, comm, nx, ny, y0, nyl, seed, T)
+            job.step()
+            torch.cuda.synchronize()
+            ok["ang"] = bool(torch.equal(job.ang[1:nyl + 1].view(torch.int32), ang1[y0:y1].view(torch.int32)))
+            ok["dsca"] = bool(torch.equal(job.out[1:nyl + 1].view(torch.int32), dsca1[y0:y1].view(torch.int32)))
+            return ok, [(x, y0 + row - 1) for x, row in zip(*job.outlets)], (s2["levels_fall_max"], s2["levels_rise_max"])
+        res = grp.run(rank_main)
+        assert grp.transport == "peer"
+    for r, (ok, _, _) in enumerate(res):
+        assert all(ok.values()), f"strip {r} of {size} differs from the one-strip run: {ok}"
+    assert sorted(o for _, outl, _ in res for o in outl) == outlets1 and len(outlets1) == 64
+    assert all(lv == (st1["levels_fall_max"], st1["levels_rise_max"]) for _, _, lv in res), "the level statistics are global"
+    assert 0 < st1["levels_fall_max"] < 32766
