@@ -118,14 +118,14 @@ __global__ __launch_bounds__(256) void dinf_reach_mask_kernel(const float* __res
     }
     mask[idx] = uint8_t(m);
 }
-__global__ __launch_bounds__(256) void dinf_reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int y_own0,
+__global__ __launch_bounds__(256) void dinf_reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int ny, int y_own0,
                                                               int y_own1, int tiles_x, int32_t* __restrict__ reach, uint32_t* __restrict__ tile_flags) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= nout) return;
     const int x = ox[o], y = oy[o];
     if (x < 0 || x >= nx || y < y_own0 || y >= y_own1) return;
     reach[size_t(y) * size_t(nx) + size_t(x)] = 1;
-    tile_flags[(y / tilek::TS) * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    tilek::activate_tiles_around(x, y, nx, ny, tiles_x, tile_flags);
 }
 __global__ __launch_bounds__(256) void dinf_apply_reach_kernel(const float* __restrict__ ANG, const int32_t* __restrict__ reach, size_t n, float nodata,
                                                                float* __restrict__ out) {
@@ -832,7 +832,7 @@ int dinf_outlet_recode(tdx_context* ctx, const Strip& st, const float* d_ang, fl
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy, outlet_x, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_oxy + n_outlets, outlet_y, size_t(n_outlets) * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(dinf_reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets), inx,
-                           st.y0, st.y1, geom.tiles_x, reach, flags);
+                           iny, st.y0, st.y1, geom.tiles_x, reach, flags);
     }
     int64_t rr = 0, ll = 0;
     int rc = reach_closure(ctx, st, reach, mask, flags, flags + ntiles, counts, &rr, &ll);

@@ -430,7 +430,7 @@ static __global__ __launch_bounds__(256) void reach_mask_kernel(const int16_t* _
 }
 // outlet cells (array coordinates; only those in the owned rows, and with skip_nodata only those on a cell with a direction
 // value): reach = 1 and their tile is activated
-static __global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int y_own0,
+static __global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* __restrict__ ox, const int32_t* __restrict__ oy, int nout, int nx, int ny, int y_own0,
                                                                 int y_own1, int tiles_x, const int16_t* __restrict__ P, int16_t nodata, int skip_nodata,
                                                                 int32_t* __restrict__ reach, uint32_t* __restrict__ tile_flags) {
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -440,7 +440,7 @@ static __global__ __launch_bounds__(256) void reach_seed_kernel(const int32_t* _
     const size_t idx = size_t(y) * size_t(nx) + size_t(x);
     if (skip_nodata && is_nodata_s(P[idx], nodata)) return;
     reach[idx] = 1;
-    tile_flags[(y / tilek::TS) * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    tilek::activate_tiles_around(x, y, nx, ny, tiles_x, tile_flags);
 }
 
 template <int BYTES> struct BitsOf;

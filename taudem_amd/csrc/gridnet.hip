@@ -281,7 +281,7 @@ int gridnet_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t p_noda
             // skip_nodata = 1: an outlet on a cell without direction is IGNORED.  The reference seeds it (gord = 1) and then indexes d1[] / d2[] with the nodata code
             // (src/gridnet.cpp:285-340): undefined behaviour, no defined result to reproduce - documented in DESIGN.md 4.5, pinned by tests/test_gpu_gridnet.py
             hipLaunchKernelGGL(d8sweep::reach_seed_kernel, dim3(tdx_blocks_for(size_t(n_outlets), 256)), dim3(256), 0, s, d_oxy, d_oxy + n_outlets, int(n_outlets), inx,
-                               st.y0, st.y1, geom.tiles_x, d_p, p_nodata, 1, reach, flags);
+                               iny, st.y0, st.y1, geom.tiles_x, d_p, p_nodata, 1, reach, flags);
         }
         int64_t rr = 0, ll = 0;
         rc = reach_closure(ctx, st, reach, rmask, flags, flags + ntiles, counts, &rr, &ll);

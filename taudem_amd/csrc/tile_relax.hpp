@@ -138,6 +138,20 @@ struct TileLds {   // LDS of one workgroup
 // strip halo ROW inside the tile's area was rewritten by the exchange).
 constexpr uint32_t FLAG_HALO = 1u, FLAG_FULL = 2u;
 
+// A cell that receives its value from OUTSIDE the relaxation (an outlet seed of the upstream closure) is news for every tile that holds one of its
+// 8 neighbours: the relaxation itself only reports cells that MOVE on a rim, so a seed on the first / last row or column of its tile must activate
+// the tiles beside it as well (found in round 4 by oracle/taudem_oracle.c: orc_dinfdecayaccum_check - the catchment above an outlet in the top row
+// of a tile was lost whenever no other rim cell of that tile moved).
+__device__ __forceinline__ void activate_tiles_around(int x, int y, int nx, int ny, int tiles_x, uint32_t* __restrict__ tile_flags) {
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xn = x + dx, yn = y + dy;
+            if (xn >= 0 && xn < nx && yn >= 0 && yn < ny) tile_flags[(yn / TS) * tiles_x + xn / TS] = FLAG_FULL;
+        }
+}
+
 constexpr int RES_CHANGED = 1 << 8;   // some cell of the tile moved (bits 0-7: which rim parts moved: N S W E NW NE SW SE)
 constexpr int RES_CAPPED = 1 << 9;    // stopped at max_sweeps before the tile-local fixed point
 

@@ -132,3 +132,38 @@ def test_outlet_on_a_cell_without_angle(ctx, oracle, monkeypatch):
         want = oracle.dinfconclimaccum(ang, dm, dg, q, csol=1.5, dx=30.0, dy=30.0, contcheck=cc, outlets=(ox, oy))
         got = ctx.dinfconclimaccum(ang, dm, dg, q, csol=1.5, dx=30.0, dy=30.0, contcheck=cc, outlets=(ox, oy))
         assert bits_equal(got, want), describe_diff(got, want, f"ctpt -o on cells without angle, contcheck={cc}")
+
+
+def test_outlets_on_tile_rims(ctx, oracle):
+    """Outlets on the first / last row or column of a 64 x 64 tile whose catchment lies in the NEIGHBOURING tile: the seed of the upstream closure must
+    activate that tile too (the relaxation only reports rim cells that move).  Round 4's host check of configs[4] found whole catchments missing
+    behind such outlets; here every accumulation tool with -o is compared with the restatement, with the outlets on the largest streams that
+    cross a tile rim."""
+    shape = (400, 460)
+    dem = oracle.synth_dem(shape, 41)
+    fel = oracle.pitremove(dem, -9999.0)
+    ang, _, _ = oracle.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    p, _, _ = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    sca = oracle.areadinf(ang, dx=30.0, dy=30.0, contcheck=False)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    rim = ((yy % 64 == 0) | (yy % 64 == 63) | (xx % 64 == 0) | (xx % 64 == 63)) & (yy > 2) & (yy < shape[0] - 3) & (xx > 2) & (xx < shape[1] - 3)
+    order = np.argsort(np.where(rim, sca, -1.0), axis=None)[::-1][:48]
+    ox, oy = (order % shape[1]).astype(np.int32), (order // shape[1]).astype(np.int32)
+    rng = np.random.default_rng(3)
+    w = rng.random(shape, dtype=np.float32)
+    dm = (0.9 + 0.1 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+    for cc in (True, False):
+        want = oracle.areadinf(ang, float(ANG_ND), 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        got = ctx.areadinf(ang, float(ANG_ND), 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"sca -o on tile rims, contcheck={cc}")
+        want = oracle.dinfdecayaccum(ang, dm, float(ANG_ND), -9999.0, 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        got = ctx.dinfdecayaccum(ang, dm, float(ANG_ND), -9999.0, 30.0, 30.0, weights=w, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"dsca -o on tile rims, contcheck={cc}")
+        want = oracle.aread8(p, -32768, contcheck=cc, outlets=(ox, oy))
+        got = ctx.aread8(p, -32768, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"ad8 -o on tile rims, contcheck={cc}")
+        want = oracle.aread8(p, -32768, weights=w, contcheck=cc, outlets=(ox, oy))
+        got = ctx.aread8(p, -32768, weights=w, contcheck=cc, outlets=(ox, oy))
+        assert bits_equal(got, want), describe_diff(got, want, f"ad8 -wg -o on tile rims, contcheck={cc}")
+    for a, b, name in zip(ctx.gridnet(p, -32768, 30.0, 30.0, outlets=(ox, oy)), oracle.gridnet(p, -32768, 30.0, 30.0, outlets=(ox, oy)), ("plen", "tlen", "gord")):
+        assert bits_equal(a, b), describe_diff(a, b, f"gridnet -o on tile rims: {name}")
