@@ -43,6 +43,11 @@ def _p(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
 
 
+def set_threads(n):
+    """Host threads for the restatement's loops with independent iterations (default 1; results do not depend on n)."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def _f64(a, n):
     return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (n,)))
 

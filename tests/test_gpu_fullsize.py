@@ -94,6 +94,22 @@ def _dinf_props(ctx, n, seed, monkeypatch, oracle=None):
         bad, first, flats = oracle.dinf_first_pass_check(fel.cpu().numpy(), ang.cpu().numpy(), slp.cpu().numpy(), dx=30.0, dy=30.0)
         assert bad == 0, f"{bad} cells differ from the first pass of setdir(); first at row {first // n} column {first % n}"
         assert flats == st["flats_initial"], (flats, st["flats_initial"])
+        # EVERY cell of ang / slp - the flat cells' angles included (a third of the raster at 32768^2): the restatement itself, with its flat loops
+        # as breadth-first searches (linear time; pinned to the real reference's rasters and 2048^2 / 4096^2 digests on CPU), run on the host cores
+        import os
+        monkeypatch.setenv("ORC_FLATS", "bfs")
+        oracle.set_threads(os.cpu_count() or 1)
+        try:
+            ang_o, slp_o, st_o = oracle.dinfflowdir(fel.cpu().numpy(), -3.0e38, 30.0, 30.0)
+        finally:
+            oracle.set_threads(1)
+            monkeypatch.delenv("ORC_FLATS")
+        assert (st_o["flats_initial"], st_o["flat_iterations"], st_o["flats_left"]) == (st["flats_initial"], st["flat_iterations"], st["flats_left"])
+        ang_h = ang.cpu().numpy()
+        neq = int(np.count_nonzero(ang_h.view(np.uint32) != ang_o.view(np.uint32)))
+        assert neq == 0, f"ang: {neq} cells differ from the restatement (flat cells included)"
+        assert np.array_equal(slp.cpu().numpy().view(np.uint32), slp_o.view(np.uint32)), "slp differs from the restatement"
+        del ang_o, slp_o, ang_h
         sca_c = ctx.areadinf(ang, dx=30.0, dy=30.0, contcheck=True)      # the tool's default mode
         bad, first = oracle.areadinf_check(ang.cpu().numpy(), sca_c.cpu().numpy(), dx=30.0, dy=30.0, contcheck=True)
         assert bad == 0, f"contcheck: {bad} cells do not follow from area()'s expression; first at row {first // n} column {first % n}"
@@ -164,8 +180,8 @@ def _host_gb():
 def test_dinf_config3_at_32768(ctx, oracle, monkeypatch):
     """BASELINE.json configs[2] at its own size (1.07 G cells, 4 x the tiles and twice the rounds of 16384^2): the properties, the sweep
     verifier, and the linear-time host checks of ang / slp / sca against the restatement's expressions."""
-    if _host_gb() < 48:
-        pytest.skip("needs ~40 GB of host memory for the linear-time checks")
+    if _host_gb() < 96:
+        pytest.skip("needs ~60 GB of host memory for the linear-time checks")
     _dinf_props(ctx, 32768, 1234, monkeypatch, oracle)
 
 

@@ -103,6 +103,31 @@ def test_cpu_large_digests(oracle, n):
     check_digest("ad8", oracle.aread8(p, -32768), R["ad8"])
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_cpu_large_digests_breadth_first_flats(oracle, monkeypatch, n):
+    """CPU: with the flat loops as breadth-first searches (ORC_FLATS=bfs, a few host threads) the restatement reproduces the REAL reference's
+    digests of p, sd8, ang and slp at 2048^2 and 4096^2 - millions of flat cells, thousands of levels, three flat iterations - in seconds.  This is
+    the form tests/test_gpu_fullsize.py uses to pin EVERY cell of ang at 32768^2."""
+    cases = _load(LARGE)
+    if str(n) not in cases:
+        pytest.skip("no reference digests")
+    case = cases[str(n)]
+    R = case["rasters"]
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    oracle.set_threads(min(8, os.cpu_count() or 1))
+    try:
+        fel = oracle.pitremove(oracle.synth_dem(n, case["seed"]), case["nodata"])
+        check_digest("fel", fel, R["fel"])
+        p, sd8, _ = oracle.d8flowdir(fel, -3.0e38, case["dx"], case["dy"])
+        ang, slp, _ = oracle.dinfflowdir(fel, -3.0e38, case["dx"], case["dy"])
+    finally:
+        oracle.set_threads(1)
+    check_digest("p", p, R["p"])
+    check_digest("sd8", sd8, R["sd8"])
+    check_digest("ang", ang, R["ang"])
+    check_digest("slp", slp, R["slp"])
+
+
 @pytest.mark.gpu
 @pytest.mark.slow
 def test_reference_digests_through_three_strips(ctx, tmp_path):

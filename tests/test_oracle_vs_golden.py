@@ -43,6 +43,24 @@ def test_flat_resolution_literal_loops(g, oracle, monkeypatch):
     assert bits_equal(slp, g["slp"]), describe_diff(slp, g["slp"], "slp (literal loops)")
 
 
+@pytest.mark.parametrize("threads", [1, 5])
+def test_flat_resolution_breadth_first_form(g, oracle, monkeypatch, threads):
+    """ORC_FLATS=bfs: the two flat loops as breadth-first searches (oracle/taudem_oracle.c: bfs_incfall / bfs_incrise - linear in the number of
+    flat cells, what makes the restatement a checker at 32768^2) give the REAL reference's p / sd8 / ang / slp like the literal and the
+    active-list forms, with one host thread and with several (the threaded loops write disjoint cells)."""
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    oracle.set_threads(threads)
+    try:
+        p, sd8, _ = oracle.d8flowdir(g["fel"], -3.0e38, g["dxc"], g["dyc"])
+        ang, slp, _ = oracle.dinfflowdir(g["fel"], -3.0e38, g["dxc"], g["dyc"])
+    finally:
+        oracle.set_threads(1)
+    assert bits_equal(p, g["p"]), describe_diff(p, g["p"], "p (bfs)")
+    assert bits_equal(sd8, g["sd8"]), describe_diff(sd8, g["sd8"], "sd8 (bfs)")
+    assert bits_equal(ang, g["ang"]), describe_diff(ang, g["ang"], "ang (bfs)")
+    assert bits_equal(slp, g["slp"]), describe_diff(slp, g["slp"], "slp (bfs)")
+
+
 @pytest.mark.parametrize("key,kw", [("ad8", {}), ("ad8_nc", {"contcheck": False}), ("ad8_w", {"w": True}), ("ad8_w_nc", {"w": True, "contcheck": False}),
                                     ("ad8_outlets", {"o": True}), ("ad8_outlets_nc", {"o": True, "contcheck": False})])
 def test_aread8(g, oracle, key, kw):
