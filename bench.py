@@ -21,6 +21,7 @@ Beside the pipeline, the N = 1 line carries (outside the timed region, one step 
   config4_strip  BASELINE.json configs[3] as ONE GPU sees it: the pipeline on a 65536 x 8192 strip (no neighbours)
   config5_strip  BASELINE.json configs[4] as ONE GPU sees it: DinfDecayAccum with weights, decay multipliers and 64 outlets on a
                  65536 x 8192 strip
+  flowalg_16384  GridNet, weighted AreaD8, AreaDinf, DinfUpDependence, DinfRevAccum at 16384 x 16384 (ms per call)
 and `--workload decay` times configs[4] itself: DinfDecayAccum -wg -o on ONE raster of 65536 columns x 8192*N rows in row strips
 (the D-infinity angles come from PitRemove -> DinfFlowDir on the same strips, outside the timed region).
 `--in-process` (N > 1): the N strips are N rank threads of THIS process on the library's own rank group (tdx_group: RCCL when every
@@ -42,11 +43,18 @@ BYTES_PER_CELL = {"pitremove": 8, "d8flowdir": 10, "aread8": 6}
 KCLASS_STAGE = {"relax": "pitremove", "bfs": "d8flowdir", "flatdir": "d8flowdir", "accum": "aread8"}
 
 
+# FETCH_SIZE correction per kernel, CALIBRATED on scripts/micro/tilebw.hip's known byte counts (profiles/r04a_pmc_tilebw_*_summary.json, round 4): the counter
+# tallies every request at 64 B - a wave row of 4-byte lanes (two 128-B requests) reads as half its bytes (factor 2.0: k4<0>, 2 147 MB read, 1 074 MB counted),
+# a row of uint8 lanes (one 64-B request) as all of them, the level fields' mix of one int16 and one uint8 per lane and row as two thirds (factor 1.5: k16,
+# 805 MB read, 537 MB counted).  WRITE_SIZE matched the bytes written (factor 1.0).
+FETCH_FACTOR = {"LevelOp": 1.5, "PitOp": 2.0, "ad8_tile": 2.0}
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries of this same command: the newest
-    profiles/rNN?_pmc_{fetch,write}_summary.json pair (scripts/gpu_r02_profile.sh + scripts/pmc_summary.py; round 1's pair has no
-    prefix).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
-    (MI355X_MICROARCH.md, HBM): it is doubled here.  Returns (bytes, note) or (None, reason)."""
+    profiles/rNN?_pmc_{fetch,write}_summary.json pair (scripts/gpu_r04_profile.sh + scripts/pmc_summary.py; round 1's pair has no
+    prefix).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is corrected with the factor calibrated for the kernel's access width
+    (FETCH_FACTOR above; MI355X_MICROARCH.md's factor 2 holds for 128-B requests only).  Returns (bytes, note) or (None, reason)."""
     import glob
 
     try:
@@ -59,9 +67,11 @@ def pmc_traffic(kernel_substr):
         wk = [k for k in w if kernel_substr in k]
         if not fk or not wk:
             return None, "kernel not in the PMC summaries"
-        fetch = f[fk[0]]["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * 2.0
+        factor = FETCH_FACTOR.get(kernel_substr, 2.0)
+        fetch = f[fk[0]]["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * factor
         write = w[wk[0]]["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
-        return fetch + write, f"profiles/{os.path.basename(ffile)} + {os.path.basename(wfile)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
+        return fetch + write, (f"profiles/{os.path.basename(ffile)} + {os.path.basename(wfile)}: ({factor}*FETCH_SIZE + WRITE_SIZE) KiB per dispatch; factor calibrated "
+                               "on scripts/micro/tilebw.hip (profiles/r04a_pmc_tilebw_fetch_summary.json)")
     except Exception as e:  # no summaries committed
         return None, f"no PMC summary ({e.__class__.__name__})"
 
@@ -290,8 +300,36 @@ def config4_strip_leg(torch, ctx, seed, T):
     cells = float(nx) * ny
     return {"workload": f"{nx}x{ny} strip (rows 0..8191 of the 65536x65536 synthetic DEM, seed {seed}): PitRemove->D8FlowDir->AreaD8 in HBM on one GPU, no neighbours",
             "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "stage_ms": {"pitremove": s1["ms_total"], "d8flowdir": s2["ms_total"], "aread8": s3["ms_total"]},
-            "flats_initial": s2["flats_initial"], "levels_fall": s2["levels_fall"], "pit_rounds": s1["rounds"],
+            "flats_initial": s2["flats_initial"], "levels_fall": s2["levels_fall"], "max_level_per_iteration": {"fall": s2["levels_fall_max"], "rise": s2["levels_rise_max"], "int16_limit": 32766}, "pit_rounds": s1["rounds"],
             "note": "8 such strips = configs[3]; their exchange / all-reduce counts per stage: profiles/r03c_8strips_65536_d8.json"}
+
+
+def flowalg_leg(torch, ctx, seed):
+    """The accumulation tools beside the headline path at 16384^2, one call each after a warm-up call, library-side HIP-event
+    time of the call: GridNet, weighted AreaD8, AreaDinf, DinfUpDependence, DinfRevAccum - so that the dependency sweeps' targets are under the driver's clock."""
+    n = 16384
+    dem = ctx.synth_dem(n, seed=seed)
+    fel = ctx.pitremove(dem, -9999.0)
+    del dem
+    p, _ = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, want_slope=False)
+    ang, slp = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    del fel, slp
+    g = torch.Generator(device=p.device).manual_seed(7)
+    w = torch.rand((n, n), device=p.device, dtype=torch.float32, generator=g)
+    dg32 = (torch.rand((n, n), device=p.device, generator=g) < 0.01).to(torch.int32)
+    ms = {}
+
+    def timed(name, fn):
+        fn()
+        torch.cuda.synchronize()
+        ms[name] = fn()[-1]["ms_total"]
+    timed("gridnet", lambda: ctx.gridnet(p, -32768, 30.0, 30.0, stats=True))
+    timed("aread8_weighted", lambda: ctx.aread8(p, weights=w, stats=True))
+    timed("areadinf", lambda: ctx.areadinf(ang, dx=30.0, dy=30.0, stats=True))
+    timed("dinfupdependence", lambda: ctx.dinfupdependence(ang, dg32, dx=30.0, dy=30.0, stats=True))
+    timed("dinfrevaccum", lambda: ctx.dinfrevaccum(ang, w, dx=30.0, dy=30.0, stats=True))
+    return {"workload": f"{n}x{n} synthetic fractal DEM (seed {seed}, pit-filled), D8 / D-infinity directions from the library, random weights / indicator grid in HBM; "
+                        "ms per call (one call after a warm-up call)", "ms": ms}
 
 
 def decay_line(world, nx, ny, args, ms_per_step, st, comm_info, job_cells_evaluated, functional):
@@ -361,13 +399,17 @@ def run_in_process(args):
                     c3 = counters(c)
                     marks.append([(b[0] - a[0], b[1] - a[1]) for a, b in ((c0, c1), (c1, c2), (c2, c3))])
                     return s1, s2, s3
-            for _ in range(args.warmup):
-                step()
-            bar.wait(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                st = step()
-            torch.cuda.synchronize(); bar.wait()
+            try:
+                for _ in range(args.warmup):
+                    step()
+                bar.wait(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    st = step()
+                torch.cuda.synchronize(); bar.wait()
+            except BaseException:
+                bar.abort()     # a rank that fails must not leave the others at the timing barrier
+                raise
             res["elapsed"] = time.perf_counter() - t0
             res["stats"] = st
             if args.workload == "decay":
@@ -407,7 +449,8 @@ def run_in_process(args):
                          "exchanges_per_step": {"pitremove": last[0][0], "d8flowdir": last[1][0], "aread8": last[2][0]},
                          "allreduces_per_step": {"pitremove": last[0][1], "d8flowdir": last[1][1], "aread8": last[2][1]}},
                 "checks": {"ad8_cells_evaluated": evaluated, "cells_with_direction": valid, "every_directed_cell_evaluated": evaluated == valid,
-                           "ad8_max": max(r["ad8_max"] for r in res)}}
+                           "ad8_max": max(r["ad8_max"] for r in res)},
+                "max_level_per_iteration": {"fall": s2["levels_fall_max"], "rise": s2["levels_rise_max"], "int16_limit": 32766, "flat_iterations": s2["flat_iterations"]}}
         if functional:
             line["functional_only"] = "ranks share GPUs: a check of the strip protocol at this size, not a throughput figure"
     print(json.dumps(line), flush=True)
@@ -630,7 +673,7 @@ def main():
             "roofline_streaming_stencil": {"kernel": "d8_slope_kernel", "algorithmic_bytes_per_cell": 10, "avg_launch_ms": slope_ms,
                                            "achieved": slope_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": slope_gbs / HBM_PEAK_GBS},
             "flats": {"initial": acc[1]["flats_initial"], "left": acc[1]["flats_left"], "iterations": acc[1]["flat_iterations"],
-                      "levels_fall": acc[1]["levels_fall"], "levels_rise": acc[1]["levels_rise"], "pit_rounds": acc[0]["rounds"],
+                      "levels_fall": acc[1]["levels_fall"], "levels_rise": acc[1]["levels_rise"], "max_level_per_iteration": {"fall": acc[1]["levels_fall_max"], "rise": acc[1]["levels_rise_max"], "int16_limit": 32766}, "pit_rounds": acc[0]["rounds"],
                       "ad8_big_cells": acc[2]["cells_evaluated"], "ad8_outer_rounds": acc[2]["rounds"]},
         }
         if comm is not None:
@@ -646,7 +689,7 @@ def main():
             del dem, fel, p, sd8, ad8
             torch.cuda.empty_cache()
             for key, leg in (("config3", lambda: config3_leg(torch, ctx, args.seed)), ("config4_strip", lambda: config4_strip_leg(torch, ctx, args.seed, T)),
-                             ("config5_strip", lambda: config5_strip_leg(torch, ctx, args.seed, T))):
+                             ("config5_strip", lambda: config5_strip_leg(torch, ctx, args.seed, T)), ("flowalg_16384", lambda: flowalg_leg(torch, ctx, args.seed))):
                 try:
                     out[key] = leg()
                 except Exception as e:   # noqa: BLE001

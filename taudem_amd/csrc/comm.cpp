@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -85,7 +86,12 @@ public:
         if (aborted_) return false;
         const unsigned gen = gen_;
         if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); return true; }
-        return cv_.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen_ != gen || aborted_; }) && !aborted_;
+        if (cv_.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen_ != gen || aborted_; }) && !aborted_) return true;
+        // timed out (or aborted): the generation can no longer complete with everybody on board - a rank that arrives late must not pass
+        // with one participant missing, and whoever waits now or later fails at once instead of sitting out its own limit
+        aborted_ = true;
+        cv_.notify_all();
+        return false;
     }
     // a rank has failed: everybody waiting here, now or later, gets `false` at once instead of waiting for a rank that will not come
     void abort() {
@@ -107,7 +113,8 @@ constexpr int RED_MAX = 16;
 
 struct tdx_rccl_comm {
     tdx_context* ctx = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;   // guarded by `use`: null after an abort
+    std::mutex use;              // held around every host-side RCCL call on `comm` (they only enqueue) and around its abort
     tdx_comm c{};
     char* bufs = nullptr;        // 4 x capacity bytes of device memory: send_up send_down recv_up recv_down
     int64_t* d_red = nullptr;    // RED_MAX device words for host-value votes
@@ -123,6 +130,8 @@ int rccl_exchange(void* user, uint64_t bytes) {
     const int rank = r->c.rank, size = r->c.size;
     hipStream_t s = r->ctx->stream;
     r->exchanges++;
+    std::lock_guard<std::mutex> lk(r->use);   // tdx_group_abort (another rank's thread) must not free the communicator under these calls
+    if (!r->comm) { g_tdx_thread_error = "rank " + std::to_string(rank) + " of " + std::to_string(size) + ": the rank group was aborted"; return 1; }
     TDX_NCCL(a.GroupStart());
     // inside the group the first failure is remembered and the group is ALWAYS closed: a thread that returned between GroupStart
     // and GroupEnd would queue every later RCCL call (the communicator's destruction included) into a group that never ends
@@ -148,6 +157,8 @@ int rccl_exchange(void* user, uint64_t bytes) {
 int rccl_allreduce_dev(void* user, int64_t* d_values, int32_t count, int32_t op) {
     tdx_rccl_comm* r = static_cast<tdx_rccl_comm*>(user);
     r->allreduces++;
+    std::lock_guard<std::mutex> lk(r->use);
+    if (!r->comm) { g_tdx_thread_error = "rank " + std::to_string(r->c.rank) + " of " + std::to_string(r->c.size) + ": the rank group was aborted"; return 1; }
     TDX_NCCL(rccl().AllReduce(d_values, d_values, size_t(count), ncclInt64, op == TDX_OP_MAX ? ncclMax : ncclSum, r->comm, r->ctx->stream));
     return 0;
 }
@@ -264,6 +275,7 @@ struct tdx_group {
     std::vector<PeerRank> pr;             // "peer"
     HostBarrier* bar = nullptr;
     std::vector<int64_t> red;             // size x RED_MAX vote slots
+    std::atomic<bool> aborted{false};
 };
 
 namespace {
@@ -382,9 +394,18 @@ extern "C" const char* tdx_group_transport(const tdx_group* g) { return g ? g->t
 // end in an error instead of waiting for a partner.  The group can only be destroyed afterwards.
 extern "C" void tdx_group_abort(tdx_group* g) {
     if (!g) return;
+    if (g->aborted.exchange(true)) return;   // one shot: every failing rank thread calls this, the first one does the work
     if (g->bar) g->bar->abort();
-    for (tdx_rccl_comm* r : g->rc)
-        if (r && r->comm) { rccl().CommAbort(r->comm); r->comm = nullptr; }
+    for (tdx_rccl_comm* r : g->rc) {
+        if (!r) continue;
+        ncclComm_t c = nullptr;
+        {   // take the communicator away under its lock: a rank thread is either before its calls (and will find null) or past them
+            std::lock_guard<std::mutex> lk(r->use);
+            c = r->comm;
+            r->comm = nullptr;
+        }
+        if (c) rccl().CommAbort(c);          // ends what is enqueued on the rank's stream; nobody holds `c` any more
+    }
 }
 extern "C" void tdx_group_destroy(tdx_group* g) {
     if (!g) return;

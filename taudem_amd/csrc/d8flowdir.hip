@@ -545,6 +545,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
         const int64_t total0 = total;
         bool sparse = false;                // this iteration works from lists (few flats left): no pass over the whole raster
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
+        bool old_list_valid = false;        // ... and whether qnext really holds them
         for (;;) {
             // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
             FlatLevels fl;
@@ -556,7 +557,8 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                                    rmask, tile_flags, tile_masked);
             };
             if (sparse) {
-                rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq);
+                // the previous queue exists as a list only if it was built (first queue of a dense strip: bit masks only) - without one every marker is rewritten
+                rc = old_list_valid ? flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq) : flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
                 if (rc != TDX_OK) return rc;
             }
             // (the first queue of a dense strip exists as bit masks only: no list)
@@ -598,6 +600,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             rc = sparse ? flats_overwrite_elevation_sparse(ctx, inx, qnext, nleft, lvl, rq, fl, zwork) : flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);
             if (rc != TDX_OK) return rc;
             zcur = zwork;
+            old_list_valid = nq_old != 0 || have_list;   // (the list this iteration worked from: every queue after the first is a list)
             nq_old = nq;
             std::swap(qlist, qnext);
             nq = nleft;

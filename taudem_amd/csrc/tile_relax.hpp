@@ -774,6 +774,9 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
             int tile = fixed ? int(entry0) : int(L.pulled[it - first]);
             bool full = flags_cur[tile] >= FLAG_FULL;
             int res;
+            // REQUIREMENT of the hand-over below: while a schedule is in a solo round NOTHING else reads or writes the field it relaxes - true for every
+            // caller (one field per schedule; the pair / fused runs of flats.hpp drive two DIFFERENT fields, the dependency sweeps own their work array).
+            // A caller that shares a field between two concurrent schedules must switch it off (TileGeom::chain_max = 0).
             // A SOLO round (one active tile in the whole raster: the tail of every dependency sweep is one chain of such rounds, the
             // longest flow path crossing one tile per round) hands over inside the launch: while an activation activates exactly one
             // tile, this workgroup - the only one running - goes on into it, instead of a list append, the end of the kernel, the next
@@ -1261,8 +1264,8 @@ static int tile_relax_run_fused(tdx_context* ctx, Op opA, tilek::Sched scA, Op o
         if (rc != TDX_OK) return rc;
         rc = A.wait_oldest();
         if (rc != TDX_OK) return rc;
-        A.collect();
-        B.collect();
+        if (!A.done) A.collect(); else A.n_col++;   // (a schedule that has ended has written no counts: its slot is only stepped over)
+        if (!B.done) B.collect(); else B.n_col++;
     }
     if (rounds_out) *rounds_out += A.rounds + B.rounds;
     if (launches_out) *launches_out += A.launches;

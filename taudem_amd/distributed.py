@@ -212,9 +212,11 @@ class StripGroup:
         def main(r):
             try:
                 out[r] = fn(r, self.contexts[r], self.comms[r])
-            except BaseException as e:   # noqa: BLE001 - reported below; the other ranks would wait for this one forever
+            except BaseException as e:   # noqa: BLE001 - reported below
                 import traceback
                 err.append((r, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+                # the other ranks must not sit in their collectives until TDX_COMM_TIMEOUT: pending and future waits fail at once
+                self._lib.tdx_group_abort(self._g)
 
         th = [threading.Thread(target=main, args=(r,), daemon=True) for r in range(self.size)]
         for t in th:
