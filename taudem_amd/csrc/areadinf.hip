@@ -437,6 +437,17 @@ __device__ __forceinline__ unsigned pending_bits(const Nbr8& nb) {
 }
 
 struct AreaEval {   // src/areadinf.cpp:187-217
+    // the same expression contributor by contributor (the walks fold the contributors that exist, in k order: eval_walk in dinf_sweep_tile.inc)
+    __device__ __forceinline__ float begin(float, double, bool) const { return 0.f; }
+    __device__ __forceinline__ void fold(float& areares, bool& con, float v, double p, float) const {
+        if (is_nodata_f(v, TDX_AREA_NODATA)) con = true;
+        else areares = (float)(areares + p * v);
+    }
+    __device__ __forceinline__ float end(float areares, bool con, float w, double dx, bool has_w, int contcheck) const {
+        if (has_w) areares = areares + w;
+        else areares = (float)(areares + dx);
+        return (con && contcheck == 1) ? TDX_AREA_NODATA : areares;
+    }
     __device__ __forceinline__ float eval(const Nbr8& nb, float w, double dx, unsigned inf, int contcheck, bool has_w) const {
         float areares = 0.f;
         bool con = (inf & 0x100u) != 0u;
@@ -455,6 +466,12 @@ struct AreaEval {   // src/areadinf.cpp:187-217
 };
 struct DecayEval {   // src/dinfdecayaccum.cpp:213-245
     float dm_nodata;
+    __device__ __forceinline__ float begin(float w, double dx, bool has_w) const { return has_w ? w : (float)dx; }
+    __device__ __forceinline__ void fold(float& acc, bool& con, float area, double p, float dm) const {
+        if (is_nodata_f(area, TDX_ANG_NODATA) || is_nodata_f(dm, dm_nodata)) con = true;
+        else acc = acc + (float)(dm * area * p);   // (dm*area) in float, times p in double
+    }
+    __device__ __forceinline__ float end(float acc, bool con, float, double, bool, int contcheck) const { return (con && contcheck == 1) ? TDX_ANG_NODATA : acc; }
     __device__ __forceinline__ float eval(const Nbr8& nb, float w, double dx, unsigned inf, int contcheck, bool has_w) const {
         float acc = has_w ? w : (float)dx;
         bool con = (inf & 0x100u) != 0u;
@@ -620,9 +637,13 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         TdxSpan sp(ctx, TDX_K_ACCUM);
         // two tile geometries over the same arrays (the state of the sweep is the result raster alone): 32 x 32 tiles for the bulk
         // rounds, 64 x 64 tiles for the tail (dinf_sweep_tile.inc)
-        const tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
+        geom.max_sweeps = dsweep64::BULK_SWEEPS;
         tilek::TileGeom geom32 = geom;
         geom32.tiles_x = (inx + 31) / 32; geom32.tiles_y = (iny + 31) / 32;
+        // lockstep sweeps of a fresh tile before the walks take over (dinf_sweep_tile.inc)
+        static const int bulk_sweeps = getenv("TDX_DINF_BULK_SWEEPS") ? std::max(0, atoi(getenv("TDX_DINF_BULK_SWEEPS"))) : dsweep32::BULK_SWEEPS;
+        geom32.max_sweeps = bulk_sweeps;
         const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y), ntiles32 = size_t(geom32.tiles_x) * size_t(geom32.tiles_y);
         uint32_t* flags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntiles * 4 * (1 + tilek::SCHED_LIST_WORDS)));
         uint32_t* flags32 = static_cast<uint32_t*>(ctx->scratch(TDX_S_G, ntiles32 * 4 * (1 + tilek::SCHED_LIST_WORDS)));

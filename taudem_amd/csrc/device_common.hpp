@@ -24,6 +24,10 @@ __device__ __forceinline__ bool is_nodata_f(float v, float nodata) { return fabs
 // linearpart<short>::isNodata: (float)(short-short) is an exact integer, so the test is equality
 __device__ __forceinline__ bool is_nodata_s(int16_t v, int16_t nodata) { return v == nodata; }
 
+// workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations, NOT for its global loads / stores (which
+// __syncthreads(), a workgroup-scope release + acquire, does)
+__device__ __forceinline__ void tdx_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 
 // Wave-aggregated append: every lane with `pred` gets a unique slot in `list` (order within a

@@ -167,3 +167,23 @@ def test_outlets_on_tile_rims(ctx, oracle):
         assert bits_equal(got, want), describe_diff(got, want, f"ad8 -wg -o on tile rims, contcheck={cc}")
     for a, b, name in zip(ctx.gridnet(p, -32768, 30.0, 30.0, outlets=(ox, oy)), oracle.gridnet(p, -32768, 30.0, 30.0, outlets=(ox, oy)), ("plen", "tlen", "gord")):
         assert bits_equal(a, b), describe_diff(a, b, f"gridnet -o on tile rims: {name}")
+
+
+def test_ramps_along_the_facet_diagonals(ctx, oracle):
+    """Planar ramps whose gradient points exactly along a facet's diagonal edge with dx != dy: S2 / S1 == D2 / D1, so VSLOPE's branch `A > AD`
+    (src/dinf.cpp:299-311) compares two equal angles.  The device decides that branch by the cross product S2 * D1 vs S1 * D2 and, inside a 1e-9
+    band around equality, by the rounded angles themselves (dinfflowdir.hip: vslope_s) - these rasters land in the band on every cell, in every
+    facet orientation, for power-of-two and other scales."""
+    dx, dy = 30.0, 25.0
+    n = 96
+    jj, ii = np.mgrid[0:n, 0:n].astype(np.float64)
+    for t in (2.0 ** -10, 3.0 * 2.0 ** -12, 5.0 * 2.0 ** -9):
+        for sx in (1.0, -1.0):
+            for sy in (1.0, -1.0):
+                # z falls by dx^2 t per column towards sx and by dy^2 t per row towards sy: the steepest descent runs along the cell diagonal
+                z = (1000.0 - sx * ii * dx * dx * t - sy * jj * dy * dy * t).astype(np.float32)
+                assert np.array_equal(z.astype(np.float64), 1000.0 - sx * ii * dx * dx * t - sy * jj * dy * dy * t), "the ramp must be exact in float32"
+                ang_o, slp_o, _ = oracle.dinfflowdir(z, -3.0e38, dx, dy)
+                ang, slp = ctx.dinfflowdir(z, -3.0e38, dx, dy)
+                assert bits_equal(slp, slp_o), describe_diff(slp, slp_o, f"slp on the diagonal ramp t={t} sx={sx} sy={sy}")
+                assert bits_equal(ang, ang_o), describe_diff(ang, ang_o, f"ang on the diagonal ramp t={t} sx={sx} sy={sy}")
