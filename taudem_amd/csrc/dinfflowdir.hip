@@ -60,6 +60,13 @@ __device__ __forceinline__ void facet_geom(const RowGeom& g, int K, double& D1, 
     AD = one ? g.ad12 : g.ad21;
 }
 
+// value number i of four (a run-time index into a register array would go through scratch memory)
+template <class T>
+__device__ __forceinline__ T sel4(int i, T a0, T a1, T a2, T a3) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+// the cells of facet K (src/dinf.cpp:328-335): E1 is the cardinal neighbour E N N W W S S E, E2 the diagonal one NE NE NW NW SW SW SE SE
+__device__ __forceinline__ int facet_cardinal(int K) { return (K & 7) >> 1; }   // 0 E, 1 N, 2 W, 3 S
+__device__ __forceinline__ int facet_diagonal(int K) { return (K - 1) >> 1; }   // 0 NE, 1 NW, 2 SW, 3 SE
+
 // VSLOPE's slope without its atan2.  Which of the three branches a facet takes is a question about the SIGN of S2 and about
 // atan2(S2, S1) > atan2(D2, D1), i.e. S2 * D1 > S1 * D2 for positive S1 - decided exactly by that product unless the two sides
 // agree to nine digits, where the rounded atan2 values themselves decide as in the reference.  The angle is needed for the
@@ -89,6 +96,10 @@ __device__ __forceinline__ double vslope_s(double E0, double E1, double E2, doub
 // setPosDirDinf + SET2 + VSLOPE as a streaming 3x3 stencil: a 256-thread block covers 64 x 64 cells, a lane walks a 16-row
 // column segment with the window in registers (3 coalesced row loads per output row).  Facets whose two corners are both not
 // lower than the centre cannot exceed SMAX = 0 and are skipped before any division.
+// (Round 4: SQ_WAIT_INST_ANY is 45 % of this kernel's wave cycles - its 16 x 8 unrolled facet bodies are 270 KB of code - yet both compact forms, the row
+// loop alone rolled up (17 KB, 123 VGPRs) and rows and facets rolled up (7 KB, 119 VGPRs), run SLOWER: 7.3 / 7.2 instead of 6.05 ms at 16384^2; held to
+// the unrolled form's 76 VGPRs they spill 41 registers.  Six waves per SIMD hide the fetch stalls better than four waves avoid them.  The list kernel
+// dinf_set2flat_kernel is the opposite case and uses the run-time facet loop.)
 constexpr int DSLOPE_ROWS = 16;
 __global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                          const RowGeom* __restrict__ geom, float* __restrict__ ANG,
@@ -237,44 +248,31 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
     bool diagOutFound = false, done = false;
     const double a = (double)zw[4];
     const int a1 = e2w[4];
-#pragma unroll
-    for (int K = 1; K <= 8; K++) {
-        if (done) continue;
-        constexpr int dummy = 0; (void)dummy;
-        const int i1 = (fI1(K) + 1) * 3 + fJ1(K) + 1, i2 = (fI2(K) + 1) * 3 + fJ2(K) + 1;
-        const bool in1 = rw[i1] > 0, in2 = rw[i2] > 0;   // dn > 0
-        double D1, D2, AD;
+    // One facet body with run-time K (not eight unrolled ones with four inlined VSLOPEs each: 70 KB of code, 63 % of the wave cycles waiting for
+    // instruction fetch): the four cases of src/dinf.cpp:399-500 differ in WHICH three numbers go into VSLOPE and in how its result is taken.
+#pragma unroll 1
+    for (int K = 1; K <= 8 && !done; K++) {
+        const int j1 = facet_cardinal(K), j2 = facet_diagonal(K);
+        const float zb = sel4(j1, zw[5], zw[1], zw[3], zw[7]), zc = sel4(j2, zw[2], zw[0], zw[6], zw[8]);
+        const bool in1 = sel4(j1, rw[5], rw[1], rw[3], rw[7]) > 0, in2 = sel4(j2, rw[2], rw[0], rw[6], rw[8]) > 0;   // dn > 0
+        const int l1 = sel4(j1, e2w[5], e2w[1], e2w[3], e2w[7]), l2 = sel4(j2, e2w[2], e2w[0], e2w[6], e2w[8]);
+        const double b = (double)zb, cc = (double)zc;
+        if (!in1 && in2 && a >= b) { KD = K; KINDW = 0; done = true; continue; }                         // ANGLE[K] = 0
+        if (in1 && !in2 && a >= cc) { if (!diagOutFound) { KD = K; KINDW = 1; diagOutFound = true; } continue; }   // ANGLE[K] = atan2(DXX[ID2], DXX[ID1]) = AD
+        const bool real = !in1 && !in2;          // both corners outside the marked flat: the real elevations; else the artificial surface
+        const double E0 = real ? a : (double)a1;
+        const double E1 = real ? b : (double)(in1 ? l1 : (a1 > l2 ? a1 : l2));
+        const double E2 = real ? cc : (double)(in2 ? l2 : (a1 > l1 ? a1 : l1));
+        double D1, D2, AD, sa, sb;
         facet_geom(g, K, D1, D2, AD);
         int kind;
-        double sa, sb;
-        if (!in1 && !in2) {
-            const double b = (double)zw[i1], cc = (double)zw[i2];
-            const double S = vslope_s(a, b, cc, D1, D2, g.dd, AD, &kind, &sa, &sb);
+        const double S = vslope_s(E0, E1, E2, D1, D2, g.dd, AD, &kind, &sa, &sb);
+        if (real) {
             if (S >= 0.0) {
                 if (b > a) { if (!diagOutFound) { diagOutFound = true; KD = K; KINDW = kind; S1W = sa; S2W = sb; } }
                 else { KD = K; KINDW = kind; S1W = sa; S2W = sb; done = true; }
             }
-        } else if (!in1 && in2) {
-            const double b = (double)zw[i1];
-            if (a >= b) { KD = K; KINDW = 0; done = true; }                       // ANGLE[K] = 0
-            else {
-                const int c1 = e2w[i2], b1 = a1 > c1 ? a1 : c1;
-                const double S = vslope_s((double)a1, (double)b1, (double)c1, D1, D2, g.dd, AD, &kind, &sa, &sb);
-                if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
-            }
-        } else if (in1 && !in2) {
-            const double cc = (double)zw[i2];
-            if (a >= cc) {
-                if (!diagOutFound) { KD = K; KINDW = 1; diagOutFound = true; }     // ANGLE[K] = atan2(DXX[ID2], DXX[ID1]) = AD
-            } else {
-                const int b1 = e2w[i1], c1 = a1 > b1 ? a1 : b1;
-                const double S = vslope_s((double)a1, (double)b1, (double)c1, D1, D2, g.dd, AD, &kind, &sa, &sb);
-                if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
-            }
-        } else {
-            const double S = vslope_s((double)a1, (double)e2w[i1], (double)e2w[i2], D1, D2, g.dd, AD, &kind, &sa, &sb);
-            if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
-        }
+        } else if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
     }
     float ang = ang0;
     if (!is_nodata_f(ang, TDX_ANG_NODATA)) ang = -1.f;
