@@ -86,6 +86,8 @@ int main(int argc, char** argv) {
             CK(tdx_d8flowdir_dev(g_ctx, fel, nx, ny, TDX_FEL_NODATA, dxc.data(), dyc.data(), p, sd8, &s2));
             CK(tdx_aread8_dev(g_ctx, p, nx, ny, TDX_P_NODATA, nullptr, -9999.0f, 1, nullptr, nullptr, -1, ad8, &s3));
         };
+        if (getenv("TDXBENCH_ADDR"))   // where the rasters landed (process-to-process timing differences of the streaming kernels: DESIGN.md 4.1)
+            fprintf(stderr, "tdxbench: dem %p fel %p p %p sd8 %p ad8 %p\n", (void*)dem, (void*)fel, (void*)p, (void*)sd8, (void*)ad8);
         for (int i = 0; i < warmup; i++) step();
         CK(tdx_synchronize(g_ctx));
         const double t0 = now_ms();
