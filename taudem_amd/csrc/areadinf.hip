@@ -683,8 +683,8 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
             RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
             if (small) { run.grid_full = unsigned(std::min(run.ntiles, 16 * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
-            run.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
-                                    unsigned pull_max) { launch(small, gg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
+            run.custom_launch = [&](const tilek::TileGeom& rg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext,
+                                    uint32_t* lnext, unsigned pull_max) { launch(small, rg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
             run.print_counts = dbg_rounds;
             if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%d tiles of %d):", run.ntiles, small ? 32 : 64);
             if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));

@@ -600,10 +600,10 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
     auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
         RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
         if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
-        runner.custom_launch = [&](unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext, uint32_t* lnext,
-                                   unsigned pull_max) {
-            if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32, Alg::kMinWaves32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
-            else hipLaunchKernelGGL((sweep_kernel<Alg, 64>), dim3(grid), dim3(Dim<64>::NT), 0, ls, alg, gg, list, count, fcur, fnext, lnext, pull_max, A);
+        runner.custom_launch = [&](const tilek::TileGeom& rg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext,
+                                   uint32_t* lnext, unsigned pull_max) {
+            if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32, Alg::kMinWaves32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, rg, list, count, fcur, fnext, lnext, pull_max, A);
+            else hipLaunchKernelGGL((sweep_kernel<Alg, 64>), dim3(grid), dim3(Dim<64>::NT), 0, ls, alg, rg, list, count, fcur, fnext, lnext, pull_max, A);
         };
         int rcl = runner.start();
         if (rcl != TDX_OK) return rcl;

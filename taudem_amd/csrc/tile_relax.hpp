@@ -23,6 +23,7 @@
 // cells out.  Critical path: (longest dependency path measured in tiles) rounds x one launch.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <type_traits>
@@ -49,6 +50,11 @@ struct TileGeom {
     int y_own0, y_own1;     // rows [y_own0, y_own1) may be updated; others are read-only halo rows
     int max_sweeps;         // sweeps per activation before a tile yields (it re-activates itself)
     int chain_max;          // solo rounds: tile hand-overs inside one launch (0 = one tile per launch; TDX_SOLO_CHAIN)
+    // Where a round reports its size to the host (set per batch by RoundRunner::enqueue; null = nobody listens): the first workgroup of the round
+    // launched with the counter `count` stores count[0] to cnt_host[count - cnt_dev] - pinned host memory - so that the host needs no copy
+    // kernel between two batches of rounds (61 of them per 16384^2 pipeline step, ~6 us each: profiles/r04m_timeline_*).
+    unsigned long long* cnt_host;
+    const unsigned long long* cnt_dev;
 };
 
 static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
@@ -60,6 +66,7 @@ static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
     g.max_sweeps = ms;
     static const int cm = getenv("TDX_SOLO_CHAIN") ? atoi(getenv("TDX_SOLO_CHAIN")) : 256;
     g.chain_max = cm;
+    g.cnt_host = nullptr; g.cnt_dev = nullptr;
     return g;
 }
 
@@ -741,6 +748,8 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
     // bid / nblocks: this workgroup's index among the workgroups of THIS schedule (a launch can carry two: relax_pair_kernel)
     const int chain_max = g.chain_max;
     const unsigned nact = unsigned(count[0]);
+    if (g.cnt_host != nullptr && bid == 0u && threadIdx.x == 0)   // this round's size, for the host (final: the previous round's launch has ended)
+        __hip_atomic_store(g.cnt_host + (count - g.cnt_dev), (unsigned long long)count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t entry0 = list[bid];                 // for a small round (below); fetched together with the count: nblocks <= number of tiles
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
     unsigned pull = nact / (2u * nblocks);
@@ -1085,6 +1094,7 @@ struct RoundRunner {
     // relaxation has 5-7 of them, a step a dozen relaxations.  parity: flag half of the first round AFTER the collected batches.
     int r = 0, parity = 0, batch = 4;
     int r_enq = 0, parity_enq = 0, n_enq = 0, n_col = 0, fl_batch[2] = {0, 0};
+    bool polled[2] = {false, false};     // the slot's batch reports through the host slot itself (no copy, no event)
     int ev_base = 0;                     // ctx->ev_batch[ev_base + slot]
     int batch_max = 64;                  // drive() / the pair lower it: with two batches in flight a whole batch of empty rounds follows the last one
     bool done = false;
@@ -1092,14 +1102,16 @@ struct RoundRunner {
     bool short_tail = getenv("TDX_RELAX_LONG_TAIL") == nullptr;   // (A/B hook)
     unsigned long long last_count = 0;   // active tiles of the last non-empty round seen
     // another tile kernel on the same schedule (tile_dep.hpp): launches one round; empty = the relaxation kernel of `op`
-    std::function<void(unsigned grid, hipStream_t st, const uint32_t* list, unsigned long long* count, uint32_t* flags_cur, uint32_t* flags_next,
-                       uint32_t* list_next, unsigned pull_max)> custom_launch;
+    // (rg: the runner's geometry of THIS launch - the caller's geometry plus where the round reports its size; the tile kernel must be given rg)
+    std::function<void(const tilek::TileGeom& rg, unsigned grid, hipStream_t st, const uint32_t* list, unsigned long long* count, uint32_t* flags_cur,
+                       uint32_t* flags_next, uint32_t* list_next, unsigned pull_max)> custom_launch;
     RoundRunner(tdx_context* c, hipStream_t st, Op o, tilek::TileGeom geom, tilek::Sched sched, uint64_t* host_mail, unsigned long long* d)
         : ctx(c), s(st), op(o), g(geom), sc(sched), h(host_mail), dbg(d) {
         ntiles = g.tiles_x * g.tiles_y;
         cgrid = tdx_blocks_for(size_t(ntiles), 256);
         grid_full = unsigned(std::min(ntiles, 8 * ctx->num_cus));
-        grid_small = unsigned(std::min(ntiles, ctx->num_cus));
+        static const int gs_env = getenv("TDX_RELAX_GRID_SMALL") ? std::max(1, atoi(getenv("TDX_RELAX_GRID_SMALL"))) : 0;   // (A/B hook)
+        grid_small = unsigned(std::min(ntiles, gs_env ? gs_env : ctx->num_cus));
         const char* e = getenv("TDX_RELAX_RING");
         ring_len = e ? std::max(3, std::min(atoi(e), tilek::COUNT_RING)) : tilek::COUNT_RING;
         lds_variant = getenv("TDX_RELAX_LDS") != nullptr;
@@ -1135,11 +1147,18 @@ struct RoundRunner {
         const bool timed = ctx->kernel_timing && s == ctx->stream;
         // the tail of a relaxation: a small grid launches faster (any grid size is correct, the cursor covers the list)
         const unsigned grid = (rounds > 0 && last_count <= 256ull) ? grid_small : grid_full;
+        // the rounds of this batch report their sizes straight into the host slot (TDX_RELAX_COUNT_COPY=1: a copy after the batch instead - A/B hook)
+        static const bool count_copy = getenv("TDX_RELAX_COUNT_COPY") != nullptr;
+        if (!count_copy) {
+            for (int b = 0; b < batch; b++) hs[b] = ~0ull;   // (the slot's previous batch has been collected)
+            g.cnt_host = reinterpret_cast<unsigned long long*>(hs);
+            g.cnt_dev = sc.counts + r;
+        } else { g.cnt_host = nullptr; g.cnt_dev = nullptr; }
         for (int b = 0; b < batch; b++) {
             const int p = (parity + b) & 1;
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
             if (custom_launch)
-                custom_launch(grid, s, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1), list_of(p ^ 1), pull_max);
+                custom_launch(g, grid, s, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1), list_of(p ^ 1), pull_max);
             else if (lds_variant)
                 hipLaunchKernelGGL((relax_kernel<Op, false>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
                                    list_of(p ^ 1), pull_max, dbg);
@@ -1151,10 +1170,13 @@ struct RoundRunner {
         }
         launches += batch;
         fl_batch[slot] = batch;
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(hs, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        hipEvent_t& ev = ctx->ev_batch[ev_base + slot];
-        if (!ev) TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        TDX_HIP_CHECK(ctx, hipEventRecord(ev, s));
+        polled[slot] = !count_copy;
+        if (count_copy) {
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(hs, sc.counts + r, size_t(batch) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            hipEvent_t& ev = ctx->ev_batch[ev_base + slot];
+            if (!ev) TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            TDX_HIP_CHECK(ctx, hipEventRecord(ev, s));   // (an event record is a barrier packet: a ~6 us bubble between two batches)
+        }
         r_enq += batch;
         parity_enq = (parity_enq + batch) & 1;
         n_enq++;
@@ -1167,8 +1189,25 @@ struct RoundRunner {
         if (tail_batch && rounds > 0 && last_count <= 256ull) batch = std::min(batch, tail_batch);
         return TDX_OK;
     }
-    int wait_oldest() {   // the oldest batch in flight has finished and its counts are on the host
-        TDX_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_batch[ev_base + (n_col & 1)]));
+    int wait_oldest() {   // the counts of the oldest batch in flight are on the host
+        const int slot = n_col & 1;
+        if (!polled[slot]) {
+            TDX_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_batch[ev_base + slot]));
+            return TDX_OK;
+        }
+        // the batch's rounds wrote their sizes themselves (round_driver): once its LAST round has reported - it has started, so every earlier round has
+        // ended - the batch's counts are complete.  No event, no barrier packet in the stream; bounded like every other wait of the library.
+        const volatile uint64_t* last = h + slot * TDX_MAIL_RUN_SLOT + (fl_batch[slot] - 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *last == ~0ull; spins++) {
+            if ((spins & 1023u) == 1023u) {
+                if (hipStreamQuery(s) == hipSuccess && *last == ~0ull)
+                    return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: a round ended without reporting its size");
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0)
+                    return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no report from a batch of rounds after 600 s");
+            }
+            __builtin_ia32_pause();
+        }
         return TDX_OK;
     }
     void collect() {   // the oldest batch in flight; its counts must have arrived (wait_oldest() or a synchronised stream)
