@@ -2,11 +2,15 @@
 seeds and masks as flatk::classify_kernel makes them (numpy, first iteration), 64x64 tiles, every active tile relaxed to its local
 fixed point per round against the previous round's halo, neighbours of a tile whose rim changed are active in the next round.
 
-    python scripts/sim_level_rounds.py [n=2048] [filter]
+    python scripts/sim_level_rounds.py [n=2048] [filter|chain]
 
 `filter`: activate a neighbour only if a changed rim cell (new level v) touches a cell x of it that is in the queue and holds more than
 v + 1 in the halo AS LOADED (an upper bound of its current level: the test never misses an improvement; a cell outside the queue
-reads -1 and never moves).  Analysis tool (uses oracle/); the result is checked against the global fixed point."""
+reads -1 and never moves).
+`chain` (round 4, the review's "carry the front rim-to-rim across plain tiles"): a tile all of whose 4096 cells are in the queue and free to move
+(no seed, no cell outside the flat: in such a tile the level field is the chessboard distance transform of its ring) is processed IN THE ROUND
+that activates it, transitively - the best case of a persistent workgroup that follows the front through such tiles - and the rounds / launches
+that are left are counted.  Analysis tool (uses oracle/); the result is checked against the global fixed point."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo')
@@ -14,6 +18,7 @@ from oracle import oracle as O
 O.build()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 FILTER = len(sys.argv) > 2 and sys.argv[2] == 'filter'
+CHAIN = len(sys.argv) > 2 and sys.argv[2] == 'chain'
 TS = 64
 INF = 0x3fffffff
 def nb(a, dy, dx, fill):
@@ -48,8 +53,13 @@ def fixpoint(v, mov):
         if (wn == v).all(): return v, it
         v = wn
 t0 = time.time()
-ref, levels = fixpoint(val.copy(), movable)
-print(f"global fixed point: {levels} levels, {int(flat.sum())} flat cells  [{time.time()-t0:.1f}s]", flush=True)
+import os
+REF_FILE = os.environ.get("SIM_REF")     # SIM_REF=file.npy: compare with (or, if absent, write) a saved result instead of the slow global iteration
+if REF_FILE and os.path.exists(REF_FILE): ref = np.load(REF_FILE); print(f"reference field from {REF_FILE}, {int(flat.sum())} flat cells", flush=True)
+elif REF_FILE: ref = None; print(f"no reference yet: this run's field goes to {REF_FILE}, {int(flat.sum())} flat cells", flush=True)
+else:
+    ref, levels = fixpoint(val.copy(), movable)
+    print(f"global fixed point: {levels} levels, {int(flat.sum())} flat cells  [{time.time()-t0:.1f}s]", flush=True)
 nt = N // TS
 Vp = np.full((N + 2, N + 2), INF, np.int64); Vp[1:-1, 1:-1] = val
 Qp = np.zeros((N + 2, N + 2), bool); Qp[1:-1, 1:-1] = inq_all
@@ -62,12 +72,20 @@ def relax_tile(win, mov):
         if np.array_equal(new, c): return c
         w[1:-1, 1:-1] = new
 active = flat.reshape(nt, TS, nt, TS).any(axis=(1, 3))
-rnd = 0; tot = 0
+fps = movable.reshape(nt, TS, nt, TS).all(axis=(1, 3))      # full, plain, seedless tiles: every cell in the queue and free to move
+print(f"tiles {nt * nt}, with flat cells {int(active.sum())}, full / plain / seedless {int(fps.sum())}", flush=True)
+rnd = 0; tot = 0; tot_fps = 0; tail_act = 0; tail_fps = 0; chained = 0
 while active.any():
     cur = Vp.copy()
     nxt = np.zeros((nt, nt), bool)
     nact = int(active.sum()); nchg = 0
-    for ty, tx in zip(*np.nonzero(active)):
+    nfps = int((active & fps).sum()); tot_fps += nfps
+    if nact <= 64: tail_act += nact; tail_fps += nfps
+    work = list(zip(*np.nonzero(active)))
+    wi = 0
+    while wi < len(work):
+        ty, tx = work[wi]; wi += 1
+        if CHAIN and wi > nact: cur = Vp       # a chained tile sees what this round has written so far (same workgroup)
         y0, x0 = ty * TS, tx * TS
         win = cur[y0:y0 + TS + 2, x0:x0 + TS + 2]
         old = win[1:-1, 1:-1]
@@ -93,9 +111,14 @@ while active.any():
         for dy, dx, hit in tests:
             if hit:
                 yy, xx = ty + dy, tx + dx
-                if 0 <= yy < nt and 0 <= xx < nt: nxt[yy, xx] = True
+                if 0 <= yy < nt and 0 <= xx < nt:
+                    if CHAIN and fps[yy, xx] and nact <= 64:
+                        work.append((yy, xx)); chained += 1          # processed in this same round (it may come up again later in the round)
+                    else: nxt[yy, xx] = True
     tot += nact
-    if rnd < 12 or nact > 50: print(f"round {rnd:3d}: active {nact:5d} changed {nchg:5d} ({100.0*nchg/nact:5.1f}%)  [{time.time()-t0:6.1f}s]", flush=True)
+    if rnd < 12 or nact > 50 or rnd % 10 == 0: print(f"round {rnd:3d}: active {nact:5d} (full/plain/seedless {nfps:5d}) changed {nchg:5d} ({100.0*nchg/nact:5.1f}%) processed {len(work):5d} [{time.time()-t0:6.1f}s]", flush=True)
     active = nxt; rnd += 1
     if rnd > 2000: break
-print("rounds", rnd, "total activations", tot, "tiles", nt * nt, "equals the global fixed point", bool(np.array_equal(Vp[1:-1, 1:-1], ref)))
+if ref is None: np.save(REF_FILE, Vp[1:-1, 1:-1]); ref = Vp[1:-1, 1:-1]
+print("rounds", rnd, "total activations", tot, "of them on full/plain/seedless tiles", tot_fps, "| rounds with <= 64 active tiles: activations", tail_act, "on full/plain/seedless tiles", tail_fps,
+      "| chained in-round activations", chained, "| tiles", nt * nt, "equals the global fixed point", bool(np.array_equal(Vp[1:-1, 1:-1], ref)))
