@@ -108,6 +108,22 @@ def aread8(p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=Tru
     return ad8
 
 
+def aread8_check(p, ad8, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=True, threads=None):
+    """Linear-time pin of aread8()'s loop body (src/aread8.cpp:231-256) to a given result (no outlets): (cells of `ad8` that are not what their
+    contributors' values in `ad8` give, index of the first one or -1, cells with a direction code)."""
+    p = np.ascontiguousarray(p, dtype=np.int16)
+    ad8 = np.ascontiguousarray(ad8, dtype=np.float32)
+    ny, nx = p.shape
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+    first, queued = C.c_long(-1), C.c_long(0)
+    f = lib().orc_aread8_check
+    f.restype = C.c_long
+    bad = f(_p(p), C.c_long(nx), C.c_long(ny), C.c_int16(nodata), _p(weights), C.c_float(weights_nodata), C.c_int(int(contcheck)), _p(ad8),
+            C.c_int(int(threads or os.cpu_count() or 1)), C.byref(first), C.byref(queued))
+    return int(bad), int(first.value), int(queued.value)
+
+
 def d8flowpathextremeup(p, sa, nodata=-32768, usemax=True, contcheck=True, outlets=None):
     """ssa of src/D8flowpathextremeup.cpp: max / min of `sa` over everything upstream of a cell (nodata -FLT_MAX)."""
     p = np.ascontiguousarray(p, dtype=np.int16)

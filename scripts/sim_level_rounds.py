@@ -88,7 +88,7 @@ while active.any():
         if CHAIN and wi > nact: cur = Vp       # a chained tile sees what this round has written so far (same workgroup)
         y0, x0 = ty * TS, tx * TS
         win = cur[y0:y0 + TS + 2, x0:x0 + TS + 2]
-        old = win[1:-1, 1:-1]
+        old = win[1:-1, 1:-1].copy()
         new = relax_tile(win, movable[y0:y0 + TS, x0:x0 + TS])
         if np.array_equal(new, old): continue
         nchg += 1

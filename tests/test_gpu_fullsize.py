@@ -322,3 +322,44 @@ def test_eight_strips_equal_one_at_65536_columns(ctx, monkeypatch):
     assert sorted(o for _, outl, _ in res for o in outl) == outlets1 and len(outlets1) == 64
     assert all(lv == (st1["levels_fall_max"], st1["levels_rise_max"]) for _, _, lv in res), "the level statistics are global"
     assert 0 < st1["levels_fall_max"] < 32766
+
+
+def test_d8_config4_strip_vs_restatement(ctx, oracle, monkeypatch):
+    """BASELINE.json configs[3] as one GPU of the 8-GPU run sees it - the pipeline on a 65536 x 8192 strip of the 65536^2 DEM - against the restatement
+    on the host: `p` and `sd8` of D8FlowDir on every cell (the restatement with its flat loops as breadth-first searches: linear time, pinned to the
+    real reference on CPU; the first pass and setFlow2 on the host threads), `ad8` of AreaD8 on every cell through aread8()'s loop body
+    (orc_aread8_check).  fel itself is pinned by its fixed-point properties at this size (and by digests up to 16384^2)."""
+    if _host_gb() < 48:
+        pytest.skip("needs ~30 GB of host memory")
+    import os
+
+    import torch
+
+    import taudem_amd as T
+
+    nx, ny = 65536, 8192
+    dem = ctx.synth_dem((ny, nx), seed=1234, base_wavelength=T.synth_base_wavelength(65536))
+    fel = ctx.pitremove(dem, -9999.0)
+    assert bool((fel >= dem).all()) and torch.equal(ctx.pitremove(fel, -9999.0), fel)
+    del dem
+    p, sd8, st = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    ad8 = ctx.aread8(p, -32768)
+    fel_h = fel.cpu().numpy()
+    del fel
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    oracle.set_threads(os.cpu_count() or 1)
+    try:
+        p_o, sd8_o, st_o = oracle.d8flowdir(fel_h, -3.0e38, 30.0, 30.0)
+    finally:
+        oracle.set_threads(1)
+    del fel_h
+    assert (st_o["flats_initial"], st_o["flat_iterations"], st_o["flats_left"]) == (st["flats_initial"], st["flat_iterations"], st["flats_left"])
+    p_h = p.cpu().numpy()
+    neq = int(np.count_nonzero(p_h != p_o))
+    assert neq == 0, f"p: {neq} cells differ from the restatement"
+    assert np.array_equal(sd8.cpu().numpy().view(np.uint32), sd8_o.view(np.uint32)), "sd8 differs from the restatement"
+    del p_o, sd8_o, sd8
+    ad8_h = ad8.cpu().numpy()
+    bad, first, queued = oracle.aread8_check(p_h, ad8_h, -32768, contcheck=True)
+    assert bad == 0, f"{bad} cells of ad8 do not follow from aread8()'s expression; first at row {first // nx} column {first % nx}"
+    assert queued == int(((p_h >= 0) & (p_h <= 8)).sum()) and float(ad8_h.max()) > 2 ** 24

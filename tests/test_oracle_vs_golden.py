@@ -180,3 +180,26 @@ def test_decay_checker_vs_restatement_with_weights_outlets_and_contamination(ora
             assert np.array_equal(mark != 0, d != np.float32(-3.402823466e38)) and queued == int(mark.sum())
     d = oracle.dinfdecayaccum(ang, dm, dx=30.0, dy=25.0, contcheck=True)      # no outlets, no weights
     assert oracle.dinfdecayaccum_check(ang, dm, d, dx=30.0, dy=25.0, contcheck=True)[:2] == (0, -1)
+
+
+@pytest.mark.parametrize("key,kw", [("ad8", {}), ("ad8_nc", {"contcheck": False}), ("ad8_w", {"w": True}), ("ad8_w_nc", {"w": True, "contcheck": False})])
+def test_aread8_checker_accepts_the_reference_rasters_and_nothing_else(g, oracle, key, kw):
+    """The linear-time AreaD8 checker (aread8()'s loop body applied to every cell of a given raster: oracle/taudem_oracle.c: orc_aread8_check) passes the rasters
+    the REAL tool wrote and notices a wrong count, a missing value and a value on a cell without direction."""
+    w = g["w"] if kw.get("w") else None
+    cc = kw.get("contcheck", True)
+    ref = np.array(g[key], copy=True)
+    bad, first, queued = oracle.aread8_check(g["p"], ref, -32768, weights=w, contcheck=cc)
+    assert (bad, first) == (0, -1), f"{key}: {bad} cells of the reference's raster fail the check, first at {first}"
+    assert queued == int(((g["p"] >= 0) & (g["p"] <= 8)).sum())
+    assert oracle.aread8_check(g["p"], ref, -32768, weights=w, contcheck=cc, threads=3)[:2] == (0, -1)
+    ys, xs = np.nonzero(ref > 0)
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])
+    t = ref.copy(); t[y, x] += np.float32(1.0) if ref[y, x] < 2 ** 23 else np.float32(8.0)
+    assert oracle.aread8_check(g["p"], t, -32768, weights=w, contcheck=cc)[0] >= 1
+    t = ref.copy(); t[y, x] = np.float32(-1.0)
+    assert oracle.aread8_check(g["p"], t, -32768, weights=w, contcheck=cc)[0] >= 1
+    ys, xs = np.nonzero(g["p"] == -32768)
+    if len(ys):
+        t = ref.copy(); t[ys[0], xs[0]] = np.float32(1.0)
+        assert oracle.aread8_check(g["p"], t, -32768, weights=w, contcheck=cc)[0] >= 1
