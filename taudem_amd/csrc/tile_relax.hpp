@@ -441,6 +441,25 @@ __device__ __forceinline__ float min_with_side_lanes(float acc, float x) {
         : "v"(x));
     return acc;
 }
+// Eight neighbours, separably: min over (a, b, hm) and over the side lanes' three-row minimum t = min3(a, c, b) - the side lanes hold the same
+// rows as this one (a = the row above as this sweep has left it).  One block, so that the order is fixed: t, then the accumulator (the one
+// wait state between t's write and its first DPP read that the s_nop 0 completes to two), then the two DPP-fused minima: 4 VALU instructions.
+__device__ __forceinline__ float min8_separable(float a, float c, float b, float hm) {
+    float acc, t;
+    asm("v_min3_f32 %1, %2, %3, %4\n\tv_min3_f32 %0, %2, %4, %5\n\ts_nop 0\n\t"
+        "v_min_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc), "=&v"(t)
+        : "v"(a), "v"(c), "v"(b), "v"(hm));
+    return acc;
+}
+__device__ __forceinline__ int min8_separable(int a, int c, int b, int hm) {
+    int acc, t;
+    asm("v_min3_i32 %1, %2, %3, %4\n\tv_min3_i32 %0, %2, %4, %5\n\ts_nop 0\n\t"
+        "v_min_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc), "=&v"(t)
+        : "v"(a), "v"(c), "v"(b), "v"(hm));
+    return acc;
+}
 __device__ __forceinline__ float min_with_side_lanes3(float acc, float a, float c, float b) {
     asm("s_nop 1\n\t"
         "v_min_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_min_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -485,9 +504,14 @@ template <class Op>
 __device__ __forceinline__ typename Op::T reg_row_min(unsigned m8, typename Op::T a, typename Op::T c, typename Op::T b, typename Op::T hm,
                                                       ShiftRegs<typename Op::T>& s) {
     using T = typename Op::T;
-    if constexpr (Op::kUniform != 0) {   // 7 (3) instructions instead of 6 + 4 (2 + 2)
+    if constexpr (Op::kUniform != 0) {
+#ifdef TDX_RELAX_NINEWAY
         const T acc = min3_raw(a, b, hm);
-        return Op::kUniform == 8 ? min_with_side_lanes3(acc, a, c, b) : min_with_side_lanes(acc, c);
+        return Op::kUniform == 8 ? min_with_side_lanes3(acc, a, c, b) : min_with_side_lanes(acc, c);   // 7 (3) instructions
+#else
+        if constexpr (Op::kUniform == 8) return min8_separable(a, c, b, hm);   // 4 instructions
+        return min_with_side_lanes(min3_raw(a, b, hm), c);
+#endif
     }
     s.lc = lane_left(c, s.lc);
     s.rc = lane_right(c, s.rc);
