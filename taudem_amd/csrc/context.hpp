@@ -41,6 +41,9 @@ struct tdx_context {
     struct Slot { void* p = nullptr; size_t bytes = 0; };
     std::vector<Slot> slots;
     void* scratch(int slot, size_t bytes);   // returns nullptr + sets err on failure
+    // the cell sizes the D8 distance table resident in slot TDX_S_FACT was built from (tdx_build_fact_table: a repeated call with the same
+    // geometry - every step of a pipeline over one raster - finds its table in place instead of a host loop, an upload and a stream synchronisation)
+    std::vector<double> fact_dxc, fact_dyc;
 
     // pinned host mailbox for small device->host readbacks (counters, flags)
     uint64_t* h_mail = nullptr;              // TDX_MAIL_WORDS words, hipHostMalloc (layout: the TDX_MAIL_* offsets below)
@@ -94,7 +97,7 @@ struct TdxSpan {
 // scratch slot ids (one namespace for all stages; stages never run concurrently on a context)
 enum {
     TDX_S_A = 0, TDX_S_B, TDX_S_C, TDX_S_D, TDX_S_E, TDX_S_F, TDX_S_G, TDX_S_H, TDX_S_I, TDX_S_J, TDX_S_K,
-    TDX_S_Q, TDX_S_L, TDX_S_M, TDX_S_N, TDX_S_O, TDX_S_P, TDX_S_R, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_COUNT
+    TDX_S_Q, TDX_S_L, TDX_S_M, TDX_S_N, TDX_S_O, TDX_S_P, TDX_S_R, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_FACT, TDX_S_COUNT
 };
 
 static inline int tdx_fail(tdx_context* ctx, int code, const std::string& msg) {
