@@ -19,7 +19,8 @@ O.build()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 FILTER = len(sys.argv) > 2 and sys.argv[2] == 'filter'
 CHAIN = len(sys.argv) > 2 and sys.argv[2] == 'chain'
-TS = 64
+import os
+TS = int(os.environ.get("SIM_TS", "64"))   # SIM_TS=128: what a coarser tile geometry would make of the round count
 INF = 0x3fffffff
 def nb(a, dy, dx, fill):
     out = np.full_like(a, fill); H, W = a.shape

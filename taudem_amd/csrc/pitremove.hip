@@ -41,18 +41,30 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     const int ybase = y_own0 + blockIdx.y * (4 * SEED_ROWS) + (threadIdx.x >> 6) * SEED_ROWS;
     const bool colok = x < nx;
     const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    // per row: centre value and the nodata flags of (x-1, x, x+1); rows outside the array count as nodata
-    auto ldrow = [&](int y, float& zc, bool& a, bool& b, bool& c) {
-        if (y >= 0 && y < ny) {
-            const float* r = Z + size_t(y) * size_t(nx);
-            zc = r[xc];
-            a = tdxk::is_nodata_f(r[xm], nodata); b = tdxk::is_nodata_f(zc, nodata); c = tdxk::is_nodata_f(r[xp], nodata);
-        } else { zc = nodata; a = b = c = true; }
-    };
-    float zn, zc, zs;
-    bool n0, n1, n2, c0, c1, c2, s0, s1, s2;
-    ldrow(ybase - 1, zn, n0, n1, n2);
-    ldrow(ybase, zc, c0, c1, c2);
+    // the lane's window: SEED_ROWS + 2 rows x 3 columns, every load issued before the first use (addresses clamped, validity applied afterwards -
+    // a load behind a row test is a branch, and a lane would then wait for one row at a time); rows outside the array count as nodata
+    float zl[SEED_ROWS + 2], zm[SEED_ROWS + 2], zr[SEED_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < SEED_ROWS + 2; j++) {
+        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        const float* r = Z + size_t(yc) * size_t(nx);
+        zl[j] = r[xm]; zm[j] = r[xc]; zr[j] = r[xp];
+    }
+    float wc[SEED_ROWS / SEED_CF];   // MODE 2: the relaxed coarse value of the blocks this lane crosses
+    if (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < SEED_ROWS / SEED_CF; q++) {
+            const int yc = (ybase - y_own0) / SEED_CF + q, xcb = xc / SEED_CF;
+            wc[q] = Wc[size_t(yc < nyc ? yc : nyc - 1) * size_t(nxc) + size_t(xcb < nxc ? xcb : nxc - 1)];
+        }
+    }
+    unsigned nod[SEED_ROWS + 2];   // bit 0 / 1 / 2: (x - 1, x, x + 1) of the row is nodata
+#pragma unroll
+    for (int j = 0; j < SEED_ROWS + 2; j++) {
+        const int y = ybase - 1 + j;
+        const bool in = y >= 0 && y < ny;
+        nod[j] = in ? ((tdxk::is_nodata_f(zl[j], nodata) ? 1u : 0u) | (tdxk::is_nodata_f(zm[j], nodata) ? 2u : 0u) | (tdxk::is_nodata_f(zr[j], nodata) ? 4u : 0u)) : 7u;
+    }
     float bmax[SEED_ROWS / SEED_CF];   // MODE 1: this lane's column of each block row it crosses
     bool bany[SEED_ROWS / SEED_CF], bseed[SEED_ROWS / SEED_CF];
 #pragma unroll
@@ -60,7 +72,9 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < SEED_ROWS; r++) {
         const int y = ybase + r;
-        ldrow(y + 1, zs, s0, s1, s2);
+        const float zc = zm[r + 1];
+        const unsigned nn = nod[r], nc = nod[r + 1], ns = nod[r + 2];
+        const bool c1 = (nc & 2u) != 0u;
         if (colok && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
             float w;
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
             else if (mask && mask[idx] == 1) w = zc;
             else if (x == 0 || y == 0 || x == nx - 1 || y == ny - 1) w = zc;   // !hasAccess(i+-1,j+-1): global edge ring
             else {
-                const bool con = (step == 2) ? (c2 || n1 || c0 || s1) : (c2 || n2 || n1 || n0 || c0 || s0 || s1 || s2);
+                const bool con = (step == 2) ? (((nc & 5u) | (nn & 2u) | (ns & 2u)) != 0u) : ((nn | nc | ns) != 0u);   // (nc & 2 is clear here)
                 w = con ? zc : FLT_MAX;
             }
             if (MODE == 0) W[idx] = w;
@@ -78,14 +92,11 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
                 if (w != FLT_MAX) bseed[r / SEED_CF] = true;
             }
             if (MODE == 2) {
-                if (w == FLT_MAX) w = Wc[size_t((y - y_own0) / SEED_CF) * size_t(nxc) + size_t(x / SEED_CF)];
+                if (w == FLT_MAX) w = wc[r / SEED_CF];
                 W[idx] = w;
             }
         }
-        zn = zc; n0 = c0; n1 = c1; n2 = c2;
-        zc = zs; c0 = s0; c1 = s1; c2 = s2;
     }
-    (void)zn;
     if (MODE == 1) {   // the 8 lanes of a block column (aligned: 64 columns per wave), then one store per block
 #pragma unroll
         for (int q = 0; q < SEED_ROWS / SEED_CF; q++) {
