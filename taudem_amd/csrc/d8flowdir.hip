@@ -48,11 +48,13 @@ using flatmask_t = uint32_t;    // one bit per row of a lane's segment
 template <int SLOPE_SEG>
 __global__ __launch_bounds__(256) void d8_slope_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
                                                        const double* __restrict__ fact, int16_t* __restrict__ P,
-                                                       float* __restrict__ SD8, flatmask_t* __restrict__ flatbits) {
+                                                       float* __restrict__ SD8, flatmask_t* __restrict__ flatbits, int nbx, int xmap) {
     using tilek::lane_left;
     using tilek::lane_right;
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
     const int lx = threadIdx.x & 63;
-    const int x = blockIdx.x * SLOPE_COLS - 1 + lx;
+    const int x = bx * SLOPE_COLS - 1 + lx;
     const int band = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * 4 + int(threadIdx.x >> 6));
     const int ybase = y_own0 + band * SLOPE_SEG;
     const bool mine = lx >= 1 && lx <= SLOPE_COLS && x < nx;
@@ -213,11 +215,13 @@ constexpr int CLS_COLS = 62;
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
                                                                  int y_own0, int y_own1, int tiles_x, lvl_t* __restrict__ lvl,
                                                                  lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
+                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap) {
     using tilek::lane_left;
     using tilek::lane_right;
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
     const int lx = threadIdx.x & 63;
-    const int x = blockIdx.x * CLS_COLS - 1 + lx;
+    const int x = bx * CLS_COLS - 1 + lx;
     const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
     const bool mine = lx >= 1 && lx <= CLS_COLS && x < nx;
     const bool inx = x >= 0 && x < nx;
@@ -372,11 +376,13 @@ constexpr int SF2_COLS = 62;
 __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
                                                                  const double* __restrict__ fact, const lvl_t* __restrict__ lvl,
                                                                  const lvl_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
-                                                                 uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter) {
+                                                                 uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter, int nbx, int xmap) {
     using tilek::lane_left;
     using tilek::lane_right;
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
     const int lx = threadIdx.x & 63;
-    const int x = blockIdx.x * SF2_COLS - 1 + lx;
+    const int x = bx * SF2_COLS - 1 + lx;
     const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
     const bool mine = lx >= 1 && lx <= SF2_COLS && x < nx;
     const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
@@ -515,9 +521,10 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     if (!flatbits || !blocksum) return TDX_ERR_NOMEM;
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        dim3 grid((inx + SLOPE_COLS - 1) / SLOPE_COLS, unsigned(nband / 4));
-        if (seg == 16) hipLaunchKernelGGL(d8_slope_kernel<16>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
-        else hipLaunchKernelGGL(d8_slope_kernel<32>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits);
+        const int nbx = (inx + SLOPE_COLS - 1) / SLOPE_COLS, xmap = tdx_xcd_map() ? 1 : 0;
+        dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), unsigned(nband / 4));
+        if (seg == 16) hipLaunchKernelGGL(d8_slope_kernel<16>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits, nbx, xmap);
+        else hipLaunchKernelGGL(d8_slope_kernel<32>, grid, dim3(256), 0, s, d_fel, inx, st.ny_arr, st.y0, st.y1, fel_nodata, d_fact, d_p, d_sd8, flatbits, nbx, xmap);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     {
@@ -564,9 +571,10 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             D8Traits tr{d_p};
             const float* zc = zcur;
             const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked) {
-                const dim3 grid((st.nx + CLS_COLS - 1) / CLS_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                const int nbx = (st.nx + CLS_COLS - 1) / CLS_COLS;
+                const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                 hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
-                                   rmask, tile_flags, tile_masked);
+                                   rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0);
             };
             if (sparse) {
                 // the previous queue exists as a list only if it was built (first queue of a dense strip: bit masks only) - without one every marker is rewritten
@@ -580,9 +588,10 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
                 if (nq > n / 32) {   // dense queue: one streaming pass
-                    const dim3 grid((st.nx + SF2_COLS - 1) / SF2_COLS, (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                    const int nbx = (st.nx + SF2_COLS - 1) / SF2_COLS;
+                    const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                     hipLaunchKernelGGL(d8_setflow2_stream_kernel, grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
-                                       d_cnt);
+                                       d_cnt, nbx, tdx_xcd_map() ? 1 : 0);
                 } else if (nq) {
                     if (fl.has_pits)
                         hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);

@@ -4,6 +4,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 
 namespace tdxk {
 
@@ -91,6 +92,21 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Column block of this workgroup in a streaming pass whose grid is (column blocks, row bands).  Block b of a launch runs on XCD b % 8 (observed -
+// MI355X_MICROARCH.md, workgroup dispatch; a matter of speed only), so in launch order two neighbouring column blocks sit on DIFFERENT L2s: the halo
+// columns both read are fetched twice and the cache lines at their seam are written in two halves.  With the grid's x extent padded to a multiple
+// of 8 (tdx_xcd_grid_x) the blocks of one XCD take one contiguous eighth of the columns instead; a padding block gets -1.  xmap == 0: launch order.
+__device__ __forceinline__ int xcd_block_x(int nblocks, int xmap) {
+    if (!xmap) return int(blockIdx.x);
+    const int b = int(blockIdx.x & 7u) * int(gridDim.x >> 3) + int(blockIdx.x >> 3);
+    return b < nblocks ? b : -1;
+}
+
 }  // namespace tdxk
 
 static inline unsigned tdx_blocks_for(uint64_t n, unsigned threads) { return unsigned((n + threads - 1) / threads); }
+
+// host side of tdxk::xcd_block_x: the x extent of the grid and the kernel's xmap argument (TDX_XCD_MAP_OFF=1: launch order - A/B hook)
+static inline bool tdx_xcd_map() { static const bool on = getenv("TDX_XCD_MAP_OFF") == nullptr; return on; }
+static inline unsigned tdx_xcd_grid_x(unsigned nblocks) { return tdx_xcd_map() ? ((nblocks + 7u) & ~7u) : nblocks; }
+

@@ -36,8 +36,10 @@ constexpr int SEED_CF = 8;   // = CF below
 template <int MODE>
 __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__ Z, const int16_t* __restrict__ mask,
                                                        float* __restrict__ W, int nx, int ny, int y_own0, int y_own1, float nodata, int step,
-                                                       float* __restrict__ Zc, float* __restrict__ Wc, int nxc, int nyc) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+                                                       float* __restrict__ Zc, float* __restrict__ Wc, int nxc, int nyc, int nbx, int xmap) {
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
+    const int x = bx * 64 + (threadIdx.x & 63);
     const int ybase = y_own0 + blockIdx.y * (4 * SEED_ROWS) + (threadIdx.x >> 6) * SEED_ROWS;
     const bool colok = x < nx;
     const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
@@ -238,7 +240,8 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     int rc = strip_exchange<float>(ctx, st, d_dem, dem_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     int64_t rounds = 0, launches = 0, outer = 0;
-    const dim3 sgrid((st.nx + 63) / 64, (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
+    const int sbx = (st.nx + 63) / 64, sxmap = 0;   // (64-column blocks on line boundaries: the XCD-aware order of d8flowdir.hip gains nothing here)
+    const dim3 sgrid(unsigned(sbx), (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
     const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;   // (test hook: read per call)
     const int nyo = st.y1 - st.y0;   // the coarse-to-fine start works on the OWNED rows: paths that leave the strip are ignored, which only loosens the bound
     if (!fourway && !no_coarse && size_t(st.nx) * size_t(nyo) >= (size_t(1) << 18)) {
@@ -250,7 +253,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
         if (!Zc || !Wc) return TDX_ERR_NOMEM;
         {
             TdxSpan sp(ctx, TDX_K_STENCIL);
-            hipLaunchKernelGGL(pit_seed_kernel<1>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc);
+            hipLaunchKernelGGL(pit_seed_kernel<1>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc, sbx, sxmap);
             if (stats) stats->launches[TDX_K_STENCIL]++;
         }
         {
@@ -265,13 +268,13 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
         }
         {
             TdxSpan sp(ctx, TDX_K_STENCIL);
-            hipLaunchKernelGGL(pit_seed_kernel<2>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc);
+            hipLaunchKernelGGL(pit_seed_kernel<2>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc, sbx, sxmap);
             if (stats) stats->launches[TDX_K_STENCIL]++;
         }
     } else {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         hipLaunchKernelGGL(pit_seed_kernel<0>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, fourway ? 2 : 1,
-                           static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, 0);
+                           static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, 0, sbx, sxmap);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // start surface halo rows
