@@ -454,10 +454,20 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
             }
         }
     }
-    unsigned long long pos = block_reserve(unsigned(__popc(keep)), counter);
+    // The wave's slots are filled row by row, so that neighbouring list entries are neighbouring cells of a raster row: the kernels of the next
+    // iteration gather the 3 x 3 windows of 64 consecutive entries per wave (lane by lane - a lane's column segment - every entry of a wave sat in
+    // a row of its own).
+    const unsigned long long pos = block_reserve(unsigned(__popc(keep)), counter);
+    const unsigned long long wbase = (unsigned long long)(unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(pos))))) |
+                                     ((unsigned long long)(unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(pos >> 32))))) << 32);   // lane 0's slot = the wave's first
+    const unsigned long long below = (1ull << lx) - 1ull;
+    unsigned rowoff = 0;
 #pragma unroll
-    for (int r = 0; r < SLOPE_ROWS; r++)
-        if (keep & (1u << r)) qnext[pos++] = uint32_t(size_t(ybase + r) * size_t(nx) + size_t(x));
+    for (int r = 0; r < SLOPE_ROWS; r++) {
+        const unsigned long long b = __ballot((keep >> r) & 1u);
+        if ((keep >> r) & 1u) qnext[wbase + rowoff + unsigned(__popcll(b & below))] = uint32_t(size_t(ybase + r) * size_t(nx) + size_t(x));
+        rowoff += unsigned(__popcll(b));
+    }
 }
 
 }  // namespace
