@@ -43,14 +43,20 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     const int ybase = y_own0 + blockIdx.y * (4 * SEED_ROWS) + (threadIdx.x >> 6) * SEED_ROWS;
     const bool colok = x < nx;
     const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    // the lane's window: SEED_ROWS + 2 rows x 3 columns, every load issued before the first use (addresses clamped, validity applied afterwards -
-    // a load behind a row test is a branch, and a lane would then wait for one row at a time); rows outside the array count as nodata
-    float zl[SEED_ROWS + 2], zm[SEED_ROWS + 2], zr[SEED_ROWS + 2];
+    // the lane's window: SEED_ROWS + 2 rows of its own column, every load issued before the first use (addresses clamped, validity applied afterwards -
+    // a load behind a row test is a branch, and a lane would then wait for one row at a time); the columns beside it are the neighbouring lanes'
+    // (one more load per row, in which only lanes 0 and 63 take part, fetches the columns beside the block); rows outside the array count as nodata
+    const int lane = int(threadIdx.x & 63);
+    const bool edge_lane = lane == 0 || lane == 63;
+    const int xe = lane == 0 ? xm : xp;
+    float zm[SEED_ROWS + 2], zedge[SEED_ROWS + 2];
 #pragma unroll
     for (int j = 0; j < SEED_ROWS + 2; j++) {
         const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
         const float* r = Z + size_t(yc) * size_t(nx);
-        zl[j] = r[xm]; zm[j] = r[xc]; zr[j] = r[xp];
+        zm[j] = r[xc];
+        zedge[j] = 0.f;
+        if (edge_lane) zedge[j] = r[xe];
     }
     float wc[SEED_ROWS / SEED_CF];   // MODE 2: the relaxed coarse value of the blocks this lane crosses
     if (MODE == 2) {
@@ -65,7 +71,9 @@ __global__ __launch_bounds__(256) void pit_seed_kernel(const float* __restrict__
     for (int j = 0; j < SEED_ROWS + 2; j++) {
         const int y = ybase - 1 + j;
         const bool in = y >= 0 && y < ny;
-        nod[j] = in ? ((tdxk::is_nodata_f(zl[j], nodata) ? 1u : 0u) | (tdxk::is_nodata_f(zm[j], nodata) ? 2u : 0u) | (tdxk::is_nodata_f(zr[j], nodata) ? 4u : 0u)) : 7u;
+        const int c = tdxk::is_nodata_f(zm[j], nodata) ? 1 : 0, e = tdxk::is_nodata_f(zedge[j], nodata) ? 1 : 0;
+        const int l = tilek::lane_left(c, 0), r = tilek::lane_right(c, 0);
+        nod[j] = in ? (unsigned(lane == 0 ? e : l) | (unsigned(c) << 1) | (unsigned(lane == 63 ? e : r) << 2)) : 7u;
     }
     float bmax[SEED_ROWS / SEED_CF];   // MODE 1: this lane's column of each block row it crosses
     bool bany[SEED_ROWS / SEED_CF], bseed[SEED_ROWS / SEED_CF];
