@@ -10,6 +10,7 @@ import taudem_amd as T
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=16384)
+ap.add_argument("--only", default="", help="comma-separated tool names (default: all)")
 a = ap.parse_args()
 n = a.size
 ctx = T.Context(0)
@@ -27,7 +28,9 @@ dg16 = (torch.rand((n, n), device=dev, generator=g) < 0.01).to(torch.int16)
 dg32 = dg16.to(torch.int32)
 outl = (np.array([n // 2, n // 3], dtype=np.int32), np.array([n - 5, n // 2], dtype=np.int32))
 res = {}
+only = set(x for x in a.only.split(',') if x)
 def timed(name, fn):
+    if only and name not in only: return
     fn()                       # warm-up (scratch allocation)
     torch.cuda.synchronize()
     out = fn()

@@ -299,7 +299,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     // sweeps fan out (a finished cell releases up to eight senders: a wide front, which would overflow the walks' hand-over queue
     // again and again) and run them to the end on every activation.
     if (full || Alg::kBulkOnHalo) {
-        for (int sweep = 0; sweep < Alg::kBulkSweeps; sweep++) {
+        for (int sweep = 0; sweep < g.max_sweeps; sweep++) {   // (TileGeom::max_sweeps carries the policy's kBulkSweeps here; TDX_D8_BULK_SWEEPS overrides it - A/B hook)
             bool prog = false;
 #pragma unroll
             for (int rr = 0; rr < RPL; rr++) {
@@ -587,7 +587,9 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
                int64_t* launches_out, int64_t* outer_out) {
     using Bits = typename BitsOf<sizeof(typename Alg::Cell)>::type;
     hipStream_t s = ctx->stream;
-    const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
+    tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
+    static const int bulk_sweeps_env = getenv("TDX_D8_BULK_SWEEPS") ? std::max(0, atoi(getenv("TDX_D8_BULK_SWEEPS"))) : -1;
+    geom.max_sweeps = bulk_sweeps_env >= 0 ? bulk_sweeps_env : Alg::kBulkSweeps;
     tilek::TileGeom geom32 = geom;
     geom32.tiles_x = (st.nx + 31) / 32; geom32.tiles_y = (st.ny_arr + 31) / 32;
     const size_t ntiles = size_t(geom.tiles_x) * size_t(geom.tiles_y), ntiles32 = size_t(geom32.tiles_x) * size_t(geom32.tiles_y);
@@ -600,6 +602,9 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
     auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
         RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
         if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
+        static const bool print_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
+        runner.print_counts = print_rounds;
+        if (print_rounds) fprintf(stderr, "\nd8 sweep rounds(%d tiles of %d):", runner.ntiles, small ? 32 : 64);
         runner.custom_launch = [&](const tilek::TileGeom& rg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext,
                                    uint32_t* lnext, unsigned pull_max) {
             if (small) hipLaunchKernelGGL((sweep_kernel<Alg, 32, Alg::kMinWaves32>), dim3(grid), dim3(Dim<32>::NT), 0, ls, alg, rg, list, count, fcur, fnext, lnext, pull_max, A);
