@@ -108,6 +108,7 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;     // rounds run on 32 x 32 tiles until this few are active (measured at 16384^2: 6000 -> 16 is 2-3 % faster for every forward tool)
     static constexpr int kMinWaves32 = 4;
+    static constexpr int kMaxRelease = 1;          // cells a finished cell can release (<= 2: their in-tile indices are made once per activation, see Lds::tw)
     // cells whose pending count includes this one: the cell it drains to
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     int mode;            // 0 sum, 1 max, 2 min
@@ -149,6 +150,7 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 5;
+    static constexpr int kMaxRelease = 1;
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
     static __host__ __device__ __forceinline__ float4 outside() { const int m1 = -1; float z; memcpy(&z, &m1, 4); return make_float4(-1.0f, -1.0f, z, 0.f); }
@@ -174,8 +176,10 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
 };
 
 constexpr int QCAP = 512;
+constexpr int QFWD = 128;   // forward policies: only a fork whose branches become ready at once uses the queue
 template <class Alg, int TSZ>
 struct Lds {
+    static constexpr int QLEN = Alg::kMaxRelease <= 2 ? QFWD : QCAP;
     static constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH;
     typename Alg::Cell v[LH * LH];
     typename Alg::Aux aux[Alg::HAS_AUX ? TS * TS : 1];
@@ -183,7 +187,12 @@ struct Lds {
     double rows[Alg::HAS_ROWS ? LH : 1];   // per-row value of the tile's rows and the ring rows, window row ly + 1 (D-infinity: a2 = atan2(dy, dx))
     uint32_t info[TS * TS];
     uint32_t cnt[TS * TS / 4];   // one byte per cell: contributors still pending (255: not a pending cell of this rank)
-    uint16_t q[2][QCAP];         // ready cells handed on to the next phase (a finished cell may release several)
+    // forward policies (a finished cell releases one or two cells): the cells it releases inside the tile, made once per activation - index t0 [0:12)
+    // t1 [12:24), "is in the tile" bits 24 / 25, "outside the tile" bits 26 / 27 - so that a hop of the walks has no direction arithmetic and no branch
+    // around its decrements (a cell that is not there decrements the lane's spare word)
+    uint32_t tw[Alg::kMaxRelease <= 2 ? TS * TS : 1];
+    uint32_t spare[Alg::kMaxRelease <= 2 ? 64 : 1];
+    uint16_t q[2][Alg::kMaxRelease <= 2 ? QFWD : QCAP];   // ready cells handed on to the next phase (a finished cell may release several)
     unsigned nq[2];
     int rim;
     int over;                    // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
@@ -247,8 +256,22 @@ __device__ __forceinline__ void stage_tile(const tilek::TileGeom& g, int tile, L
         }
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
-            S.info[(ry0 + r) * TS + lx] = ((oki >> r) & 1u) ? si[r] : 0u;
+            const unsigned inf = ((oki >> r) & 1u) ? si[r] : 0u;
+            S.info[(ry0 + r) * TS + lx] = inf;
             if (Alg::HAS_AUX) S.aux[(ry0 + r) * TS + lx] = sa[r];
+            if constexpr (Alg::kMaxRelease <= 2) {
+                unsigned tw = 0u, m = Alg::rel_mask(inf);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int k = m ? __ffs(int(m)) : 0;
+                    m &= m - 1u;
+                    if (!k) continue;
+                    const int nx2 = lx + d1(k), ny2 = ry0 + r + d2(k);
+                    if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) tw |= 1u << (26 + t);
+                    else tw |= (unsigned(ny2 * TS + nx2) << (12 * t)) | (1u << (24 + t));
+                }
+                S.tw[(ry0 + r) * TS + lx] = tw;
+            }
         }
         if (Alg::HAS_DIST) {
 #pragma unroll
@@ -338,7 +361,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     __syncthreads();
     // ---- walks: a lane follows a chain as long as it finishes the last pending contributor of a released cell; further cells
     // released by the same step go to the hand-over queue, which the workgroup drains in phases
-    auto walk = [&](int c, int phase) {
+    auto walk_generic = [&](int c, int phase) {
         unsigned inf = S.info[c];
         for (;;) {
             const int ly = c / TS, cx = c % TS, cl = (ly + 1) * LH + cx + 1;
@@ -358,7 +381,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
                 if (next < 0) { next = tc; ninf = tinf; }
                 else {
                     const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
-                    if (slot < unsigned(QCAP)) S.q[phase ^ 1][slot] = uint16_t(tc);
+                    if (slot < unsigned(Lds<Alg, TSZ>::QLEN)) S.q[phase ^ 1][slot] = uint16_t(tc);
                     else S.over = 1;
                 }
             }
@@ -366,10 +389,43 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             c = next; inf = ninf;
         }
     };
+    auto walk_fwd = [&](int c, int phase) {   // kMaxRelease <= 2: the released cells come from the tile's target words
+        unsigned inf = S.info[c], tw = S.tw[c];
+        uint32_t* const spare = &S.spare[tid & 63];
+        for (;;) {
+            const int ly = c / TS, cx = c % TS, cl = (ly + 1) * LH + cx + 1;
+            Cell nb[9];
+            load_nbrs(cl, nb);
+            alg.eval(S, c, cl, ly, inf, nb);
+            if (tw >> 26) out_of_tile(inf, cx, ly);   // releases a cell of a neighbouring tile (cells on the tile's rim only)
+            const int t0 = int(tw & 0xFFFu), t1 = int((tw >> 12) & 0xFFFu);
+            const bool ok0 = ((tw >> 24) & 1u) != 0u, ok1 = Alg::kMaxRelease > 1 && ((tw >> 25) & 1u) != 0u;
+            const unsigned sh0 = 8u * unsigned(t0 & 3), sh1 = 8u * unsigned(t1 & 3);
+            const unsigned old0 = __hip_atomic_fetch_sub(ok0 ? &S.cnt[t0 >> 2] : spare, 1u << sh0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned old1 = 0u, inf1 = 0u, tw1 = 0u;
+            if (Alg::kMaxRelease > 1) old1 = __hip_atomic_fetch_sub(ok1 ? &S.cnt[t1 >> 2] : spare, 1u << sh1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned inf0 = S.info[t0], tw0 = S.tw[t0];
+            if (Alg::kMaxRelease > 1) { inf1 = S.info[t1]; tw1 = S.tw[t1]; }
+            const bool last0 = ok0 && ((old0 >> sh0) & 255u) == 1u, last1 = ok1 && ((old1 >> sh1) & 255u) == 1u;   // its last pending contributor
+            if (last0 && last1) {   // a fork with both branches ready: the second one goes to the queue of the next phase
+                const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
+                if (slot < unsigned(Lds<Alg, TSZ>::QLEN)) S.q[phase ^ 1][slot] = uint16_t(t1);
+                else S.over = 1;
+            }
+            if (!(last0 || last1)) break;
+            c = last0 ? t0 : t1;
+            inf = last0 ? inf0 : inf1;
+            tw = last0 ? tw0 : tw1;
+        }
+    };
+    auto walk = [&](int c, int phase) {
+        if constexpr (Alg::kMaxRelease <= 2) walk_fwd(c, phase);
+        else walk_generic(c, phase);
+    };
     for (unsigned m = readymask; m; m &= m - 1u) walk((ry0 + (__ffs(int(m)) - 1)) * TS + lx, 0);
     for (int phase = 1;; phase ^= 1) {
         __syncthreads();                        // every push into q[phase] has landed
-        const unsigned n = S.nq[phase] < unsigned(QCAP) ? S.nq[phase] : unsigned(QCAP);
+        const unsigned n = S.nq[phase] < unsigned(Lds<Alg, TSZ>::QLEN) ? S.nq[phase] : unsigned(Lds<Alg, TSZ>::QLEN);
         if (n == 0u) break;
         for (unsigned i = tid; i < n; i += unsigned(NT)) walk(int(S.q[phase][i]), phase);
         __syncthreads();                        // q[phase] has been read by everybody

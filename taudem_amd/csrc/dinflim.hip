@@ -65,6 +65,7 @@ struct ConcLimAlg {   // src/DinfConcLimAccum.cpp:226-262; record = {ctpt, q, dm
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
+    static constexpr int kMaxRelease = 2;
     float dm_nodata, q_nodata, csol;
     int contcheck;
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
@@ -106,6 +107,7 @@ struct TransLimAlg {   // src/DinfTransLimAccum.cpp:236-307; record = {tla, csou
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
+    static constexpr int kMaxRelease = 2;
     float tsup_nodata, tc_nodata, cin_nodata;
     int usec, contcheck;
     const float* cin_src;   // the input concentration raster (null without -cs): what slot w held before the evaluation turned it into the deposition

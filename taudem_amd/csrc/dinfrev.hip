@@ -70,6 +70,7 @@ struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
     static constexpr int kBulkSweeps = 1 << 20;      // to the end: the reverse sweep is a wide front (d8_sweep.hpp)
     static constexpr bool kBulkOnHalo = true;
     static constexpr int kMinWaves32 = 5;
+    static constexpr int kMaxRelease = 8;
     static constexpr unsigned kBulkUntil = 64;       // a wide front of thousands of tiles to the very end: several small tiles per CU beat one large one (489 -> 380 ms at 16384^2)
     static __device__ __forceinline__ float head(float c) { return c; }
     static __host__ __device__ __forceinline__ float outside() { return -1.0f; }
@@ -104,6 +105,7 @@ struct RevAccAlg {   // src/DinfRevAccum.cpp:176-199; record = {racc, dmax}
     static constexpr bool kBulkOnHalo = true;
     static constexpr unsigned kBulkUntil = 64;
     static constexpr int kMinWaves32 = 4;
+    static constexpr int kMaxRelease = 8;
     float w_nodata;
     static __device__ __forceinline__ float head(const float2& c) { return c.x; }
     static __host__ __device__ __forceinline__ float2 outside() { return make_float2(TDX_ANG_NODATA, TDX_ANG_NODATA); }
