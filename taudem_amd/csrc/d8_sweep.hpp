@@ -149,7 +149,7 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr int kBulkSweeps = BULK_SWEEPS;
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
-    static constexpr int kMinWaves32 = 5;
+    static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 1;
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { const unsigned code = (inf >> 9) & 15u; return (code >= 1u && code <= 8u) ? 1u << (code - 1u) : 0u; }
     static __device__ __forceinline__ float head(const float4& c) { return c.x; }
@@ -447,7 +447,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
 
 // MINW: waves per SIMD the register allocation is held to (= 256-thread tiles per CU of the 32 x 32 geometry; policy constant kMinWaves32):
 // 4 is what the kernels take by themselves (107-117 VGPRs); 5 (<= 102 VGPRs) puts a fifth tile on a CU where the LDS allows it - measured
-// per policy at 16384^2 (profiles/r03k_*): GridNet 64.0 -> 60.0 ms (3 spilled registers), DinfUpDependence 381 -> 376 ms (2), DinfRevAccum
+// per policy at 16384^2 (profiles/r03k_*): GridNet 64.0 -> 60.0 ms (3 spilled registers; with the target words of round 4 eleven, and 4 is as fast: 59 ms), DinfUpDependence 381 -> 376 ms (2), DinfRevAccum
 // slower (10 spills), the limited accumulations are LDS-bound at 4 tiles, weighted AreaD8 / ExtremeUp need 88 VGPRs anyway
 template <class Alg, int TSZ, int MINW = 4>
 __global__ __launch_bounds__(Dim<TSZ>::NT, MINW) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
