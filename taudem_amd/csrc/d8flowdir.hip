@@ -342,12 +342,12 @@ __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restric
 __global__ __launch_bounds__(256) void d8_recollect_kernel(const int16_t* __restrict__ P, const uint32_t* __restrict__ list,
                                                            unsigned long long nq, uint32_t* __restrict__ out,
                                                            unsigned long long* __restrict__ counter) {
-    const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
+    const unsigned long long q0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 8;   // eight consecutive entries per thread: the list keeps its order
     uint32_t keep[8];
     unsigned cnt = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const unsigned long long q = base + (unsigned long long)i * 256;
+        const unsigned long long q = q0 + (unsigned long long)i;
         if (q < nq) {
             const uint32_t c = list[q];
             if (P[c] == 0) keep[cnt++] = c;

@@ -189,22 +189,38 @@ __device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, T
 __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, lvl_t* __restrict__ lvl,
                                                                  lvl_t* __restrict__ rq, uint32_t* __restrict__ list,
                                                                  unsigned long long* __restrict__ counter) {
-    const size_t base = first + size_t(blockIdx.x) * (256 * 8) + threadIdx.x;   // cells [first, n): the owned rows
+    // a thread takes EIGHT CONSECUTIVE cells (and block_reserve hands out slots in thread order), so the list is in raster order: the list kernels of
+    // flat resolution gather the 3 x 3 windows of 64 consecutive entries per wave - with a thread's cells 256 apart, as they were, consecutive entries
+    // alternated between eight distant places
+    const size_t c0 = first + (size_t(blockIdx.x) * 256 + threadIdx.x) * 8;   // cells [first, n): the owned rows
     unsigned mask = 0;
+    float a[8];
+    const bool whole = c0 + 8 <= n && (c0 & 3u) == 0;   // (16-byte loads / stores: hipMalloc'ed rasters)
+    if (whole) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ANG + c0), a1 = *reinterpret_cast<const float4*>(ANG + c0 + 4);
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const size_t c = base + size_t(i) * 256;
-        if (c < n) {
-            const bool f = dinf_is_flat(ANG[c]);
-            lvl[c] = f ? 0 : -1;
-            rq[c] = f ? 0 : -1;
-            if (f) mask |= 1u << i;
-        }
+        for (int i = 0; i < 8; i++) a[i] = c0 + i < n ? ANG[c0 + i] : TDX_ANG_NODATA;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (c0 + i < n && dinf_is_flat(a[i])) mask |= 1u << i;
+    if (whole && (c0 & 7u) == 0) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = (((mask >> (2 * j)) & 1u) ? 0u : 0xFFFFu) | (((mask >> (2 * j + 1)) & 1u) ? 0u : 0xFFFF0000u);   // 0 in the queue, -1 outside
+        *reinterpret_cast<uint4*>(lvl + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(rq + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (c0 + i < n) { const lvl_t m = ((mask >> i) & 1u) ? lvl_t(0) : lvl_t(-1); lvl[c0 + i] = m; rq[c0 + i] = m; }
     }
     unsigned long long pos = block_reserve(unsigned(__popc(mask)), counter);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (mask & (1u << i)) list[pos++] = uint32_t(base + size_t(i) * 256);
+        if (mask & (1u << i)) list[pos++] = uint32_t(c0 + size_t(i));
 }
 
 __global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
@@ -289,12 +305,12 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
 __global__ __launch_bounds__(256) void dinf_recollect_kernel(const float* __restrict__ ANG, const uint32_t* __restrict__ list,
                                                              unsigned long long nq, uint32_t* __restrict__ out,
                                                              unsigned long long* __restrict__ counter) {
-    const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
+    const unsigned long long q0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 8;   // eight consecutive entries per thread: the list keeps its (raster) order
     uint32_t keep[8];
     unsigned cnt = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const unsigned long long q = base + (unsigned long long)i * 256;
+        const unsigned long long q = q0 + (unsigned long long)i;
         if (q < nq) {
             const uint32_t c = list[q];
             if (dinf_is_flat(ANG[c])) keep[cnt++] = c;
