@@ -163,33 +163,43 @@ __global__ __launch_bounds__(1024) void flat_scan_kernel(unsigned* __restrict__ 
 }
 __global__ __launch_bounds__(256) void flat_list_kernel(const flatmask_t* __restrict__ bits, size_t nmasks, int nx, int y_own0, int seg, const unsigned* __restrict__ blockoff,
                                                         uint32_t* __restrict__ list) {
+    // The block's 2048 masks are 32 groups of 64 neighbouring columns (chunk i, wave w); the list takes them group by group and, within a group, ROW BY ROW, so that
+    // consecutive entries are neighbouring cells of a raster row (mask by mask - a column's rows - every entry of a wave of the list kernels sat in a row of its own).
+    constexpr int NCH = FLATQ_PER_BLOCK / 256;
     const size_t base = size_t(blockIdx.x) * FLATQ_PER_BLOCK + threadIdx.x;
-    unsigned mk[FLATQ_PER_BLOCK / 256];
-    unsigned c = 0;
+    const int lane = int(threadIdx.x & 63), w = int(threadIdx.x >> 6);
+    unsigned mk[NCH];
+    __shared__ unsigned scnt[NCH][4];
 #pragma unroll
-    for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
+    for (int i = 0; i < NCH; i++) {
         const size_t m = base + size_t(i) * 256;
         mk[i] = m < nmasks ? bits[m] : 0u;
-        c += unsigned(__popc(mk[i]));
-    }
-    unsigned v = c;
+        unsigned c = unsigned(__popc(mk[i]));
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned t = __shfl_up(v, off, 64);
-        if (int(threadIdx.x & 63) >= off) v += t;
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (lane == 0) scnt[i][w] = c;
     }
-    __shared__ unsigned sw[4];
-    if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = v;
     __syncthreads();
-    unsigned pos = blockoff[blockIdx.x] + v - c;
-    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) pos += sw[w];
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < FLATQ_PER_BLOCK / 256; i++) {
-        if (!mk[i]) continue;
-        const size_t m = base + size_t(i) * 256;
-        const unsigned band = unsigned(m / size_t(nx)), x = unsigned(m - size_t(band) * size_t(nx));
+    for (int i = 0; i < NCH; i++) {
+        unsigned any = mk[i];   // rows in which some column of the group has a flat cell (wave-uniform)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) any |= __shfl_xor(any, off, 64);
+        if (!any) continue;
+        unsigned pos = blockoff[blockIdx.x];
+        for (int j = 0; j < i; j++) pos += scnt[j][0] + scnt[j][1] + scnt[j][2] + scnt[j][3];
+        for (int u = 0; u < w; u++) pos += scnt[i][u];
+        const size_t m = base + size_t(i) * 256, mc = m < nmasks ? m : nmasks - 1;
+        const unsigned band = unsigned(mc / size_t(nx)), x = unsigned(mc - size_t(band) * size_t(nx));
         const size_t c0 = size_t(y_own0 + int(band) * seg) * size_t(nx) + size_t(x);
-        for (unsigned b = mk[i]; b; b &= b - 1u) list[pos++] = uint32_t(c0 + size_t(__ffs(int(b)) - 1) * size_t(nx));
+        for (unsigned rows = any; rows; rows &= rows - 1u) {
+            const int r = __ffs(int(rows)) - 1;
+            const bool mine = (mk[i] >> r) & 1u;
+            const unsigned long long b = __ballot(mine);
+            if (mine) list[pos + unsigned(__popcll(b & below))] = uint32_t(c0 + size_t(r) * size_t(nx));
+            pos += unsigned(__popcll(b));
+        }
     }
 }
 
@@ -554,7 +564,8 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     // raster at BASELINE.json configs[1]) is classified, evaluated (level statistics) and re-directed by streaming passes, and the marker
     // reset of a later iteration rewrites the whole strip anyway (flats_reset_markers_after).  The choice is this rank's own: nothing that
     // is exchanged depends on it.
-    const bool have_list = nq <= n / 16;
+    const bool force_list = getenv("TDX_FLATS_LIST") != nullptr;   // (test hook, read per call: the first queue as a list for a dense queue too)
+    const bool have_list = force_list || nq <= n / 16;
     if (total > 0 && nq > 0 && have_list) {
         TdxSpan sp(ctx, TDX_K_MISC);
         hipLaunchKernelGGL(flat_list_kernel, dim3(nqblocks), dim3(256), 0, s, flatbits, nmasks, inx, st.y0, seg, blocksum, qlist);

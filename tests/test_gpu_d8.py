@@ -59,6 +59,36 @@ def test_pipeline_vs_oracle(shape, seed, ctx, oracle):
         assert bits_equal(a, a_o), describe_diff(a, a_o, f"ad8 contcheck={cc}")
 
 
+@pytest.mark.parametrize("shape,seed", [((257, 301), 5), ((1000, 777), 7), ((96, 4100), 9)])
+def test_first_flat_queue_as_a_list(shape, seed, ctx, oracle, monkeypatch):
+    """A dense first flat queue never exists as a list (bit masks + streaming passes); TDX_FLATS_LIST=1 builds it anyway (flat_list_kernel: the path of
+    rasters with few flats) - same directions, same counts."""
+    dem = oracle.synth_dem(shape, seed)
+    fel_o = oracle.pitremove(dem, -9999.0)
+    p_o, sd8_o, st_o = oracle.d8flowdir(fel_o, -3.0e38, 30.0, 30.0)
+    monkeypatch.setenv("TDX_FLATS_LIST", "1")
+    p, sd8, st = ctx.d8flowdir(fel_o, -3.0e38, 30.0, 30.0, stats=True)
+    assert st["flats_initial"] == st_o["flats_initial"] and st["flat_iterations"] == st_o["flat_iterations"]
+    assert bits_equal(sd8, sd8_o), describe_diff(sd8, sd8_o, "sd8")
+    assert bits_equal(p, p_o), describe_diff(p, p_o, "p")
+
+
+def test_few_flats_take_the_list_kernels(ctx, oracle):
+    """A raster whose flats are a few patches on a slope (well under 1/32 of the cells): the first queue is a list, setFlow2 and the statistics run on it."""
+    ny, nx = 300, 420
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    dem = (1000.0 - 0.5 * xx - 0.31 * yy + 0.2 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.float32)
+    for (y0, x0, h, w) in ((20, 30, 9, 14), (100, 200, 17, 6), (180, 90, 5, 40), (250, 300, 12, 12), (60, 350, 3, 3)):
+        dem[y0:y0 + h, x0:x0 + w] = dem[y0:y0 + h, x0:x0 + w].min()
+    fel_o = oracle.pitremove(dem, -9999.0)
+    p_o, sd8_o, st_o = oracle.d8flowdir(fel_o, -3.0e38, 30.0, 30.0)
+    assert 0 < st_o["flats_initial"] < dem.size // 32
+    p, sd8, st = ctx.d8flowdir(fel_o, -3.0e38, 30.0, 30.0, stats=True)
+    assert st["flats_initial"] == st_o["flats_initial"] and st["flat_iterations"] == st_o["flat_iterations"] and st["flats_left"] == st_o["flats_left"]
+    assert bits_equal(sd8, sd8_o), describe_diff(sd8, sd8_o, "sd8")
+    assert bits_equal(p, p_o), describe_diff(p, p_o, "p")
+
+
 def test_round_schedule_count_ring_wraps(ctx, oracle, monkeypatch):
     """The per-round count ring of the tile engine wraps (tiny ring, no coarse start: many rounds) without losing the pending round."""
     dem = oracle.synth_dem((700, 900), 31)
