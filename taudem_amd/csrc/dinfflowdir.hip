@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
     const size_t c0 = first + (size_t(blockIdx.x) * 256 + threadIdx.x) * 8;   // cells [first, n): the owned rows
     unsigned mask = 0;
     float a[8];
-    const bool whole = c0 + 8 <= n && (c0 & 3u) == 0;   // (16-byte loads / stores: hipMalloc'ed rasters)
+    const bool whole = c0 + 8 <= n && (reinterpret_cast<uintptr_t>(ANG + c0) & 15u) == 0;   // (16-byte loads: the caller's raster may start anywhere)
     if (whole) {
         const float4 a0 = *reinterpret_cast<const float4*>(ANG + c0), a1 = *reinterpret_cast<const float4*>(ANG + c0 + 4);
         a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (c0 + i < n && dinf_is_flat(a[i])) mask |= 1u << i;
-    if (whole && (c0 & 7u) == 0) {
+    if (c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) w[j] = (((mask >> (2 * j)) & 1u) ? 0u : 0xFFFFu) | (((mask >> (2 * j + 1)) & 1u) ? 0u : 0xFFFF0000u);   // 0 in the queue, -1 outside
