@@ -89,6 +89,23 @@ def test_few_flats_take_the_list_kernels(ctx, oracle):
     assert bits_equal(p, p_o), describe_diff(p, p_o, "p")
 
 
+def test_distance_table_follows_the_cell_sizes(ctx, oracle):
+    """The D8 distance table stays on the device between calls with the same cell sizes (tdx_build_fact_table): other sizes, other rows, the old sizes
+    again - each call matches the restatement."""
+    dem = oracle.synth_dem((180, 240), 11)
+    fel = oracle.pitremove(dem, -9999.0)
+    rows = np.linspace(20.0, 35.0, 180)
+    for dx, dy in ((30.0, 30.0), (10.0, 25.0), (30.0, 30.0), (rows, 28.0), (rows[::-1].copy(), 28.0), (10.0, 25.0)):
+        p_o, sd8_o, _ = oracle.d8flowdir(fel, -3.0e38, dx, dy)
+        p, sd8 = ctx.d8flowdir(fel, -3.0e38, dx, dy)
+        assert bits_equal(sd8, sd8_o), describe_diff(sd8, sd8_o, "sd8")
+        assert bits_equal(p, p_o), describe_diff(p, p_o, "p")
+    fel2 = oracle.pitremove(oracle.synth_dem((90, 240), 12), -9999.0)   # fewer rows with the same leading cell sizes
+    p_o, sd8_o, _ = oracle.d8flowdir(fel2, -3.0e38, 10.0, 25.0)
+    p, sd8 = ctx.d8flowdir(fel2, -3.0e38, 10.0, 25.0)
+    assert bits_equal(sd8, sd8_o) and bits_equal(p, p_o)
+
+
 def test_round_schedule_count_ring_wraps(ctx, oracle, monkeypatch):
     """The per-round count ring of the tile engine wraps (tiny ring, no coarse start: many rounds) without losing the pending round."""
     dem = oracle.synth_dem((700, 900), 31)
