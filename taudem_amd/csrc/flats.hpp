@@ -127,6 +127,11 @@ struct LevelPlainT {
     static __device__ __forceinline__ int cell_floor(int lock, int v) { return lock == 0 ? 0 : v; }
     static __device__ __forceinline__ int apply(int lock, int own, int m) { return tilek::med3_raw(m + 1, lock, own); }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
+    // activation filter (tile_relax.hpp): a halo cell that may move (mask != 0) improves from a neighbour value below its own level - 1
+    static __device__ __forceinline__ int act_never() { return int(0x80000000u); }
+    static __device__ __forceinline__ int act_threshold(uint8_t m, int v) { return m ? v - 1 : act_never(); }
+    // ... and the value alone says as much: -1 = outside the queue, a seed's level (1, 2) is below every new value
+    static __device__ __forceinline__ int act_threshold_raw(S g) { return g >= 0 ? decode(g) - 1 : act_never(); }
 };
 
 template <int INC, class S>   // INC 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
@@ -156,6 +161,11 @@ struct LevelOpT {
     }
     static __device__ __forceinline__ int cell_floor(int cst, int) { return cst; }
     static __device__ __forceinline__ bool settled(int, int v) { return v <= 1; }
+    // activation filter (tile_relax.hpp): a halo cell with a mask improves from a neighbour value below its own value - INC (whichever neighbours the mask selects)
+    static __device__ __forceinline__ int act_never() { return int(0x80000000u); }
+    static __device__ __forceinline__ int act_threshold(uint8_t m, int v) { return m ? v - INC : act_never(); }
+    // ... and the value alone says as much: a negative marker = outside the queue, a seed's value is below every new value
+    static __device__ __forceinline__ int act_threshold_raw(S g) { return g >= 0 ? decode(g) - INC : act_never(); }
 };
 using LevelOp = LevelOpT<1, lvl_t>;
 using ReachOp = LevelOpT<0, int32_t>;

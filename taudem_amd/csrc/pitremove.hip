@@ -201,6 +201,9 @@ struct PitOp {
     static __device__ __forceinline__ float cell_floor(float z, float w) { return (w > z) ? z : w; }
     static __device__ __forceinline__ float apply(float z, float w, float m) { return tilek::med3_raw(z, w, m); }
     static __device__ __forceinline__ bool settled(float z, float w) { return !(w > z); }
+    // activation filter (tile_relax.hpp): a halo cell that still stands above its elevation comes down for a neighbour value below its own
+    static __device__ __forceinline__ float act_never() { return -FLT_MAX; }
+    static __device__ __forceinline__ float act_threshold(float z, float w) { return (w > z) ? w : act_never(); }
 };
 
 }  // namespace
