@@ -381,36 +381,65 @@ __global__ __launch_bounds__(256) void setup_out_kernel(const float* __restrict_
     P[idx] = pp;
     if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
 }
-__global__ __launch_bounds__(256) void setup_in_kernel(const uint8_t* __restrict__ code, int nx, int ny, uint32_t* __restrict__ info) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= ny) return;
-    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    unsigned c[9];
+// per cell: which neighbours send to it (and whether as their first or second target), whether a neighbour is missing, its own targets - from the code bytes of its 3 x 3
+// window.  62-column window like the streaming passes of d8flowdir.hip: a lane loads ONE code byte per window row (18 for 16 output rows, all before the first use), the
+// columns beside it are the neighbouring lanes' (the per-cell form loaded nine bytes per cell: 4.8 ms at 32768^2).
+constexpr int SIN_COLS = 62, SIN_ROWS = 16;
+__global__ __launch_bounds__(256) void setup_in_kernel(const uint8_t* __restrict__ code, int nx, int ny, uint32_t* __restrict__ info, int nbx, int xmap) {
+    using tilek::lane_left;
+    using tilek::lane_right;
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
+    const int lx = threadIdx.x & 63;
+    const int x = bx * SIN_COLS - 1 + lx;
+    const int ybase = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * (4 * SIN_ROWS) + int(threadIdx.x >> 6) * SIN_ROWS);
+    const bool mine = lx >= 1 && lx <= SIN_COLS && x < nx;
+    const bool inx = x >= 0 && x < nx;
+    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+    int cw[SIN_ROWS + 2];
 #pragma unroll
-    for (int k = 1; k <= 8; k++) {   // all loads first (clamped), validity afterwards
-        const int xn = x + d1(k), yn = y + d2(k);
-        const bool in = xn >= 0 && xn < nx && yn >= 0 && yn < ny;
-        c[k] = code[size_t(in ? yn : y) * size_t(nx) + size_t(in ? xn : x)];
-        if (!in) c[k] = DINF_CODE_NODATA;
+    for (int j = 0; j < SIN_ROWS + 2; j++) {
+        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        cw[j] = code[size_t(yc) * size_t(nx) + size_t(xc)];
     }
-    const unsigned own = code[idx];
-    unsigned inf = 0;
 #pragma unroll
-    for (int k = 1; k <= 8; k++) {
-        if (dinf_code_missing(c[k])) inf |= 0x100u;          // (a sink on a cell without angle: missing for the contamination test, sends nothing)
-        if (c[k] == DINF_CODE_NODATA) continue;
-        const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
-        const int via = dinf_code_sends(c[k], kk == 0 ? 8 : kk);
-        if (via) inf |= 1u << (k - 1);
-        if (via == 2) inf |= 1u << (16 + k - 1);                       // not its first target: its second
+    for (int j = 0; j < SIN_ROWS + 2; j++) {
+        const int y = ybase - 1 + j;
+        if (!inx || y < 0 || y >= ny) cw[j] = DINF_CODE_NODATA;   // outside the raster
     }
-    if (own != DINF_CODE_NODATA && (own & DINF_CODE_PART)) {
-        inf |= (own & 7u) << 9;
-        if (own & DINF_CODE_P1) inf |= 1u << 12;
-        if (own & DINF_CODE_P2) inf |= 1u << 13;
+#pragma unroll
+    for (int r = 0; r < SIN_ROWS; r++) {
+        const int y = ybase + r;
+        // window in the order of the neighbour index k = 1 .. 8 (E NE N NW W SW S SE)
+        const int n1 = cw[r], c1 = cw[r + 1], s1 = cw[r + 2];
+        unsigned c[9];
+        c[1] = unsigned(lane_right(c1, int(DINF_CODE_NODATA)));
+        c[2] = unsigned(lane_right(n1, int(DINF_CODE_NODATA)));
+        c[3] = unsigned(n1);
+        c[4] = unsigned(lane_left(n1, int(DINF_CODE_NODATA)));
+        c[5] = unsigned(lane_left(c1, int(DINF_CODE_NODATA)));
+        c[6] = unsigned(lane_left(s1, int(DINF_CODE_NODATA)));
+        c[7] = unsigned(s1);
+        c[8] = unsigned(lane_right(s1, int(DINF_CODE_NODATA)));
+        if (!(mine && y < ny)) continue;
+        const unsigned own = unsigned(c1);
+        unsigned inf = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+            if (dinf_code_missing(c[k])) inf |= 0x100u;          // (a sink on a cell without angle: missing for the contamination test, sends nothing)
+            if (c[k] == DINF_CODE_NODATA) continue;
+            const int kk = (k + 4) % 8;                                   // direction from the neighbour to this cell
+            const int via = dinf_code_sends(c[k], kk == 0 ? 8 : kk);
+            if (via) inf |= 1u << (k - 1);
+            if (via == 2) inf |= 1u << (16 + k - 1);                       // not its first target: its second
+        }
+        if (own != DINF_CODE_NODATA && (own & DINF_CODE_PART)) {
+            inf |= (own & 7u) << 9;
+            if (own & DINF_CODE_P1) inf |= 1u << 12;
+            if (own & DINF_CODE_P2) inf |= 1u << 13;
+        }
+        info[size_t(y) * size_t(nx) + size_t(x)] = inf;
     }
-    info[idx] = inf;
 }
 
 __device__ __forceinline__ bool pending(float v) { return __float_as_uint(v) == DINF_PENDING_BITS; }
@@ -625,7 +654,9 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             if (!code) return TDX_ERR_NOMEM;
             hipLaunchKernelGGL(dsweep::setup_out_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, ang_use, n, inx, st.y0, st.y1, ang_nodata, d_rows, code, d_P, d_out,
                                out_nodata);
-            hipLaunchKernelGGL(dsweep::setup_in_kernel, dim3((inx + 63) / 64, (iny + 3) / 4), dim3(256), 0, s, code, inx, iny, info32);
+            const int sin_nbx = (inx + dsweep::SIN_COLS - 1) / dsweep::SIN_COLS;
+            hipLaunchKernelGGL(dsweep::setup_in_kernel, dim3(tdx_xcd_grid_x(unsigned(sin_nbx)), (iny + 4 * dsweep::SIN_ROWS - 1) / (4 * dsweep::SIN_ROWS)), dim3(256), 0, s, code, inx, iny,
+                               info32, sin_nbx, tdx_xcd_map() ? 1 : 0);
         }
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
