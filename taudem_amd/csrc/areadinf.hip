@@ -381,6 +381,30 @@ __global__ __launch_bounds__(256) void setup_out_kernel(const float* __restrict_
     P[idx] = pp;
     if (y >= y_own0 && y < y_own1) OUT[idx] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
 }
+// four cells per thread (a raster whose width is a multiple of 4 on 16-byte boundaries): one 16-byte load, four 16-byte proportion stores, a 4-byte code store, one 16-byte
+// store of the pending pattern - a quarter of the memory instructions of the one-cell form
+__global__ __launch_bounds__(256) void setup_out4_kernel(const float* __restrict__ ANG, size_t n, int nx, int y_own0, int y_own1, float nodata,
+                                                         const RowProp* __restrict__ rows, uint8_t* __restrict__ code, double2* __restrict__ P,
+                                                         float* __restrict__ OUT, float out_nodata) {
+    const size_t idx = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (idx >= n) return;
+    const int y = int(idx / size_t(nx));   // (nx % 4 == 0: the four cells are in one row)
+    const float4 a4 = *reinterpret_cast<const float4*>(ANG + idx);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+    const double a2 = rows[y].a2;
+    unsigned cw = 0;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool nd = is_nodata_f(a[i], nodata), part = !(nd || a[i] == ANG_OUTSIDE);
+        double2 pp;
+        cw |= (unsigned(dinf_code(a[i], nd, part, a2, &pp.x, &pp.y)) & 0xFFu) << (8 * i);
+        P[idx + i] = pp;
+        o[i] = part ? __uint_as_float(DINF_PENDING_BITS) : out_nodata;
+    }
+    *reinterpret_cast<uint32_t*>(code + idx) = cw;
+    if (y >= y_own0 && y < y_own1) *reinterpret_cast<float4*>(OUT + idx) = make_float4(o[0], o[1], o[2], o[3]);
+}
 // per cell: which neighbours send to it (and whether as their first or second target), whether a neighbour is missing, its own targets - from the code bytes of its 3 x 3
 // window.  62-column window like the streaming passes of d8flowdir.hip: a lane loads ONE code byte per window row (18 for 16 output rows, all before the first use), the
 // columns beside it are the neighbouring lanes' (the per-cell form loaded nine bytes per cell: 4.8 ms at 32768^2).
@@ -652,8 +676,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         {
             uint8_t* code = static_cast<uint8_t*>(ctx->scratch(TDX_S_B, n));
             if (!code) return TDX_ERR_NOMEM;
-            hipLaunchKernelGGL(dsweep::setup_out_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, ang_use, n, inx, st.y0, st.y1, ang_nodata, d_rows, code, d_P, d_out,
-                               out_nodata);
+            if (inx % 4 == 0 && ((reinterpret_cast<uintptr_t>(ang_use) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0)
+                hipLaunchKernelGGL(dsweep::setup_out4_kernel, dim3(tdx_blocks_for(n / 4, 256)), dim3(256), 0, s, ang_use, n, inx, st.y0, st.y1, ang_nodata, d_rows, code, d_P,
+                                   d_out, out_nodata);
+            else
+                hipLaunchKernelGGL(dsweep::setup_out_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, ang_use, n, inx, st.y0, st.y1, ang_nodata, d_rows, code, d_P, d_out,
+                                   out_nodata);
             const int sin_nbx = (inx + dsweep::SIN_COLS - 1) / dsweep::SIN_COLS;
             hipLaunchKernelGGL(dsweep::setup_in_kernel, dim3(tdx_xcd_grid_x(unsigned(sin_nbx)), (iny + 4 * dsweep::SIN_ROWS - 1) / (4 * dsweep::SIN_ROWS)), dim3(256), 0, s, code, inx, iny,
                                info32, sin_nbx, tdx_xcd_map() ? 1 : 0);
