@@ -5,8 +5,9 @@
 //                        "neighbour points back" branch is unreachable, so the
 //                        pass is a pure per-cell function of the 3x3 window.
 //   flat resolution      resolveflats (src/d8.cpp:459-680).  The reference re-sweeps every flat cell
-//                        once per level (N^1.5); both of its relaxations are breadth-first levels, so
-//                        they run here as frontier BFS with one launch per level:
+//                        once per level (N^1.5); both of its relaxations are breadth-first level fields -
+//                        fixed points of a monotone operator - and run on the tile relaxation engine
+//                        (flats.hpp, tile_relax.hpp: 64 x 64 tiles to their local fixed point, rounds):
 //                          incfall: elev2(c) = level at which c stops incrementing
 //                                   level 1  = a non-crossing neighbour is <= and has a direction
 //                                   level 2 += an equal, non-crossing neighbour that is NOT a flat cell
@@ -16,7 +17,10 @@
 //                                   8-connected flat cells; s(c) = Tr - q(c) + 1
 //                        The sweep counts T, Tr of the reference's loops are reconstructed from the
 //                        level counts (they leak into the artificial elevations of pits and into s).
+//   classification       d8_classify_stream_kernel (a dense queue: one pass over the strip) / flatk::classify_kernel
+//                        (a list): seeds of both fields, eligibility masks, activation flags of the tiles
 //   d8_setflow2_kernel   setFlow2 (src/d8.cpp:412-454) per flat cell on the artificial surface
+//                        (d8_setflow2_stream_kernel for a dense queue; it also writes the next iteration's list)
 //   outer iteration      while flats decrease: overwrite the WHOLE elevation grid with (float)elev2
 //                        (src/d8.cpp:669-675) and repeat (src/d8.cpp:300-317)
 #include <cstring>
