@@ -10,10 +10,11 @@
 //   * pit_seed_kernel    streaming 3x3 stencil: Z -> W0                 (src/flood.cpp:243-271); with the coarse-to-fine start: Z -> first
 //                        coarse level, and later Z + relaxed coarse level -> start surface
 //   * tilek::relax_kernel<PitOp>  the tile relaxation engine of tile_relax.hpp: one workgroup per
-//                        ACTIVE 64x64 tile, W tile + halo in LDS, Z in registers, chaotic in-LDS
-//                        relaxation to the tile-local fixed point, write-back of changed cells; tiles
-//                        whose rim changed re-activate their neighbours; rounds are chained on the
-//                        device (no host round trip per round)
+//                        ACTIVE 64x64 tile, W and Z of a lane's 16-row column segment in registers
+//                        (neighbour columns = neighbour lanes, LDS only between the four waves),
+//                        relaxation to the tile-local fixed point, write-back of changed cells; a tile
+//                        whose rim changed re-activates the neighbours it can still improve; rounds are
+//                        chained on the device (no host round trip per round)
 //
 // HBM traffic per activation of a tile = 2 tile images in + changed cells out; rounds ~ longest fill
 // path measured in tiles.
