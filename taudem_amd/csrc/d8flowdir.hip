@@ -390,7 +390,8 @@ constexpr int SF2_COLS = 62;
 __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
                                                                  const double* __restrict__ fact, const lvl_t* __restrict__ lvl,
                                                                  const lvl_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
-                                                                 uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter, int nbx, int xmap) {
+                                                                 uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter, int nbx, int xmap,
+                                                                 lvl_t* __restrict__ lvl_next, lvl_t* __restrict__ rq_next) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int bx = tdxk::xcd_block_x(nbx, xmap);
@@ -465,6 +466,19 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
 #undef TDX_SF2
                 P[size_t(y) * size_t(nx) + size_t(x)] = dir;
                 if (dir == 0) keep |= 1u << r;
+            }
+        }
+    }
+    // The markers of the NEXT iteration (0 on the cells that are still flat, -1 elsewhere) go to a second pair of rasters on the way: the pass visits every owned
+    // cell anyway, and two fills of the level rasters plus the list pass that re-marked the queue were 0.27 ms of the second iteration at 16384^2
+    if (lvl_next != nullptr) {
+#pragma unroll
+        for (int r = 0; r < SLOPE_ROWS; r++) {
+            if (mine && ybase + r < y_own1) {
+                const size_t idx = size_t(ybase + r) * size_t(nx) + size_t(x);
+                const lvl_t m = ((keep >> r) & 1u) ? lvl_t(0) : lvl_t(-1);
+                lvl_next[idx] = m;
+                rq_next[idx] = m;
             }
         }
     }
@@ -590,6 +604,8 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
         bool sparse = false;                // this iteration works from lists (few flats left): no pass over the whole raster
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
         bool old_list_valid = false;        // ... and whether qnext really holds them
+        lvl_t *lvl_next = nullptr, *rq_next = nullptr;   // the next iteration's markers, written by the streaming setFlow2 (rasters of their own)
+        bool markers_ready = false;
         for (;;) {
             // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
             FlatLevels fl;
@@ -601,11 +617,21 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
                                    rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0);
             };
-            if (sparse) {
+            if (sparse && markers_ready) {
+                // the streaming setFlow2 of the previous iteration left this iteration's markers in the second pair of rasters
+                std::swap(lvl, lvl_next);
+                std::swap(rq, rq_next);
+                fbuf = FlatBuffers{lvl, rq};
+                rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows (flats_reset_markers)
+                if (rc != TDX_OK) return rc;
+                rc = strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
+                if (rc != TDX_OK) return rc;
+            } else if (sparse) {
                 // the previous queue exists as a list only if it was built (first queue of a dense strip: bit masks only) - without one every marker is rewritten
                 rc = old_list_valid ? flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq) : flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
                 if (rc != TDX_OK) return rc;
             }
+            markers_ready = false;
             // (the first queue of a dense strip exists as bit masks only: no list)
             rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
             if (rc != TDX_OK) return rc;
@@ -615,8 +641,15 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                 if (nq > n / 32) {   // dense queue: one streaming pass
                     const int nbx = (st.nx + SF2_COLS - 1) / SF2_COLS;
                     const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
+                    static const bool no_next = getenv("TDX_FLATS_NO_NEXT_MARKERS") != nullptr;   // (A/B hook)
+                    if (!no_next && !lvl_next) {
+                        lvl_next = static_cast<lvl_t*>(ctx->scratch(TDX_S_P, n * sizeof(lvl_t)));
+                        rq_next = static_cast<lvl_t*>(ctx->scratch(TDX_S_R, n * sizeof(lvl_t)));
+                        if (!lvl_next || !rq_next) return TDX_ERR_NOMEM;
+                    }
                     hipLaunchKernelGGL(d8_setflow2_stream_kernel, grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
-                                       d_cnt, nbx, tdx_xcd_map() ? 1 : 0);
+                                       d_cnt, nbx, tdx_xcd_map() ? 1 : 0, lvl_next, rq_next);
+                    markers_ready = lvl_next != nullptr;
                 } else if (nq) {
                     if (fl.has_pits)
                         hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
