@@ -108,6 +108,25 @@ def aread8(p, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=Tru
     return ad8
 
 
+def pitremove_check(dem, fel, nodata=-9999.0, mask=None, fourway=False, threads=None):
+    """Linear-time certificate of a PitRemove result (flood(), src/flood.cpp:243-479): every cell against the fixed-point equation of the relaxation
+    (seed rule; W = Z if Z >= min of the neighbours' W, else that minimum) AND a flood from the seed cells through neighbours that are not lower,
+    which must reach every data cell (an under-filled closed basin satisfies every equation and is only found by the flood).
+    Returns (offending cells, index of the first one or -1, cells the flood reached)."""
+    dem = np.ascontiguousarray(dem, dtype=np.float32)
+    fel = np.ascontiguousarray(fel, dtype=np.float32)
+    ny, nx = dem.shape
+    assert fel.shape == dem.shape
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.int16)
+    first, reached = C.c_long(-1), C.c_long(0)
+    f = lib().orc_pitremove_check
+    f.restype = C.c_long
+    bad = f(_p(dem), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(mask), C.c_int(int(fourway)), _p(fel), C.c_int(int(threads or os.cpu_count() or 1)),
+            C.byref(first), C.byref(reached))
+    return int(bad), int(first.value), int(reached.value)
+
+
 def aread8_check(p, ad8, nodata=-32768, weights=None, weights_nodata=-9999.0, contcheck=True, threads=None):
     """Linear-time pin of aread8()'s loop body (src/aread8.cpp:231-256) to a given result (no outlets): (cells of `ad8` that are not what their
     contributors' values in `ad8` give, index of the first one or -1, cells with a direction code)."""

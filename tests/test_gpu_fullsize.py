@@ -7,7 +7,19 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 
 
-def _props(ctx, n, seed, monkeypatch, oracle=None):
+def _certify_fel(oracle, dem, fel, what):
+    """Every cell of `fel` against the linear-time PitRemove certificate of the restatement (oracle/taudem_oracle.c: orc_pitremove_check - the fixed-point
+    equation of flood()'s relaxation per cell, src/flood.cpp:243-271,292-331, plus the flood from the seed cells that must reach every data cell; pinned
+    on CPU to the REAL tool's rasters, tests/test_oracle_vs_golden.py).  dem / fel: torch tensors or numpy arrays."""
+    d = dem.cpu().numpy() if hasattr(dem, "cpu") else dem
+    f = fel.cpu().numpy() if hasattr(fel, "cpu") else fel
+    bad, first, reached = oracle.pitremove_check(d, f, -9999.0)
+    nx = d.shape[1]
+    assert bad == 0, f"{what}: {bad} cells of fel fail flood()'s certificate; first at row {first // nx} column {first % nx}"
+    assert reached == d.size, f"{what}: the flood from the seed cells reached {reached} of {d.size} cells"
+
+
+def _props(ctx, n, seed, monkeypatch, oracle=None, certify=None):
     import torch
 
     dem = ctx.synth_dem(n, seed=seed)
@@ -15,6 +27,8 @@ def _props(ctx, n, seed, monkeypatch, oracle=None):
     # (1) the filled surface is a fixed point of the fill and never below the input (src/flood.cpp:307-330)
     assert bool((fel >= dem).all())
     assert torch.equal(ctx.pitremove(fel, -9999.0), fel), "pitremove is not idempotent"
+    if certify is not None:   # ... and it is flood()'s surface on every cell (no over-filled cell, no under-filled basin)
+        _certify_fel(certify, dem, fel, f"{n} x {n}")
     # (2) no interior pit remains: every interior cell has a neighbour that is not higher
     f = fel[1:-1, 1:-1]
     lower_eq = torch.zeros_like(f, dtype=torch.bool)
@@ -66,11 +80,11 @@ def _props(ctx, n, seed, monkeypatch, oracle=None):
 
 
 def test_properties_hold_where_the_oracle_confirms_them(ctx, oracle, monkeypatch):
-    _props(ctx, 700, 3, monkeypatch, oracle)
+    _props(ctx, 700, 3, monkeypatch, oracle, certify=oracle)
 
 
-def test_properties_at_16384(ctx, monkeypatch):
-    amax = _props(ctx, 16384, 1234, monkeypatch)
+def test_properties_at_16384(ctx, oracle, monkeypatch):
+    amax = _props(ctx, 16384, 1234, monkeypatch, certify=oracle)
     assert amax > 2 ** 24      # the exact re-evaluation path was exercised
 
 
@@ -88,6 +102,8 @@ def _dinf_props(ctx, n, seed, monkeypatch, oracle=None):
     monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
     dem = ctx.synth_dem(n, seed=seed)
     fel = ctx.pitremove(dem, -9999.0)
+    if oracle is not None:   # the input of everything below, on every cell
+        _certify_fel(oracle, dem, fel, f"{n} x {n}")
     del dem
     ang, slp, st = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
     if oracle is not None:
@@ -328,7 +344,7 @@ def test_d8_config4_strip_vs_restatement(ctx, oracle, monkeypatch):
     """BASELINE.json configs[3] as one GPU of the 8-GPU run sees it - the pipeline on a 65536 x 8192 strip of the 65536^2 DEM - against the restatement
     on the host: `p` and `sd8` of D8FlowDir on every cell (the restatement with its flat loops as breadth-first searches: linear time, pinned to the
     real reference on CPU; the first pass and setFlow2 on the host threads), `ad8` of AreaD8 on every cell through aread8()'s loop body
-    (orc_aread8_check).  fel itself is pinned by its fixed-point properties at this size (and by digests up to 16384^2)."""
+    (orc_aread8_check), `fel` of PitRemove on every cell through flood()'s certificate (orc_pitremove_check: per-cell fixed-point equation + the flood from the seed cells)."""
     if _host_gb() < 48:
         pytest.skip("needs ~30 GB of host memory")
     import os
@@ -341,6 +357,7 @@ def test_d8_config4_strip_vs_restatement(ctx, oracle, monkeypatch):
     dem = ctx.synth_dem((ny, nx), seed=1234, base_wavelength=T.synth_base_wavelength(65536))
     fel = ctx.pitremove(dem, -9999.0)
     assert bool((fel >= dem).all()) and torch.equal(ctx.pitremove(fel, -9999.0), fel)
+    _certify_fel(oracle, dem, fel, "65536 x 8192 strip")
     del dem
     p, sd8, st = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
     ad8 = ctx.aread8(p, -32768)

@@ -203,3 +203,70 @@ def test_aread8_checker_accepts_the_reference_rasters_and_nothing_else(g, oracle
     if len(ys):
         t = ref.copy(); t[ys[0], xs[0]] = np.float32(1.0)
         assert oracle.aread8_check(g["p"], t, -32768, weights=w, contcheck=cc)[0] >= 1
+
+
+def _fill_level(fel, dem, nodata):
+    """cells the reference raised (fel > dem, both data)"""
+    return (fel > dem) & (dem != np.float32(nodata))
+
+
+def test_pitremove_checker_accepts_the_reference_rasters_and_nothing_else(g, oracle):
+    """The linear-time PitRemove certificate (oracle/taudem_oracle.c: orc_pitremove_check - every cell against the fixed-point equation of flood()'s
+    relaxation, src/flood.cpp:243-271,292-331, plus a flood from the seed cells that must reach every data cell) passes the `fel` the REAL tool wrote
+    (all five cases: holes, -4way + depression mask among them), with one thread and with several, and notices (a) one raised cell, (b) one lowered
+    filled cell, (c) a value on a nodata cell and (d) a closed basin that was left UN-FILLED - the defect idempotence under the product's own
+    operator cannot see, and the reason for the flood: every cell of such a basin satisfies its local equation."""
+    dem, ref, nodata = g["dem"], np.array(g["fel"], copy=True), float(g["nodata"])
+    mask = g["mask"] if "mask" in g else None
+    fw = bool(g["fourway"])
+    ndata = int((np.abs(dem - np.float32(nodata)) >= 1e-5).sum())
+    for th in (1, 4):
+        bad, first, reached = oracle.pitremove_check(dem, ref, nodata, mask=mask, fourway=fw, threads=th)
+        assert (bad, first) == (0, -1), f"{bad} cells of the reference's fel fail the certificate, first at {first}"
+        assert reached == ndata
+    raised = _fill_level(ref, dem, nodata)
+    ys, xs = np.nonzero(raised)
+    assert len(ys) > 0, "the golden case has no filled cell"
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])
+    t = ref.copy(); t[y, x] = np.nextafter(t[y, x], np.float32(np.inf))                       # (a) one ulp too high
+    assert oracle.pitremove_check(dem, t, nodata, mask=mask, fourway=fw)[0] >= 1
+    t = ref.copy(); t[y, x] = np.nextafter(t[y, x], np.float32(-np.inf))                      # (b) one ulp too low
+    assert oracle.pitremove_check(dem, t, nodata, mask=mask, fourway=fw)[0] >= 1
+    ys0, xs0 = np.nonzero(np.abs(dem - np.float32(nodata)) < 1e-5)
+    if len(ys0):
+        t = ref.copy(); t[ys0[0], xs0[0]] = np.float32(1.0)                                     # (c)
+        assert oracle.pitremove_check(dem, t, nodata, mask=mask, fourway=fw)[0] >= 1
+    # (d) the largest filled basin (cells of one fill level, 4-connected through the raised set) put back to an under-filled level: its cells to
+    # max(dem, level - d) with level - d above the basin's floor - water cells hold their neighbours' minimum, dry cells their elevation: every
+    # equation of (i) holds inside; only the rim (which now has a lower neighbour but keeps its level) and the flood can tell
+    from scipy import ndimage
+    lab, n = ndimage.label(raised)
+    sizes = ndimage.sum(raised, lab, index=np.arange(1, n + 1))
+    big = int(np.argmax(sizes)) + 1
+    basin = lab == big
+    level = np.float32(ref[basin].max())
+    floor = np.float32(dem[basin].min())
+    if level > floor:
+        low = np.float32(floor + (level - floor) * np.float32(0.5))
+        t = ref.copy()
+        t[basin] = np.maximum(dem[basin], low)
+        bad, first, reached = oracle.pitremove_check(dem, t, nodata, mask=mask, fourway=fw)
+        assert bad >= 1 and reached < ndata, "an under-filled closed basin passed the certificate"
+
+
+def test_pitremove_checker_on_a_closed_two_cell_basin(oracle):
+    """The smallest closed basin: two cells at 1 inside a rim at 5 on a plane at 2 that drains to the edge.  flood() fills them to 5.  Left at 1 - or at
+    3, both cells equal, each holding its neighbours' minimum - every cell satisfies its own equation except that nothing drains: the flood
+    from the seed cells never enters (it would have to step down from the rim)."""
+    dem = np.full((9, 10), 2.0, np.float32)
+    dem[3:6, 3:7] = 5.0
+    dem[4, 4:6] = 1.0
+    fel = oracle.pitremove(dem, -9999.0)
+    assert fel[4, 4] == 5.0 and fel[4, 5] == 5.0
+    assert oracle.pitremove_check(dem, fel, -9999.0)[:2] == (0, -1)
+    for lvl in (1.0, 3.0):
+        t = fel.copy(); t[4, 4:6] = np.float32(lvl)
+        bad, first, reached = oracle.pitremove_check(dem, t, -9999.0)
+        assert bad >= 1 and reached < dem.size, f"basin left at {lvl}"
+    t = fel.copy(); t[4, 4:6] = np.float32(6.0)     # over-filled: above the rim
+    assert oracle.pitremove_check(dem, t, -9999.0)[0] >= 1
