@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--workload", choices=("d8", "decay"), default="d8", help="d8: PitRemove->D8FlowDir->AreaD8 (the metric); decay: DinfDecayAccum -wg -o on strips")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the config3 / config5_strip legs after the timed region")
     ap.add_argument("--in-process", action="store_true", help="N > 1: rank threads of this process (tdx_group) instead of one process per rank")
+    ap.add_argument("--segments", type=int, default=0, choices=(0, 1, 2), help="--in-process: segment trace of the timed steps (2: one rank on the device at a "
+                    "time) -> projected_ngpu_ms in the line (taudem_amd.distributed.project_critical_path)")
+    ap.add_argument("--segments-out", default="", help="--segments: also write every rank's segment list to this JSON file (scripts/project_8gpu.py reads it)")
     return ap.parse_args()
 
 
@@ -301,7 +304,24 @@ def config4_strip_leg(torch, ctx, seed, T):
     return {"workload": f"{nx}x{ny} strip (rows 0..8191 of the 65536x65536 synthetic DEM, seed {seed}): PitRemove->D8FlowDir->AreaD8 in HBM on one GPU, no neighbours",
             "ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "stage_ms": {"pitremove": s1["ms_total"], "d8flowdir": s2["ms_total"], "aread8": s3["ms_total"]},
             "flats_initial": s2["flats_initial"], "levels_fall": s2["levels_fall"], "max_level_per_iteration": {"fall": s2["levels_fall_max"], "rise": s2["levels_rise_max"], "int16_limit": 32766}, "pit_rounds": s1["rounds"],
-            "note": "8 such strips = configs[3]; their exchange / all-reduce counts per stage: profiles/r03c_8strips_65536_d8.json"}
+            "note": "8 such strips = configs[3]: the `config4_8strips_one_gpu` leg of this line runs them as eight rank threads on this GPU (exchange / all-reduce counts, "
+                    "projected 8-GPU critical path); profiles/r05*_8strips_65536_d8.json"}
+
+
+def config4_8strips_leg(torch, T, args):
+    """BASELINE.json configs[3] itself - the 65536 x 65536 raster in EIGHT strips of 65536 x 8192 - on the ONE GPU the driver gives this run: eight rank
+    threads on the library's rank group (peer transport), every halo exchange, vote and cross-strip dependency of the 8-GPU protocol included.  One timed
+    step with the ranks sharing the device (a functional figure, not a throughput), then one traced step with the ranks taking turns on it, from which
+    the critical path of the run with one GPU per rank is PROJECTED (sum over the segments between collectives of the slowest rank + collectives x
+    assumed latencies; scripts/project_8gpu.py)."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.warmup, a.steps, a.segments, a.segments_out = "d8", 1, 1, 2, ""
+    line = strips_in_process(torch, T, a, 8, 65536, 65536)
+    keep = ("ms_per_step", "stage_ms_per_step_rank0", "comm", "checks", "max_level_per_iteration", "projected_ngpu_ms")
+    out = {"workload": line["config"]["workload"], "note": "eight ranks share ONE GPU: ms_per_step is functional only; projected_ngpu_ms is a projection, not a measurement"}
+    out.update({k: line[k] for k in keep if k in line})
+    return out
 
 
 def flowalg_leg(torch, ctx, seed):
@@ -350,18 +370,27 @@ def decay_line(world, nx, ny, args, ms_per_step, st, comm_info, job_cells_evalua
 
 def run_in_process(args):
     """N strips as N rank threads of this process (taudem_amd.distributed.StripGroup): the library's own rank group."""
-    import threading
-
     import torch
 
     import taudem_amd as T
-    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
 
     world = args.gpus
-    ndev = torch.cuda.device_count()
     nx, ny = (args.nx or args.ny or 65536), (args.ny or args.nx or 8192 * world)
     if args.size:
         nx, ny = args.size, args.size * world
+    line = strips_in_process(torch, T, args, world, nx, ny)
+    print(json.dumps(line), flush=True)
+
+
+def strips_in_process(torch, T, args, world, nx, ny):
+    """One raster of nx columns x ny rows in `world` row strips, one rank thread per strip on the library's rank group; returns the line.  With
+    args.segments the timed steps are followed by ONE traced step (option "segment_trace") from which the critical path of a run with one GPU per
+    rank is projected (taudem_amd.distributed.project_critical_path)."""
+    import threading
+
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+
+    ndev = torch.cuda.device_count()
     devices = [r % ndev for r in range(world)]
     parts = partition_rows(ny, world)
     bar = threading.Barrier(world)
@@ -407,10 +436,17 @@ def run_in_process(args):
                 for _ in range(args.steps):
                     st = step()
                 torch.cuda.synchronize(); bar.wait()
+                res["elapsed"] = time.perf_counter() - t0
+                if args.segments:   # one more step, traced (mode 2: the rank threads take turns on the device - not a step to time)
+                    c.set_option("segment_trace", args.segments)
+                    bar.wait()
+                    step()
+                    torch.cuda.synchronize(); bar.wait()
+                    res["segments"] = c.segments()
+                    c.set_option("segment_trace", 0)
             except BaseException:
                 bar.abort()     # a rank that fails must not leave the others at the timing barrier
                 raise
-            res["elapsed"] = time.perf_counter() - t0
             res["stats"] = st
             if args.workload == "decay":
                 res["evaluated"] = job.evaluated_cells(torch)
@@ -453,7 +489,18 @@ def run_in_process(args):
                 "max_level_per_iteration": {"fall": s2["levels_fall_max"], "rise": s2["levels_rise_max"], "int16_limit": 32766, "flat_iterations": s2["flat_iterations"]}}
         if functional:
             line["functional_only"] = "ranks share GPUs: a check of the strip protocol at this size, not a throughput figure"
-    print(json.dumps(line), flush=True)
+    if args.segments:
+        from taudem_amd.distributed import project_critical_path
+        logs = [r["segments"] for r in res]
+        proj = project_critical_path(logs)
+        line["projected_ngpu_ms"] = {"per_step": proj["total_ms"],
+                                     "per_stage": {k: {kk: vv for kk, vv in v.items() if kk != "phases"} for k, v in proj["per_stage"].items()},
+                                     "phases": {k: v["phases"] for k, v in proj["per_stage"].items()},
+                                     "assumed": proj["assumed"]}
+        if args.segments_out:
+            with open(args.segments_out, "w") as f:
+                json.dump({"world": world, "nx": nx, "ny": ny, "workload": args.workload, "steps": 1, "mode": args.segments, "logs": logs}, f)
+    return line
 
 
 def main():
@@ -695,6 +742,13 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     out[key] = {"error": f"{e.__class__.__name__}: {e}"}
                 torch.cuda.empty_cache()
+            # last: the eight strips need ~190 GB of their own - this context's scratch arena (sized by config3) goes first
+            ctx.close()
+            torch.cuda.empty_cache()
+            try:
+                out["config4_8strips_one_gpu"] = config4_8strips_leg(torch, T, args)
+            except Exception as e:   # noqa: BLE001
+                out["config4_8strips_one_gpu"] = {"error": f"{e.__class__.__name__}: {e}"}
         line = json.dumps(out)
     # The JSON line is the LAST thing on stdout: whatever any rank or the C runtimes (RCCL prints a version banner
     # through C stdio) have buffered goes out first, and the ranks leave without running teardown code that prints.

@@ -97,6 +97,20 @@ int tdx_context_set_option(tdx_context* ctx, const char* name, int64_t value);
 int tdx_device_count(void);
 /* halo exchanges and all-reduces this context has taken part in since it was created (strip runs; 0 on a single strip) */
 void tdx_context_comm_counters(const tdx_context* ctx, int64_t* exchanges, int64_t* allreduces);
+/* Segment trace (option "segment_trace" = 1 | 2): a strip call is a sequence of segments of rank-local work, each ended by a collective (the
+ * role of share() / MPI_Allreduce in src/linearpart.h:194-360, src/aread8.cpp:282-303) or by the end of the call; every rank passes through the
+ * same sequence.  device_ms = HIP-event time of the segment on the rank's stream, wall_ms = host time.  Mode 2 lets one rank at a time onto the
+ * device (ranks that share a GPU), so that a segment is timed as it would run on a GPU of its own: sum over segments of the maximum over ranks
+ * + collectives x latency is the critical path of the N-GPU run (scripts/project_8gpu.py).  tdx_context_segments copies up to `capacity` records,
+ * clears the log when `out` is given, and returns the number of records that were logged. */
+typedef struct tdx_segment {
+    char stage[24];   /* "pitremove", "d8flowdir", "aread8" ...                                  */
+    char phase[24];   /* sub-stage, free text ("forest", "big cells"); may be empty              */
+    int32_t kind;     /* what ended the segment: 0 halo exchange, 1 all-reduce, 2 end of the call */
+    float device_ms;
+    float wall_ms;
+} tdx_segment;
+int64_t tdx_context_segments(tdx_context* ctx, tdx_segment* out, int64_t capacity);
 
 /* device memory helpers so that callers without a HIP binding (ctypes, cgo ...) can stage data */
 int tdx_device_alloc(tdx_context* ctx, uint64_t bytes, void** dptr);

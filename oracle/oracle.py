@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtaudem_oracle.so")
+LIB_L32 = os.path.join(HERE, "libtaudem_oracle_l32.so")   # the same source with 32-bit level counters in resolveflats() (ORC_LVL_T)
 REF_DIR = os.path.join(HERE, "_ref")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
@@ -23,7 +24,8 @@ _lib = None
 
 def build(force=False):
     """Compile the C restatement (and, when /root/reference is present, the reference tools)."""
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "taudem_oracle.c")):
+    src_t = os.path.getmtime(os.path.join(HERE, "taudem_oracle.c"))
+    if force or any(not os.path.exists(f) or os.path.getmtime(f) < src_t for f in (LIB, LIB_L32)):
         subprocess.run(["make", "-C", HERE, "restatement"], check=True, capture_output=True)
     if os.path.isdir("/root/reference/src"):
         subprocess.run(["make", "-C", HERE, "ref", "-j8"], check=True, capture_output=True)
@@ -37,6 +39,18 @@ def lib():
         _lib.orc_prop.restype = C.c_double
         _lib.orc_prop.argtypes = [C.c_float, C.c_int, C.c_double, C.c_double]
     return _lib
+
+
+_lib32 = None
+
+
+def lib32():
+    """The restatement with 32-bit level counters (flats deeper than the reference's `short` partitions hold): a superset of the reference, not a parity claim."""
+    global _lib32
+    if _lib32 is None:
+        build()
+        _lib32 = C.CDLL(LIB_L32)
+    return _lib32
 
 
 def _p(a):
@@ -84,14 +98,14 @@ def pitremove(dem, nodata=-9999.0, mask=None, fourway=False):
     return fel
 
 
-def d8flowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0):
+def d8flowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0, levels32=False):
     fel = np.ascontiguousarray(fel, dtype=np.float32)
     ny, nx = fel.shape
     p = np.empty((ny, nx), dtype=np.int16)
     sd8 = np.empty((ny, nx), dtype=np.float32)
     st = (C.c_long * 8)()
     dxc, dyc = _f64(dx, ny), _f64(dy, ny)
-    lib().orc_d8flowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(p), _p(sd8), st)
+    (lib32() if levels32 else lib()).orc_d8flowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(p), _p(sd8), st)
     stats = {"flats_initial": st[0], "flat_iterations": st[1], "flats_left": st[2], "sweeps_fall": st[3], "sweeps_rise": st[4]}
     return p, sd8, stats
 
@@ -182,14 +196,14 @@ def threshold(ssa, thresh, nodata=-1.0, mask=None):
     return src
 
 
-def dinfflowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0):
+def dinfflowdir(fel, nodata=-3.0e38, dx=1.0, dy=1.0, levels32=False):
     fel = np.ascontiguousarray(fel, dtype=np.float32)
     ny, nx = fel.shape
     ang = np.empty((ny, nx), dtype=np.float32)
     slp = np.empty((ny, nx), dtype=np.float32)
     st = (C.c_long * 8)()
     dxc, dyc = _f64(dx, ny), _f64(dy, ny)
-    lib().orc_dinfflowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(ang), _p(slp), st)
+    (lib32() if levels32 else lib()).orc_dinfflowdir(_p(fel), C.c_long(nx), C.c_long(ny), C.c_float(nodata), _p(dxc), _p(dyc), _p(ang), _p(slp), st)
     return ang, slp, {"flats_initial": st[0], "flat_iterations": st[1], "flats_left": st[2]}
 
 

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round 4, call R: kernel timeline of ONE 16384^2 step (native harness): every launch in time order with its grid, per stream overlap visible from the offsets
+# kernel timeline of ONE 16384^2 step (native harness): every launch in time order with its grid, per stream overlap visible from the offsets
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04r
+O=$R/gpurun_out/timeline
 mkdir -p $O
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- $R/taudem_amd/bin/tdxbench d8 -n ${1:-16384} -steps 1 -warmup 1 > $O/run.log 2>&1)
 python - <<'PY'
 import csv, glob, os
-O = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/r04r'
+O = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/timeline'
 f = glob.glob(O + '/tr/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 def short(n): return n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60]

@@ -63,6 +63,11 @@ class TdxStats(C.Structure):
         return d
 
 
+class TdxSegment(C.Structure):
+    """struct tdx_segment of include/taudem_amd.h (segment trace of a strip run)."""
+    _fields_ = [("stage", C.c_char * 24), ("phase", C.c_char * 24), ("kind", C.c_int32), ("device_ms", C.c_float), ("wall_ms", C.c_float)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
 
@@ -184,6 +189,7 @@ _SIGNATURES = {
     "tdx_rccl_comm_destroy": (None, [_P]),
     "tdx_rccl_selftest": (C.c_int, [_P]),
     "tdx_context_comm_counters": (None, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tdx_context_segments": (_I64, [_P, C.POINTER(TdxSegment), _I64]),
     "tdx_group_create": (C.c_int, [C.c_int32, _P, _I64, C.POINTER(_P)]),
     "tdx_group_context": (_P, [_P, C.c_int32]),
     "tdx_group_comm": (_P, [_P, C.c_int32]),

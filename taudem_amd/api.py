@@ -60,6 +60,16 @@ class Context:
         """Context options of include/taudem_amd.h (e.g. "kernel_timing")."""
         check(self._lib.tdx_context_set_option(self._h, name.encode(), int(value)), self._h)
 
+    def segments(self):
+        """The segment trace since the last call (option "segment_trace"): [(stage, phase, kind, device_ms, wall_ms)], kind 0 = ended by a halo
+        exchange, 1 = by an all-reduce, 2 = by the end of the call.  Clears the log."""
+        n = int(self._lib.tdx_context_segments(self._h, None, 0))
+        if n == 0:
+            return []
+        buf = (_lib.TdxSegment * n)()
+        self._lib.tdx_context_segments(self._h, buf, n)
+        return [(b.stage.decode(), b.phase.decode(), int(b.kind), float(b.device_ms), float(b.wall_ms)) for b in buf]
+
     def __del__(self):
         try:
             self.close()

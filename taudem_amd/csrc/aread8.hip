@@ -111,6 +111,23 @@ __global__ __launch_bounds__(256) void d8_apply_reach_kernel(const int16_t* __re
     Pout[i] = q;
 }
 
+// cells that take part in the sweep (d8_participates): the bound of every exact count (aread8_impl).  A few thousand blocks stride over the rows and end
+// in ONE atomic each (a word takes ~90 M atomics/s: one atomic per wave was 12.7 ms of a 0.3 ms pass at 65536 x 8192, profiles/r05b_*).
+__global__ __launch_bounds__(256) void d8_count_participating_kernel(const int16_t* __restrict__ P, size_t n, int16_t nodata, unsigned long long* __restrict__ total) {
+    unsigned c = 0;
+    for (size_t i0 = (size_t(blockIdx.x) * 256 + threadIdx.x) * 8; i0 < n; i0 += size_t(gridDim.x) * 2048) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (i0 + j < n && d8_participates(P[i0 + j], nodata)) c++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+}
+
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
     size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -712,9 +729,92 @@ __global__ __launch_bounds__(256) void ad8_big_keys_kernel(const uint32_t* __res
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q < nbig) keys[q] = cellw[biglist[q]];
 }
-__global__ __launch_bounds__(256) void ad8_big_pos_kernel(const uint32_t* __restrict__ sorted, unsigned long long nbig, uint32_t* __restrict__ pos) {
+// (the list kernels below take the list's length from DEVICE memory: the list shrinks from one outer round to the next - ad8_big_compact_kernel - and
+// nobody waits for the host to learn by how much; their grids cover the first round's length)
+__global__ __launch_bounds__(256) void ad8_big_pos_kernel(const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev, uint32_t* __restrict__ pos) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q < nbig) pos[sorted[q]] = uint32_t(q);
+    if (q < *nbig_dev) pos[sorted[q]] = uint32_t(q);
+}
+// The entries of `in` whose cell is still pending (ad8 == BIG_MARK), in list order -> out; *nout = their number.  One workgroup: a list is at most a few
+// 10^5 entries (630 542 cells above 2^24 in the eight strips of BASELINE.json configs[3]) and every outer round only keeps what the neighbouring strips
+// still block.  Ascending exact count stays a dependency order of what is left.
+__global__ __launch_bounds__(1024) void ad8_big_compact_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ root_in, const unsigned long long* __restrict__ nin_dev,
+                                                               const float* __restrict__ A, uint32_t* __restrict__ out, uint32_t* __restrict__ root_out,
+                                                               unsigned long long* __restrict__ nout) {
+    __shared__ unsigned wsum[16];
+    const unsigned long long n = *nin_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long base = 0;
+    for (unsigned long long q0 = 0; q0 < n; q0 += 1024) {
+        const unsigned long long q = q0 + threadIdx.x;
+        const uint32_t cell = q < n ? in[q] : 0u;
+        const bool keep = q < n && A[cell] == BIG_MARK;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[w] = unsigned(__popcll(m));
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const unsigned v = wsum[i]; before += i < w ? v : 0u; total += v; }
+        if (keep) {
+            const unsigned long long o = base + before + unsigned(__popcll(m & ((1ull << lane) - 1ull)));
+            out[o] = cell;
+            root_out[o] = root_in[q];   // (the tree a cell belongs to: what is left of a tree stays one group)
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nout = base;
+}
+
+// ---- the forest of big cells, tree by tree ----
+// The cell a big cell drains to is big as well (its count is larger) unless the flow leaves the strip or ends: the big cells form a forest, a big
+// contributor of a big cell lies in the same tree, and trees do not depend on each other.  One wave folding ALL of them in count order costs ~0.12 us per
+// cell - 12 ms for the ~10^5 big cells of a 65536 x 8192 strip of BASELINE.json configs[3], the largest item of AreaD8's critical path across the eight
+// strips (profiles/r05c_*) - so the list is grouped by tree (root by pointer jumping, stable sort by root: ascending count survives inside a tree) and
+// every tree gets a wave of its own.
+__global__ __launch_bounds__(256) void ad8_big_next_kernel(const int16_t* __restrict__ P, int nx, int y_own0, int y_own1, const uint32_t* __restrict__ sorted,
+                                                           unsigned long long nbig, const uint32_t* __restrict__ pos, const float* __restrict__ A,
+                                                           uint32_t* __restrict__ nxt) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nbig) return;
+    const size_t c = size_t(sorted[q]);
+    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
+    const int p = P[c];
+    uint32_t r = uint32_t(q);   // a root: the flow ends, leaves the strip, or goes on into a cell that is not big
+    if (p >= 1 && p <= 8) {
+        const int xn = x + d1(p), yn = y + d2(p);
+        if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
+            const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
+            if (A[n] == BIG_MARK) r = pos[n];
+        }
+    }
+    nxt[q] = r;
+}
+__global__ __launch_bounds__(256) void ad8_big_jump_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, unsigned long long nbig) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (q < nbig) out[q] = in[in[q]];
+}
+// first list position of every group of equal roots (the list is grouped by root) -> segbeg[0 .. nseg), segbeg[nseg] = n; one workgroup like ad8_big_compact_kernel
+__global__ __launch_bounds__(1024) void ad8_big_segments_kernel(const uint32_t* __restrict__ root, const unsigned long long* __restrict__ n_dev,
+                                                                uint32_t* __restrict__ segbeg, unsigned long long* __restrict__ nseg) {
+    __shared__ unsigned wsum[16];
+    const unsigned long long n = *n_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long base = 0;
+    for (unsigned long long q0 = 0; q0 < n; q0 += 1024) {
+        const unsigned long long q = q0 + threadIdx.x;
+        const bool first = q < n && (q == 0 || root[q] != root[q - 1]);
+        const unsigned long long m = __ballot(first);
+        if (lane == 0) wsum[w] = unsigned(__popcll(m));
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const unsigned v = wsum[i]; before += i < w ? v : 0u; total += v; }
+        if (first) segbeg[base + before + unsigned(__popcll(m & ((1ull << lane) - 1ull)))] = uint32_t(q);
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { segbeg[base] = uint32_t(n); *nseg = base; }
 }
 
 // Step 1 (parallel over the sorted list): everything about a big cell that does not depend on other pending cells - which
@@ -722,11 +822,11 @@ __global__ __launch_bounds__(256) void ad8_big_pos_kernel(const uint32_t* __rest
 constexpr uint32_t BIG_NODEP = 0xFFFFFFFFu;
 constexpr uint32_t BIGF_PENDING = 1u, BIGF_BLOCKED = 2u, BIGF_CON = 4u;   // bits 8-15: contributor mask
 __global__ __launch_bounds__(256) void ad8_big_gather_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                             const uint32_t* __restrict__ sorted, unsigned long long nbig,
+                                                             const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
                                                              const uint32_t* __restrict__ pos, const float* __restrict__ A, float* __restrict__ vals,
                                                              uint32_t* __restrict__ deps, uint32_t* __restrict__ flags, float* __restrict__ bigval) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
+    if (q >= *nbig_dev) return;
     const size_t c = size_t(sorted[q]);
     const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
     const float mine = A[c];
@@ -767,15 +867,21 @@ __global__ __launch_bounds__(256) void ad8_big_gather_kernel(const int16_t* __re
 // of the same chunk are handed on in list order.  A cell with a blocked contributor stays pending (BIG_MARK) for the
 // next outer round.
 constexpr unsigned BIG_LDS = 15360;
-__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const uint32_t* __restrict__ sorted, unsigned long long nbig,
+__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
+                                                          const uint32_t* __restrict__ segbeg, const unsigned long long* __restrict__ nseg_dev,
                                                           const float* __restrict__ vals, const uint32_t* __restrict__ deps,
                                                           const uint32_t* __restrict__ flags, float* __restrict__ bigval, float* __restrict__ A,
                                                           unsigned long long* __restrict__ nfinal) {
     __shared__ float s_big[BIG_LDS];
     const int lane = threadIdx.x;
     unsigned long long done = 0;
-    for (unsigned long long i = lane; i < nbig && i < BIG_LDS; i += 64) s_big[i] = bigval[i];
-    const bool spill = nbig > BIG_LDS;
+    // The list is grouped by TREE of the big-cell forest (segbeg: first list position of every tree, ascending exact count inside a tree; null: one
+    // group).  A big contributor of a big cell lies in the same tree, so trees are independent: one wave per tree, as many waves as the launch has.
+    const unsigned long long nseg = segbeg ? *nseg_dev : 1ull;
+    for (unsigned long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const unsigned long long b0 = segbeg ? (unsigned long long)segbeg[seg] : 0ull, nbig = segbeg ? (unsigned long long)segbeg[seg + 1] : *nbig_dev;   // this wave's part: [b0, nbig)
+    for (unsigned long long i = lane; b0 + i < nbig && i < BIG_LDS; i += 64) s_big[i] = bigval[b0 + i];
+    const bool spill = nbig - b0 > BIG_LDS;
     // operands of the first chunk; the next chunk's are fetched while the current one is folded
     uint32_t f = 0, c = 0, dp[8];
     float ak[8];
@@ -787,8 +893,8 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
             for (int k = 0; k < 8; k++) { ak[k] = vals[q * 8 + k]; dp[k] = deps[q * 8 + k]; }
         }
     };
-    fetch((unsigned long long)lane);
-    for (unsigned long long chunk0 = 0; chunk0 < nbig; chunk0 += 64) {
+    fetch(b0 + (unsigned long long)lane);
+    for (unsigned long long chunk0 = b0; chunk0 < nbig; chunk0 += 64) {
         const unsigned long long q = chunk0 + (unsigned long long)lane;
         const uint32_t fl = f, cell = c;
         float a8[8];
@@ -805,7 +911,7 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
                 if (d8[k] == BIG_NODEP) continue;
                 if ((unsigned long long)d8[k] >= q) blocked = true;                // (cannot happen: a contributor's count is smaller)
                 else if ((unsigned long long)d8[k] >= chunk0) inchunk |= 1u << k;
-                else a8[k] = d8[k] < BIG_LDS ? s_big[d8[k]] : ld_agent(&bigval[d8[k]]);
+                else a8[k] = (d8[k] - b0) < BIG_LDS ? s_big[d8[k] - b0] : ld_agent(&bigval[d8[k]]);
             }
         }
         float result = BIG_MARK;
@@ -878,13 +984,14 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
             if (lane == i) result = fold();
         }
         if (pending && result != BIG_MARK) {
-            if (q < BIG_LDS) s_big[q] = result;
+            if (q - b0 < BIG_LDS) s_big[q - b0] = result;
             else st_agent(&bigval[q], result);
             A[cell] = result;   // read again only after this kernel (exchange / host)
             done++;
         }
         if (spill) drain_stores();   // later chunks read these values back through the L2
     }
+    }   // trees
     if (done) atomicAdd(nfinal, done);
 }
 
@@ -946,6 +1053,7 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     int64_t outer = 1;
+    ctx->phase = "forest";
     {
         TdxSpan sp(ctx, TDX_K_ACCUM);
         hipLaunchKernelGGL(ad8_forest_walk_kernel, dim3(tdx_blocks_for(size_t(g.nnodes_local), 256)), dim3(256), 0, s, g, node_acc, node_indeg, node_next,
@@ -966,6 +1074,8 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
             outer++;
         }
     }
+    const int64_t outer_forest = outer;
+    ctx->phase = "apply";
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
@@ -979,33 +1089,73 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     int64_t nbig_all = int64_t(nbig);
     rc = strip_allreduce(ctx, st, &nbig_all, 1, TDX_OP_SUM);
     if (rc != TDX_OK) return rc;
+    ctx->phase = "big cells";
     if (nbig_all > 0) {
         TdxSpan sp(ctx, TDX_K_MISC);
-        // dependency order = ascending exact count (left in cellw by the apply pass)
-        uint32_t* keys = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, size_t(nbig ? nbig : 1) * 4 * 3));
+        // dependency order = ascending exact count (left in cellw by the apply pass); list arrays of nbig words: sort keys, sorted keys, the list in count
+        // order, two root arrays (pointer jumping; later: the compacted list's roots), the list grouped by tree, its second buffer, the trees' first positions
+        const size_t nb1 = size_t(nbig ? nbig : 1);
+        uint32_t* keys = static_cast<uint32_t*>(ctx->scratch(TDX_S_H, (nb1 * 8 + 4) * 4));
         if (!keys) return TDX_ERR_NOMEM;
-        uint32_t *keys_sorted = keys + (nbig ? nbig : 1), *sorted = keys_sorted + (nbig ? nbig : 1);
+        uint32_t *keys_sorted = keys + nb1, *sorted = keys_sorted + nb1, *rootA = sorted + nb1, *rootB = rootA + nb1, *grouped = rootB + nb1, *listB = grouped + nb1,
+                 *segbeg = listB + nb1;
         uint32_t* pos = cellw;   // list position of every big cell (the per-cell words are no longer needed once the keys are out)
+        static const bool no_trees = getenv("TDX_AD8_BIG_ONE_WAVE") != nullptr;            // (A/B hook: one wave folds the whole list in count order)
+        static const bool no_incremental = getenv("TDX_AD8_BIG_FULL_ROUNDS") != nullptr;   // (A/B hook: every outer round on the whole list)
+        uint32_t *cur = sorted, *cur_root = rootA, *other = listB, *other_root = rootB;
+        unsigned long long* n_cur = d_cnt;            // the apply pass's counter = the first list's length
+        const unsigned gb = tdx_blocks_for(nb1, 256);
         if (nbig) {
-            hipLaunchKernelGGL(ad8_big_keys_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, biglist, nbig, cellw, keys);
+            hipLaunchKernelGGL(ad8_big_keys_kernel, dim3(gb), dim3(256), 0, s, biglist, nbig, cellw, keys);
             rc = tdx_sort_pairs_u32(ctx, TDX_S_I, keys, keys_sorted, biglist, sorted, size_t(nbig));
             if (rc != TDX_OK) return rc;
-            hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, sorted, nbig, pos);
+            if (!no_trees) {
+                hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(gb), dim3(256), 0, s, sorted, n_cur, pos);
+                hipLaunchKernelGGL(ad8_big_next_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.y0, st.y1, sorted, nbig, pos, d_ad8, rootA);
+                uint32_t *ra = rootA, *rb = rootB;
+                for (unsigned long long reach = 1; reach < nbig; reach *= 2) {   // after j steps a pointer spans 2^j cells of its chain
+                    hipLaunchKernelGGL(ad8_big_jump_kernel, dim3(gb), dim3(256), 0, s, ra, rb, nbig);
+                    std::swap(ra, rb);
+                }
+                // stable sort by root: the trees become groups, ascending count inside each (the keys arrays are free again)
+                rc = tdx_sort_pairs_u32(ctx, TDX_S_I, ra, keys, sorted, grouped, size_t(nbig));
+                if (rc != TDX_OK) return rc;
+                cur = grouped; cur_root = keys; other = listB; other_root = keys_sorted;
+            }
         }
         // per big cell: 8 contributor values, 8 dependency positions, flags, current value
-        float* big_vals = static_cast<float*>(ctx->scratch(TDX_S_J, size_t(nbig ? nbig : 1) * 4 * 18));
+        float* big_vals = static_cast<float*>(ctx->scratch(TDX_S_J, nb1 * 4 * 18));
         if (!big_vals) return TDX_ERR_NOMEM;
-        uint32_t* big_deps = reinterpret_cast<uint32_t*>(big_vals) + size_t(nbig ? nbig : 1) * 8;
-        uint32_t* big_flags = big_deps + size_t(nbig ? nbig : 1) * 8;
-        float* big_val = reinterpret_cast<float*>(big_flags + size_t(nbig ? nbig : 1));
+        uint32_t* big_deps = reinterpret_cast<uint32_t*>(big_vals) + nb1 * 8;
+        uint32_t* big_flags = big_deps + nb1 * 8;
+        float* big_val = reinterpret_cast<float*>(big_flags + nb1);
         rc = strip_exchange<float>(ctx, st, d_ad8, TDX_AREA_NODATA);   // which halo cells await re-evaluation
         if (rc != TDX_OK) return rc;
+        // Outer rounds: a cell whose contributor in a neighbouring strip is still pending stays pending; what the round finished travels in the exchanged
+        // boundary rows.  Every round works on the list of what is STILL pending (groups and their order survive: ad8_big_compact_kernel), not on all big
+        // cells again.
+        int flip = 0;
         for (;;) {
             if (nbig) {
-                hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(tdx_blocks_for(nbig, 256)), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, sorted,
-                                   nbig, pos, d_ad8, big_vals, big_deps, big_flags, big_val);
-                hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, sorted, nbig, big_vals, big_deps, big_flags, big_val, d_ad8,
-                                   d_cnt + 2);
+                hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(gb), dim3(256), 0, s, cur, n_cur, pos);
+                hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, cur, n_cur, pos, d_ad8, big_vals,
+                                   big_deps, big_flags, big_val);
+                if (no_trees)
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, cur, n_cur, static_cast<const uint32_t*>(nullptr),
+                                       static_cast<const unsigned long long*>(nullptr), big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
+                else {
+                    hipLaunchKernelGGL(ad8_big_segments_kernel, dim3(1), dim3(1024), 0, s, cur_root, n_cur, segbeg, d_cnt + 6);
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, cur,
+                                       n_cur, segbeg, d_cnt + 6, big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
+                }
+                if (st.multi() && !no_incremental) {
+                    unsigned long long* n_next = d_cnt + 4 + flip;
+                    hipLaunchKernelGGL(ad8_big_compact_kernel, dim3(1), dim3(1024), 0, s, cur, cur_root, n_cur, d_ad8, other, other_root, n_next);
+                    std::swap(cur, other);
+                    std::swap(cur_root, other_root);
+                    n_cur = n_next;
+                    flip ^= 1;
+                }
             }
             if (stats) stats->launches[TDX_K_MISC]++;
             if (!st.multi()) break;
@@ -1019,6 +1169,12 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         }
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());
+    if (st.multi()) {
+        static const bool trace = getenv("TDX_COMM_TRACE") != nullptr && atoi(getenv("TDX_COMM_TRACE")) != 0;
+        if (trace)
+            fprintf(stderr, "taudem_amd[rank %d/%d] aread8: %lld outer rounds of the crossing forest, %lld of the big cells; %llu big cells here, %lld in all strips\n",
+                    st.comm->rank, st.comm->size, (long long)outer_forest, (long long)(outer - outer_forest + 1), nbig, (long long)nbig_all);
+    }
     tdx_stats* stt = stats;
     ctx->end_call();
     if (stt) { stt->rounds = outer; stt->cells_evaluated = nbig_all; }
@@ -1035,18 +1191,7 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
     const int inx = st.nx, iny = st.ny_arr;
     const size_t n = size_t(inx) * size_t(iny);
     const bool force_walk = getenv("TDX_AD8_WALK") != nullptr;
-    // The tile contraction carries exact cell counts in 32-bit words (node_acc, the apply pass's LDS counters, the big-cell
-    // sort keys): a count is at most the number of cells of the WHOLE raster, so the raster (all strips) must hold fewer
-    // than 2^32 cells.  Larger rasters take the pull walk, whose float32 adds have no such limit.
-    // TDX_AD8_COUNT_LIMIT: test hook for that switch.
     bool tiled = ex.mode == D8X_SUM && !d_w && !force_walk;
-    if (tiled) {
-        int64_t cells = int64_t(st.nx) * int64_t(st.y1 - st.y0);
-        int rc0 = strip_allreduce(ctx, st, &cells, 1, TDX_OP_SUM);
-        if (rc0 != TDX_OK) return rc0;
-        const int64_t limit = getenv("TDX_AD8_COUNT_LIMIT") ? atoll(getenv("TDX_AD8_COUNT_LIMIT")) : int64_t(0xFFFFFFFFll);
-        if (cells > limit) tiled = false;
-    }
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     int16_t* p_use = d_p;
     int rc;
@@ -1077,6 +1222,27 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
         if (rc != TDX_OK) return rc;
         hipLaunchKernelGGL(d8_apply_reach_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, s, d_p, reach, n, p_nodata, pprime);
         p_use = pprime;
+    }
+    // The tile contraction carries exact cell counts in 32-bit words (node_acc, the apply pass's LDS counters, the big-cell
+    // sort keys).  A count is at most the number of PARTICIPATING cells of the whole raster (all strips; with outlets: of their
+    // upstream closure), so that number must stay below 2^32: a raster of fewer cells passes at once, a larger one - 65536 x 65536,
+    // BASELINE.json configs[3], is exactly 2^32 cells, 4 294 700 699 of them with a direction - has its participating cells counted
+    // (one streaming pass over p).  Beyond that the tile dependency sweep runs, whose float32 adds have no such limit.
+    // TDX_AD8_COUNT_LIMIT: test hook for that switch.
+    if (tiled) {
+        int64_t cells = int64_t(st.nx) * int64_t(st.y1 - st.y0);
+        int rc0 = strip_allreduce(ctx, st, &cells, 1, TDX_OP_SUM);
+        if (rc0 != TDX_OK) return rc0;
+        const int64_t limit = getenv("TDX_AD8_COUNT_LIMIT") ? atoll(getenv("TDX_AD8_COUNT_LIMIT")) : int64_t(0xFFFFFFFFll);
+        if (cells > limit) {
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt + 3, 0, sizeof(unsigned long long), s));
+            const size_t first = size_t(st.y0) * size_t(inx), nown = size_t(st.y1 - st.y0) * size_t(inx);
+            hipLaunchKernelGGL(d8_count_participating_kernel, dim3(std::min(tdx_blocks_for((nown + 7) / 8, 256), 2048u)), dim3(256), 0, s, p_use + first, nown, p_nodata, d_cnt + 3);
+            int64_t npart = 0;
+            rc0 = strip_allreduce_device(ctx, st, d_cnt + 3, 1, TDX_OP_SUM, &npart);
+            if (rc0 != TDX_OK) return rc0;
+            if (npart > limit) tiled = false;
+        }
     }
     if (tiled && getenv("TDX_AD8_SWEEP") == nullptr) return aread8_tiled(ctx, st, p_use, p_nodata, contcheck, d_ad8, stats);
 

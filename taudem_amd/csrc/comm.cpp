@@ -23,6 +23,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "context.hpp"
@@ -114,7 +115,9 @@ constexpr int RED_MAX = 16;
 struct tdx_rccl_comm {
     tdx_context* ctx = nullptr;
     ncclComm_t comm = nullptr;   // guarded by `use`: null after an abort
-    std::mutex use;              // held around every host-side RCCL call on `comm` (they only enqueue) and around its abort
+    std::mutex use;              // held around every host-side RCCL call on `comm` (they only enqueue) and, when it can be had, around its abort
+    std::atomic<bool> dead{false};   // set by tdx_group_abort BEFORE it asks for `use`: no new RCCL call starts on this communicator
+    bool abandoned = false;      // the communicator was aborted under a rank thread that was stuck inside an RCCL call: nobody may touch `comm` again
     tdx_comm c{};
     char* bufs = nullptr;        // 4 x capacity bytes of device memory: send_up send_down recv_up recv_down
     int64_t* d_red = nullptr;    // RED_MAX device words for host-value votes
@@ -131,7 +134,7 @@ int rccl_exchange(void* user, uint64_t bytes) {
     hipStream_t s = r->ctx->stream;
     r->exchanges++;
     std::lock_guard<std::mutex> lk(r->use);   // tdx_group_abort (another rank's thread) must not free the communicator under these calls
-    if (!r->comm) { g_tdx_thread_error = "rank " + std::to_string(rank) + " of " + std::to_string(size) + ": the rank group was aborted"; return 1; }
+    if (!r->comm || r->dead.load()) { g_tdx_thread_error = "rank " + std::to_string(rank) + " of " + std::to_string(size) + ": the rank group was aborted"; return 1; }
     TDX_NCCL(a.GroupStart());
     // inside the group the first failure is remembered and the group is ALWAYS closed: a thread that returned between GroupStart
     // and GroupEnd would queue every later RCCL call (the communicator's destruction included) into a group that never ends
@@ -158,7 +161,7 @@ int rccl_allreduce_dev(void* user, int64_t* d_values, int32_t count, int32_t op)
     tdx_rccl_comm* r = static_cast<tdx_rccl_comm*>(user);
     r->allreduces++;
     std::lock_guard<std::mutex> lk(r->use);
-    if (!r->comm) { g_tdx_thread_error = "rank " + std::to_string(r->c.rank) + " of " + std::to_string(r->c.size) + ": the rank group was aborted"; return 1; }
+    if (!r->comm || r->dead.load()) { g_tdx_thread_error = "rank " + std::to_string(r->c.rank) + " of " + std::to_string(r->c.size) + ": the rank group was aborted"; return 1; }
     TDX_NCCL(rccl().AllReduce(d_values, d_values, size_t(count), ncclInt64, op == TDX_OP_MAX ? ncclMax : ncclSum, r->comm, r->ctx->stream));
     return 0;
 }
@@ -229,7 +232,7 @@ extern "C" void tdx_rccl_comm_destroy(tdx_rccl_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->comm) rccl().CommDestroy(c->comm);
+    if (c->comm && !c->abandoned) rccl().CommDestroy(c->comm);
     (void)hipFree(c->bufs); (void)hipFree(c->d_red); (void)hipHostFree(c->h_red);
     delete c;
 }
@@ -398,13 +401,18 @@ extern "C" void tdx_group_abort(tdx_group* g) {
     if (g->bar) g->bar->abort();
     for (tdx_rccl_comm* r : g->rc) {
         if (!r) continue;
-        ncclComm_t c = nullptr;
-        {   // take the communicator away under its lock: a rank thread is either before its calls (and will find null) or past them
-            std::lock_guard<std::mutex> lk(r->use);
-            c = r->comm;
-            r->comm = nullptr;
-        }
-        if (c) rccl().CommAbort(c);          // ends what is enqueued on the rank's stream; nobody holds `c` any more
+        // Take the communicator away under its lock: a rank thread is either before its calls (and will find `dead`) or past them.  A rank thread
+        // that is STUCK inside an RCCL call (ncclGroupEnd setting up a connection to a peer that has already failed) holds the lock for good -
+        // and the abort is the only thing that releases it: after a bounded wait the communicator is aborted under that thread's feet (what
+        // ncclCommAbort is for); its call returns an error, every later call finds `dead`, and nobody touches the handle again.
+        r->dead.store(true);
+        std::unique_lock<std::mutex> lk(r->use, std::defer_lock);
+        bool got = false;
+        for (int i = 0; i < 200 && !(got = lk.try_lock()); i++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        ncclComm_t c = r->comm;
+        if (got) { r->comm = nullptr; lk.unlock(); }
+        else r->abandoned = true;
+        if (c) rccl().CommAbort(c);          // ends what is enqueued on the rank's stream
     }
 }
 extern "C" void tdx_group_destroy(tdx_group* g) {

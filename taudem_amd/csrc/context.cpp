@@ -1,7 +1,10 @@
 #include "context.hpp"
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 thread_local std::string g_tdx_thread_error;
 
@@ -23,6 +26,53 @@ void* tdx_context::scratch(int slot, size_t bytes) {
     return s.p;
 }
 
+// the device token of segment_trace mode 2 (a plain mutex would have to be unlocked by the thread that locked it; a rank thread always is, but keep it explicit)
+namespace {
+std::mutex g_tok_m;
+std::condition_variable g_tok_cv;
+bool g_tok_taken = false;
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+void tdx_context::seg_begin() {
+    if (!seg_mode || seg_open) return;
+    if (seg_mode == 2 && comm_size > 1) {
+        std::unique_lock<std::mutex> lk(g_tok_m);
+        g_tok_cv.wait(lk, [] { return !g_tok_taken; });
+        g_tok_taken = true;
+        seg_token = true;
+    }
+    if (!seg_ev0) { (void)hipEventCreate(&seg_ev0); (void)hipEventCreate(&seg_ev1); }
+    (void)hipEventRecord(seg_ev0, stream);
+    seg_t0 = now_ms();
+    seg_open = true;
+}
+
+void tdx_context::seg_end(int kind) {
+    if (!seg_mode || !seg_open) return;
+    (void)hipEventRecord(seg_ev1, stream);
+    (void)hipEventSynchronize(seg_ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, seg_ev0, seg_ev1);
+    segments.push_back(Segment{stage, phase, kind, ms, float(now_ms() - seg_t0)});
+    seg_open = false;
+    if (seg_token) {
+        { std::lock_guard<std::mutex> lk(g_tok_m); g_tok_taken = false; }
+        g_tok_cv.notify_one();
+        seg_token = false;
+    }
+}
+
+void tdx_context::abort_call() {
+    timing = false; cur_stats = nullptr;
+    if (seg_token) {   // a failing rank must not keep the others off the device
+        { std::lock_guard<std::mutex> lk(g_tok_m); g_tok_taken = false; }
+        g_tok_cv.notify_one();
+        seg_token = false;
+    }
+    seg_open = false;
+}
+
 hipEvent_t tdx_context::get_event() {
     if (events_used == event_pool.size()) {
         hipEvent_t e;
@@ -38,6 +88,8 @@ void tdx_context::begin_call(tdx_stats* st) {
     timing = (st != nullptr);
     spans.clear();
     events_used = 0;
+    phase = "";
+    seg_begin();
     if (st) {
         memset(st, 0, sizeof(*st));
         ev_begin = get_event();
@@ -60,6 +112,7 @@ void tdx_context::span_end(int index) {
 }
 
 void tdx_context::end_call() {
+    seg_end(2);
     if (timing) {
         ev_end = get_event();
         (void)hipEventRecord(ev_end, stream);
@@ -93,12 +146,33 @@ const char* tdx_version(void) { return "taudem_amd 0.1.0 (TauDEM 5.4.0 hot path,
 int tdx_context_set_option(tdx_context* c, const char* name, int64_t value) {
     if (!c || !name) return TDX_ERR_ARG;
     if (strcmp(name, "kernel_timing") == 0) { c->kernel_timing = value != 0; return TDX_OK; }
+    if (strcmp(name, "segment_trace") == 0) {
+        if (value < 0 || value > 2) return tdx_fail(c, TDX_ERR_ARG, "segment_trace: 0 (off), 1 (timed) or 2 (timed, one rank on the device at a time)");
+        c->seg_mode = int(value);
+        c->segments.clear();
+        return TDX_OK;
+    }
     return tdx_fail(c, TDX_ERR_ARG, std::string("unknown option ") + name);
 }
 
 void tdx_context_comm_counters(const tdx_context* c, int64_t* exchanges, int64_t* allreduces) {
     if (exchanges) *exchanges = c ? c->comm_exchanges_total : 0;
     if (allreduces) *allreduces = c ? c->comm_allreduces_total : 0;
+}
+
+int64_t tdx_context_segments(tdx_context* c, tdx_segment* out, int64_t capacity) {
+    if (!c) return 0;
+    const int64_t n = int64_t(c->segments.size());
+    for (int64_t i = 0; out && i < n && i < capacity; i++) {
+        const tdx_context::Segment& g = c->segments[size_t(i)];
+        tdx_segment& o = out[i];
+        memset(&o, 0, sizeof(o));
+        strncpy(o.stage, g.stage ? g.stage : "", sizeof(o.stage) - 1);
+        strncpy(o.phase, g.phase ? g.phase : "", sizeof(o.phase) - 1);
+        o.kind = g.kind; o.device_ms = g.device_ms; o.wall_ms = g.wall_ms;
+    }
+    if (out) c->segments.clear();
+    return n;
 }
 
 int tdx_device_count(void) {
@@ -151,6 +225,7 @@ void tdx_context_destroy(tdx_context* c) {
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->seg_ev0) { (void)hipEventDestroy(c->seg_ev0); (void)hipEventDestroy(c->seg_ev1); }
     for (hipEvent_t e : c->ev_batch) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

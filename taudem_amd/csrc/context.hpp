@@ -48,6 +48,7 @@ struct tdx_context {
     // pinned host mailbox for small device->host readbacks (counters, flags)
     uint64_t* h_mail = nullptr;              // TDX_MAIL_WORDS words, hipHostMalloc (layout: the TDX_MAIL_* offsets below)
     uint64_t* d_mail = nullptr;              // TDX_MAIL_WORDS words of device memory
+    uint32_t run_seq = 0;                    // sequence number of the last batch of rounds enqueued on this context (tile_relax.hpp: RoundRunner::enqueue)
 
     // ---- timing ----
     struct Span { hipEvent_t a, b; int kclass; };
@@ -65,10 +66,24 @@ struct tdx_context {
     int64_t comm_exchanges = 0, comm_allreduces = 0;   // of the running call
     int64_t comm_exchanges_total = 0, comm_allreduces_total = 0;   // since the context was created (tdx_context_comm_counters)
 
+    // ---- segment trace (option "segment_trace"; scripts/project_8gpu.py): a strip run is a sequence of SEGMENTS of rank-local work, each ended by a
+    // collective (halo exchange / all-reduce) or by the end of the call.  Every rank passes through the same sequence (the protocol is rank-symmetric),
+    // so the critical path of a real N-GPU run is  sum over segments of (max over ranks of the segment's time) + collectives x their latency  - which
+    // can be measured on ONE GPU: mode 2 serialises the ranks' segments through a process-wide token, so that each segment is timed alone on the device.
+    struct Segment { const char* stage; const char* phase; int kind; float device_ms; float wall_ms; };   // kind: 0 exchange, 1 all-reduce, 2 end of call
+    int seg_mode = 0;                         // 0 off, 1 timed, 2 timed + one rank on the device at a time
+    bool seg_open = false, seg_token = false;
+    hipEvent_t seg_ev0 = nullptr, seg_ev1 = nullptr;
+    double seg_t0 = 0.0;
+    const char* phase = "";                   // sub-stage of the running call (free text: "forest", "big cells" ...)
+    std::vector<Segment> segments;
+    void seg_begin();                         // after a collective has returned / at the start of a call
+    void seg_end(int kind);                   // before a collective is entered / at the end of a call
+
     hipEvent_t get_event();
     void begin_call(tdx_stats* st);
     void end_call();                          // synchronises, fills stats
-    void abort_call() { timing = false; cur_stats = nullptr; }   // an entry point leaves early: nothing may point at the caller's stats any more
+    void abort_call();   // an entry point leaves early: nothing may point at the caller's stats any more
     int span_begin(int kclass);              // returns the span's index (-1 when timing is off); spans may nest
     void span_end(int index);
 };

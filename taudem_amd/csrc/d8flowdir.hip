@@ -226,9 +226,10 @@ __device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, siz
 // (62-column window like d8_slope_kernel: a lane loads ONE value per row and array, the west / east neighbours are lane shifts; the 2 x 18 row
 // loads of a lane are issued back to back.  The first version read three overlapping cells per row and array inside the row loop: 1.36 ms.)
 constexpr int CLS_COLS = 62;
+template <class LV>
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
-                                                                 int y_own0, int y_own1, int tiles_x, lvl_t* __restrict__ lvl,
-                                                                 lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                                 int y_own0, int y_own1, int tiles_x, LV* __restrict__ lvl,
+                                                                 LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
                                                                  uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap) {
     using tilek::lane_left;
     using tilek::lane_right;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
         const int ps0 = lane_left(ps1, 0), ps2 = lane_right(ps1, 0);
         if (mine && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-            lvl_t l = -1, q = -1;
+            LV l = -1, q = -1;
             unsigned fm = 0, rm = 0;
             if (pc1 == 0) {   // a flat cell: interior, all eight neighbours valid
                 const float z0 = zc1;
@@ -323,16 +324,17 @@ struct D8Traits {
 };
 
 // setFlow2 (src/d8.cpp:412-454) for every cell of the flat list
+template <class LV>
 __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restrict__ Z, int nx, const double* __restrict__ fact,
                                                           const uint32_t* __restrict__ list, unsigned long long nq,
-                                                          const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
+                                                          const LV* __restrict__ lvl, const LV* __restrict__ rq,
                                                           FlatLevels fl, int16_t* __restrict__ P) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
     const int y = int(c / size_t(nx));
     const double* f = fact + size_t(y) * 9;
-    const int e2c = int(flat_elev2(lvl[c], rq[c], fl));
+    const int e2c = int(flat_elev2<LV>(lvl[c], rq[c], fl));
     const float z0 = Z[c];
     float smax = 0.f;
     int16_t dir = P[c];   // 0, or nodata for a cell marked as pit in this iteration
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void d8_setflow2_kernel(const float* __restric
         const int k = order[o];
         const size_t n = size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k));
         if (rq[n] > 0) {   // dn > 0: neighbour is a marked flat cell
-            const int e2n = int(flat_elev2(lvl[n], rq[n], fl));
+            const int e2n = int(flat_elev2<LV>(lvl[n], rq[n], fl));
             const float slope = (float)(f[k] * (double)(e2c - e2n));
             if (slope > smax) { dir = int16_t(k); smax = slope; }
         } else {
@@ -371,8 +373,9 @@ __global__ __launch_bounds__(256) void d8_recollect_kernel(const int16_t* __rest
     for (unsigned i = 0; i < cnt; i++) out[pos + i] = keep[i];
 }
 
+template <class LV>
 __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                           const lvl_t* __restrict__ lvl, int16_t* __restrict__ P) {
+                                                           const LV* __restrict__ lvl, int16_t* __restrict__ P) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
@@ -387,11 +390,12 @@ __global__ __launch_bounds__(256) void d8_mark_pits_kernel(const uint32_t* __res
 // DPP lane shift of a register (3 coalesced loads per window row instead of 9), and only the window rows next to a row
 // that holds a flat cell are loaded at all (wave-uniform branches; flats are clustered).
 constexpr int SF2_COLS = 62;
+template <class LV>
 __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1,
-                                                                 const double* __restrict__ fact, const lvl_t* __restrict__ lvl,
-                                                                 const lvl_t* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
+                                                                 const double* __restrict__ fact, const LV* __restrict__ lvl,
+                                                                 const LV* __restrict__ rq, FlatLevels fl, int16_t* __restrict__ P,
                                                                  uint32_t* __restrict__ qnext, unsigned long long* __restrict__ counter, int nbx, int xmap,
-                                                                 lvl_t* __restrict__ lvl_next, lvl_t* __restrict__ rq_next) {
+                                                                 LV* __restrict__ lvl_next, LV* __restrict__ rq_next) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int bx = tdxk::xcd_block_x(nbx, xmap);
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < SLOPE_ROWS + 2; j++) {
             if (e2[j] == 0) pit |= 1u << j;
-            e2[j] = int(flat_elev2(e2[j], rr[j], fl));
+            e2[j] = int(flat_elev2<LV>(e2[j], rr[j], fl));
         }
 #pragma unroll
         for (int r = 0; r < SLOPE_ROWS; r++) {
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
         for (int r = 0; r < SLOPE_ROWS; r++) {
             if (mine && ybase + r < y_own1) {
                 const size_t idx = size_t(ybase + r) * size_t(nx) + size_t(x);
-                const lvl_t m = ((keep >> r) & 1u) ? lvl_t(0) : lvl_t(-1);
+                const LV m = ((keep >> r) & 1u) ? LV(0) : LV(-1);
                 lvl_next[idx] = m;
                 rq_next[idx] = m;
             }
@@ -528,7 +532,8 @@ int tdx_build_fact_table(tdx_context* ctx, int64_t ny, const double* dxc, const 
 
 // One strip of setdird8() (src/d8.cpp:227-320).  Counts that steer the outer loop (flats left) are summed
 // over the ranks, so every rank takes the same branches (src/d8.cpp:294-316).
-static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, int16_t* d_p,
+template <class LV>
+static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, int16_t* d_p,
                           float* d_sd8, tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -539,8 +544,8 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     if (rc != TDX_OK) return rc;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
     // flat-resolution markers and the flat queue are produced by the slope pass itself
-    lvl_t* lvl = static_cast<lvl_t*>(ctx->scratch(TDX_S_A, n * sizeof(lvl_t)));
-    lvl_t* rq = static_cast<lvl_t*>(ctx->scratch(TDX_S_B, n * sizeof(lvl_t)));
+    LV* lvl = static_cast<LV*>(ctx->scratch(TDX_S_A, n * sizeof(LV)));
+    LV* rq = static_cast<LV*>(ctx->scratch(TDX_S_B, n * sizeof(LV)));
     uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, n * 4));
     if (!lvl || !rq || !qlist) return TDX_ERR_NOMEM;
 
@@ -596,7 +601,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
         if (!qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;            // allocated only if a second iteration is needed
         const float* zcur = d_fel;
-        FlatBuffers fbuf{lvl, rq};
+        FlatBuffersT<LV> fbuf{lvl, rq};
 
         // first call of resolveflats: queue = cells with flowDir == 0 (src/d8.cpp:492-503) = qlist from the slope pass
         int64_t last = total;
@@ -604,7 +609,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
         bool sparse = false;                // this iteration works from lists (few flats left): no pass over the whole raster
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
         bool old_list_valid = false;        // ... and whether qnext really holds them
-        lvl_t *lvl_next = nullptr, *rq_next = nullptr;   // the next iteration's markers, written by the streaming setFlow2 (rasters of their own)
+        LV *lvl_next = nullptr, *rq_next = nullptr;   // the next iteration's markers, written by the streaming setFlow2 (rasters of their own)
         bool markers_ready = false;
         for (;;) {
             // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
@@ -614,17 +619,17 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked) {
                 const int nbx = (st.nx + CLS_COLS - 1) / CLS_COLS;
                 const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
-                hipLaunchKernelGGL(d8_classify_stream_kernel, grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
+                hipLaunchKernelGGL((d8_classify_stream_kernel<LV>), grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
                                    rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0);
             };
             if (sparse && markers_ready) {
                 // the streaming setFlow2 of the previous iteration left this iteration's markers in the second pair of rasters
                 std::swap(lvl, lvl_next);
                 std::swap(rq, rq_next);
-                fbuf = FlatBuffers{lvl, rq};
-                rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows (flats_reset_markers)
+                fbuf = FlatBuffersT<LV>{lvl, rq};
+                rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows (flats_reset_markers)
                 if (rc != TDX_OK) return rc;
-                rc = strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
+                rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
                 if (rc != TDX_OK) return rc;
             } else if (sparse) {
                 // the previous queue exists as a list only if it was built (first queue of a dense strip: bit masks only) - without one every marker is rewritten
@@ -633,7 +638,7 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
             }
             markers_ready = false;
             // (the first queue of a dense strip exists as bit masks only: no list)
-            rc = flats_bfs<D8Traits>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
+            rc = flats_bfs<D8Traits, LV>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
@@ -643,17 +648,17 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
                     const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                     static const bool no_next = getenv("TDX_FLATS_NO_NEXT_MARKERS") != nullptr;   // (A/B hook)
                     if (!no_next && !lvl_next) {
-                        lvl_next = static_cast<lvl_t*>(ctx->scratch(TDX_S_P, n * sizeof(lvl_t)));
-                        rq_next = static_cast<lvl_t*>(ctx->scratch(TDX_S_R, n * sizeof(lvl_t)));
+                        lvl_next = static_cast<LV*>(ctx->scratch(TDX_S_P, n * sizeof(LV)));
+                        rq_next = static_cast<LV*>(ctx->scratch(TDX_S_R, n * sizeof(LV)));
                         if (!lvl_next || !rq_next) return TDX_ERR_NOMEM;
                     }
-                    hipLaunchKernelGGL(d8_setflow2_stream_kernel, grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
+                    hipLaunchKernelGGL((d8_setflow2_stream_kernel<LV>), grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
                                        d_cnt, nbx, tdx_xcd_map() ? 1 : 0, lvl_next, rq_next);
                     markers_ready = lvl_next != nullptr;
                 } else if (nq) {
                     if (fl.has_pits)
-                        hipLaunchKernelGGL(d8_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
-                    hipLaunchKernelGGL(d8_setflow2_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
+                        hipLaunchKernelGGL((d8_mark_pits_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
+                    hipLaunchKernelGGL((d8_setflow2_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
                     hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
                 }
                 TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -689,6 +694,17 @@ static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float
     TDX_HIP_CHECK(ctx, hipGetLastError());
     ctx->end_call();
     return TDX_OK;
+}
+
+// The level fields are int16 like the reference's elev2 / dn / s partitions (src/d8.cpp:483,486,595); a flat deeper than they hold (32 766 levels - the
+// reference's short counters wrap there, so nothing there is defined to be equal to) starts the call over on int32 fields: the slope pass is repeated, the
+// inputs are untouched (elevDEM := elev2 works on a copy).  Every rank sees the same level maxima, so every rank takes the same path.
+// TDX_LEVELS_INT32=1 (test hook, read per call): int32 fields from the start.
+static int d8flowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, int16_t* d_p,
+                          float* d_sd8, tdx_stats* stats) {
+    int rc = getenv("TDX_LEVELS_INT32") ? TDX_FLATS_TOO_DEEP : d8flowdir_levels<int16_t>(ctx, st, d_fel, fel_nodata, dxc, dyc, d_p, d_sd8, stats);
+    if (rc == TDX_FLATS_TOO_DEEP) rc = d8flowdir_levels<int32_t>(ctx, st, d_fel, fel_nodata, dxc, dyc, d_p, d_sd8, stats);
+    return rc;
 }
 
 extern "C" int tdx_d8flowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,

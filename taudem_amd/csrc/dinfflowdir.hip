@@ -186,8 +186,9 @@ struct DinfTraits {
 __device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, TDX_ANG_NODATA) && a < 0.0f; }
 
 // flat queue + markers (8 cells per lane, one atomic per block)
-__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, lvl_t* __restrict__ lvl,
-                                                                 lvl_t* __restrict__ rq, uint32_t* __restrict__ list,
+template <class LV>
+__global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, LV* __restrict__ lvl,
+                                                                 LV* __restrict__ rq, uint32_t* __restrict__ list,
                                                                  unsigned long long* __restrict__ counter) {
     // a thread takes EIGHT CONSECUTIVE cells (and block_reserve hands out slots in thread order), so the list is in raster order: the list kernels of
     // flat resolution gather the 3 x 3 windows of 64 consecutive entries per wave - with a thread's cells 256 apart, as they were, consecutive entries
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (c0 + i < n && dinf_is_flat(a[i])) mask |= 1u << i;
-    if (c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {
+    if (sizeof(LV) == 2 && c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {   // eight int16 markers = one 16-byte store
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) w[j] = (((mask >> (2 * j)) & 1u) ? 0u : 0xFFFFu) | (((mask >> (2 * j + 1)) & 1u) ? 0u : 0xFFFF0000u);   // 0 in the queue, -1 outside
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            if (c0 + i < n) { const lvl_t m = ((mask >> i) & 1u) ? lvl_t(0) : lvl_t(-1); lvl[c0 + i] = m; rq[c0 + i] = m; }
+            if (c0 + i < n) { const LV m = ((mask >> i) & 1u) ? LV(0) : LV(-1); lvl[c0 + i] = m; rq[c0 + i] = m; }
     }
     unsigned long long pos = block_reserve(unsigned(__popc(mask)), counter);
 #pragma unroll
@@ -223,8 +224,9 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
         if (mask & (1u << i)) list[pos++] = uint32_t(c0 + size_t(i));
 }
 
+template <class LV>
 __global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                             const lvl_t* __restrict__ lvl, float* __restrict__ ANG) {
+                                                             const LV* __restrict__ lvl, float* __restrict__ ANG) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const size_t c = list[q];
@@ -237,9 +239,10 @@ __global__ __launch_bounds__(256) void dinf_mark_pits_kernel(const uint32_t* __r
 // Here the whole 3 x 3 neighbourhood of the three arrays is requested up front (27 loads in flight together: one latency), the facet
 // loop is unrolled over registers with a `done` flag in place of the break, and VSLOPE's atan2 is evaluated once, for the facet that
 // wins (vslope_s decides its three branches without the angle, as in dinf_slope_kernel).
+template <class LV>
 __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restrict__ Z, int nx, const RowGeom* __restrict__ geom,
                                                             const uint32_t* __restrict__ list, unsigned long long nq,
-                                                            const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
+                                                            const LV* __restrict__ lvl, const LV* __restrict__ rq,
                                                             FlatLevels fl, float* __restrict__ ANG) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
     const int y = int(c0 / size_t(nx));
     // window w[(di + 1) * 3 + (dj + 1)]: a flat cell is an interior cell, all nine cells exist
     float zw[9];
-    lvl_t lw[9], rw[9];
+    LV lw[9], rw[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const size_t n = size_t(ptrdiff_t(c0) + ptrdiff_t(i / 3 - 1) * nx + (i % 3 - 1));
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void dinf_set2flat_kernel(const float* __restr
     const RowGeom g = geom[y];
     int e2w[9];   // elev2 + s of the nine cells (src/d8.cpp:545,640-645; only read where the cell is a marked flat cell)
 #pragma unroll
-    for (int i = 0; i < 9; i++) e2w[i] = int(flat_elev2(lw[i], rw[i], fl));
+    for (int i = 0; i < 9; i++) e2w[i] = int(flat_elev2<LV>(lw[i], rw[i], fl));
     double SMAX = 0.0;
     int KD = 0, KINDW = 0;          // winning facet; how its angle follows: 0: A = 0, 1: A = AD, 2: A = atan2(S2W, S1W)
     double S1W = 0., S2W = 0.;
@@ -323,7 +326,8 @@ __global__ __launch_bounds__(256) void dinf_recollect_kernel(const float* __rest
 }  // namespace
 
 // One strip of setdir() (src/dinf.cpp:156-243); the same strip protocol as d8flowdir_impl (d8flowdir.hip).
-static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, float* d_ang,
+template <class LV>
+static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, float* d_ang,
                             float* d_slp, tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -366,23 +370,23 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
     if (stats) { stats->flats_initial = total; stats->flats_left = total; }
 
     if (total > 0) {
-        lvl_t* lvl = static_cast<lvl_t*>(ctx->scratch(TDX_S_A, n * sizeof(lvl_t)));
-        lvl_t* rq = static_cast<lvl_t*>(ctx->scratch(TDX_S_B, n * sizeof(lvl_t)));
+        LV* lvl = static_cast<LV*>(ctx->scratch(TDX_S_A, n * sizeof(LV)));
+        LV* rq = static_cast<LV*>(ctx->scratch(TDX_S_B, n * sizeof(LV)));
         uint32_t* qlist = static_cast<uint32_t*>(ctx->scratch(TDX_S_C, size_t(nq) * 4));
         uint32_t* qnext = static_cast<uint32_t*>(ctx->scratch(TDX_S_D, size_t(nq) * 4));
         if (!lvl || !rq || !qlist || !qnext) return TDX_ERR_NOMEM;
         float* zwork = nullptr;
         const float* zcur = d_fel;
-        FlatBuffers fbuf{lvl, rq};
+        FlatBuffersT<LV> fbuf{lvl, rq};
         rc = strip_exchange<float>(ctx, st, d_ang, TDX_ANG_NODATA);   // angles of the neighbours' boundary rows
         if (rc != TDX_OK) return rc;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
         const size_t own_first = size_t(st.y0) * size_t(inx), own_end = size_t(st.y1) * size_t(inx);
-        hipLaunchKernelGGL(dinf_collect_flats_kernel, dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
+        hipLaunchKernelGGL((dinf_collect_flats_kernel<LV>), dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
                            qlist, d_cnt);
-        rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows
+        rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
         if (rc != TDX_OK) return rc;
-        rc = strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
+        rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
         if (rc != TDX_OK) return rc;
         int64_t last = total;
         bool first = true;
@@ -392,15 +396,15 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
-            rc = flats_bfs<DinfTraits>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
+            rc = flats_bfs<DinfTraits, LV>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
             if (rc != TDX_OK) return rc;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
                 if (nq) {
                     if (fl.has_pits)
-                        hipLaunchKernelGGL(dinf_mark_pits_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
-                    hipLaunchKernelGGL(dinf_set2flat_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
+                        hipLaunchKernelGGL((dinf_mark_pits_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
+                    hipLaunchKernelGGL((dinf_set2flat_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
                     hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_cnt);
                 }
                 TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -428,6 +432,16 @@ static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, flo
     TDX_HIP_CHECK(ctx, hipGetLastError());
     ctx->end_call();
     return TDX_OK;
+}
+
+// The level fields are int16 like the reference's elev2 / dn / s partitions (src/dinf.cpp:614-617); a flat deeper than they hold (32 766 levels - the
+// reference's short counters wrap there, so nothing there is defined to be equal to) starts the call over on int32 fields.  TDX_LEVELS_INT32=1 (test
+// hook, read per call): int32 fields from the start.
+static int dinfflowdir_impl(tdx_context* ctx, const Strip& st, float* d_fel, float fel_nodata, const double* dxc, const double* dyc, float* d_ang,
+                            float* d_slp, tdx_stats* stats) {
+    int rc = getenv("TDX_LEVELS_INT32") ? TDX_FLATS_TOO_DEEP : dinfflowdir_levels<int16_t>(ctx, st, d_fel, fel_nodata, dxc, dyc, d_ang, d_slp, stats);
+    if (rc == TDX_FLATS_TOO_DEEP) rc = dinfflowdir_levels<int32_t>(ctx, st, d_fel, fel_nodata, dxc, dyc, d_ang, d_slp, stats);
+    return rc;
 }
 
 extern "C" int tdx_dinfflowdir_dev(tdx_context* ctx, const float* d_fel, int64_t nx, int64_t ny, float fel_nodata,

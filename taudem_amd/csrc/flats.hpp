@@ -39,13 +39,18 @@ struct FlatLevels { int T; int Tr; int has_pits; };
 // (the reference's int16 counters overflow there too).
 using lvl_t = int16_t;
 constexpr int LVL_SAT = 32767;
-struct FlatBuffers { lvl_t* lvl; lvl_t* rq; };
+constexpr int TDX_FLATS_TOO_DEEP = -4242;   // internal: flats_bfs on int16 fields met a level beyond them; the caller re-runs on int32 fields
+template <class LV>
+struct FlatBuffersT { LV* lvl; LV* rq; };
+using FlatBuffers = FlatBuffersT<lvl_t>;
 
 // elev2 + s as the reference's int16 arithmetic leaves it (src/d8.cpp:545,640-645)
-__host__ __device__ __forceinline__ int16_t flat_elev2(int lvl, int rq, FlatLevels fl) {
+// (LV = int16: wraps like the reference's short; LV = int32: the wider fields of a flat deeper than 32 766 levels, see flats_bfs)
+template <class LV>
+__host__ __device__ __forceinline__ LV flat_elev2(int lvl, int rq, FlatLevels fl) {
     const int e = (lvl < 0) ? 1 : (lvl > 0 ? lvl : 1 + fl.T);
     const int s = (rq > 0) ? (fl.Tr - rq + 1) : 0;
-    return (int16_t)(e + s);
+    return (LV)(e + s);
 }
 
 namespace flatk {
@@ -55,10 +60,10 @@ using namespace tdxk;
 // masks of both relaxations (bit k-1 = neighbour k may hand its level to this cell) and the
 // activation flag of the cell's tile.  Flat cells are interior cells, so all 8 neighbours exist.
 constexpr int CLASSIFY_ITEMS = 4;
-template <class Traits>
+template <class Traits, class LV>
 __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* __restrict__ Z, int nx, int tiles_x,
-                                                       const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
-                                                       lvl_t* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                       const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
+                                                       LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
                                                        uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * CLASSIFY_ITEMS) + threadIdx.x;
 #pragma unroll
@@ -171,8 +176,9 @@ using LevelOp = LevelOpT<1, lvl_t>;
 using ReachOp = LevelOpT<0, int32_t>;
 
 // out[0] = max level, out[1] = #cells never reached by incfall, out[2] = max incrise level
+template <class LV>
 static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* __restrict__ list, unsigned long long nq,
-                                                                const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
+                                                                const LV* __restrict__ lvl, const LV* __restrict__ rq,
                                                                 unsigned long long* __restrict__ out) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * 8) + threadIdx.x;
     int ml = 0, mr = 0;
@@ -212,12 +218,13 @@ static __global__ __launch_bounds__(256) void flat_stats_kernel(const uint32_t* 
 
 // the same three numbers from a pass over the owned rows (cells outside the queue hold -1 in both fields): for a dense queue, where
 // reading two int16 per cell costs less than building and gathering through a list of a third of the raster
-static __global__ __launch_bounds__(256) void flat_stats_stream_kernel(const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq, size_t first, size_t count,
+template <class LV>
+static __global__ __launch_bounds__(256) void flat_stats_stream_kernel(const LV* __restrict__ lvl, const LV* __restrict__ rq, size_t first, size_t count,
                                                                        unsigned long long* __restrict__ out) {
     const size_t base = first + size_t(blockIdx.x) * (256 * 16) + size_t(threadIdx.x);
     int ml = 0, mr = 0;
     unsigned unv = 0;
-    lvl_t l[16], r[16];
+    LV l[16], r[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {   // all loads first (clamped), a wave reads 128 contiguous bytes of each field per step
         const size_t c = base + size_t(i) * 256, cc = c < first + count ? c : first + count - 1;
@@ -254,7 +261,7 @@ static __global__ __launch_bounds__(256) void flat_stats_stream_kernel(const lvl
 
 // the same, 8 cells per 16-byte load (first and count multiples of 8: whole rows of a raster whose width is one): the one-cell form spends its
 // time on 2-byte load instructions, not on bytes
-static __global__ __launch_bounds__(256) void flat_stats_stream8_kernel(const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq, size_t first, size_t count,
+static __global__ __launch_bounds__(256) void flat_stats_stream8_kernel(const int16_t* __restrict__ lvl, const int16_t* __restrict__ rq, size_t first, size_t count,
                                                                         unsigned long long* __restrict__ out) {
     const size_t nvec = count / 8;
     const uint4* L = reinterpret_cast<const uint4*>(lvl + first);
@@ -306,24 +313,27 @@ static __global__ __launch_bounds__(256) void flat_stats_stream8_kernel(const lv
     }
 }
 
-static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
-                                                      lvl_t* __restrict__ rq) {
+template <class LV>
+static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
+                                                      LV* __restrict__ rq) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     lvl[list[q]] = 0;
     rq[list[q]] = 0;
 }
 
-static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq,
+template <class LV>
+static __global__ __launch_bounds__(256) void overwrite_elev_kernel(size_t n, const LV* __restrict__ lvl, const LV* __restrict__ rq,
                                                              FlatLevels fl, float* __restrict__ Zout) {
     const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i < n) Zout[i] = (float)flat_elev2(lvl[i], rq[i], fl);
+    if (i < n) Zout[i] = (float)flat_elev2<LV>(lvl[i], rq[i], fl);
 }
 
 // The next iteration's elevation only where it will be read: on the cells of the new flat queue and their 8 neighbours (flat
 // cells are interior cells).  Several threads may store the same value to one cell.
+template <class LV>
 static __global__ __launch_bounds__(256) void overwrite_elev_sparse_kernel(const uint32_t* __restrict__ list, unsigned long long nq, int nx,
-                                                                           const lvl_t* __restrict__ lvl, const lvl_t* __restrict__ rq, FlatLevels fl,
+                                                                           const LV* __restrict__ lvl, const LV* __restrict__ rq, FlatLevels fl,
                                                                            float* __restrict__ Zout) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
@@ -337,13 +347,14 @@ static __global__ __launch_bounds__(256) void overwrite_elev_sparse_kernel(const
 #pragma unroll
     for (int k = 0; k <= 8; k++) {
         const size_t n = k ? size_t(ptrdiff_t(c) + ptrdiff_t(d2(k)) * nx + d1(k)) : c;
-        Zout[n] = (float)flat_elev2(l[k], r[k], fl);
+        Zout[n] = (float)flat_elev2<LV>(l[k], r[k], fl);
     }
 }
 
 // markers of the cells of the PREVIOUS queue back to "not in Q"
-static __global__ __launch_bounds__(256) void unmark_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, lvl_t* __restrict__ lvl,
-                                                              lvl_t* __restrict__ rq) {
+template <class LV>
+static __global__ __launch_bounds__(256) void unmark_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
+                                                              LV* __restrict__ rq) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     lvl[list[q]] = -1;
@@ -358,40 +369,44 @@ static inline int flats_read_counters(tdx_context* ctx, int nwords) {
     return TDX_OK;
 }
 
-static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const uint32_t* qlist, unsigned long long nq, lvl_t* lvl, lvl_t* rq) {
+template <class LV>
+static inline int flats_reset_markers(tdx_context* ctx, const Strip& st, const uint32_t* qlist, unsigned long long nq, LV* lvl, LV* rq) {
     const size_t n = size_t(st.nx) * size_t(st.ny_arr);
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(lvl, 0xFF, n * sizeof(lvl_t), ctx->stream));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(rq, 0xFF, n * sizeof(lvl_t), ctx->stream));
-    if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
-    int rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));   // queue membership of the neighbours' boundary rows
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(lvl, 0xFF, n * sizeof(LV), ctx->stream));
+    TDX_HIP_CHECK(ctx, hipMemsetAsync(rq, 0xFF, n * sizeof(LV), ctx->stream));
+    if (nq) hipLaunchKernelGGL((flatk::reset_q_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
+    int rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
-    return strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
+    return strip_exchange<LV>(ctx, st, rq, LV(-1));
 }
 
 // Same markers as flats_reset_markers when lvl / rq are "not in Q" everywhere except on the cells of the previous queue `qold`
 // (which is what a flat iteration leaves behind): a later iteration of a few thousand cells does not rewrite two rasters.
+template <class LV>
 static inline int flats_reset_markers_after(tdx_context* ctx, const Strip& st, const uint32_t* qold, unsigned long long nq_old, const uint32_t* qlist,
-                                            unsigned long long nq, lvl_t* lvl, lvl_t* rq) {
+                                            unsigned long long nq, LV* lvl, LV* rq) {
     const size_t n = size_t(st.nx) * size_t(st.ny_arr);
     if (nq_old > n / 16) return flats_reset_markers(ctx, st, qlist, nq, lvl, rq);
-    if (nq_old) hipLaunchKernelGGL(flatk::unmark_q_kernel, dim3(tdx_blocks_for(nq_old, 256)), dim3(256), 0, ctx->stream, qold, nq_old, lvl, rq);
-    if (nq) hipLaunchKernelGGL(flatk::reset_q_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
-    int rc = strip_exchange<lvl_t>(ctx, st, lvl, lvl_t(-1));
+    if (nq_old) hipLaunchKernelGGL((flatk::unmark_q_kernel<LV>), dim3(tdx_blocks_for(nq_old, 256)), dim3(256), 0, ctx->stream, qold, nq_old, lvl, rq);
+    if (nq) hipLaunchKernelGGL((flatk::reset_q_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, lvl, rq);
+    int rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));
     if (rc != TDX_OK) return rc;
-    return strip_exchange<lvl_t>(ctx, st, rq, lvl_t(-1));
+    return strip_exchange<LV>(ctx, st, rq, LV(-1));
 }
 
 // elevDEM := (float)elev2 where the next iteration (queue `qlist`) reads it: the queue cells and their neighbours
-static inline int flats_overwrite_elevation_sparse(tdx_context* ctx, int nx, const uint32_t* qlist, unsigned long long nq, const lvl_t* lvl, const lvl_t* rq,
+template <class LV>
+static inline int flats_overwrite_elevation_sparse(tdx_context* ctx, int nx, const uint32_t* qlist, unsigned long long nq, const LV* lvl, const LV* rq,
                                                    FlatLevels fl, float* zout) {
     TdxSpan sp(ctx, TDX_K_MISC);
-    if (nq) hipLaunchKernelGGL(flatk::overwrite_elev_sparse_kernel, dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, nx, lvl, rq, fl, zout);
+    if (nq) hipLaunchKernelGGL((flatk::overwrite_elev_sparse_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, ctx->stream, qlist, nq, nx, lvl, rq, fl, zout);
     return TDX_OK;
 }
 
-static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const lvl_t* lvl, const lvl_t* rq, FlatLevels fl, float* zout) {
+template <class LV>
+static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const LV* lvl, const LV* rq, FlatLevels fl, float* zout) {
     TdxSpan sp(ctx, TDX_K_MISC);
-    hipLaunchKernelGGL(flatk::overwrite_elev_kernel, dim3(tdx_blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, lvl, rq, fl, zout);
+    hipLaunchKernelGGL((flatk::overwrite_elev_kernel<LV>), dim3(tdx_blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, lvl, rq, fl, zout);
     return TDX_OK;
 }
 
@@ -421,9 +436,10 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 // whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags; qlist may then be null (no list was
 // built for a dense queue): the level statistics come from a pass over the owned rows instead.
 using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked)>;
-template <class Traits>
+template <class Traits, class LV>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
-                     FlatBuffers b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr) {
+                     FlatBuffersT<LV> b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr) {
+    using LOp = flatk::LevelOpT<1, LV>;
     hipStream_t s = ctx->stream;
     const int nx = st.nx;
     const size_t n = size_t(nx) * size_t(st.ny_arr);
@@ -451,16 +467,17 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
         TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
         if (nq)
-            hipLaunchKernelGGL((flatk::classify_kernel<Traits>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
+            hipLaunchKernelGGL((flatk::classify_kernel<Traits, LV>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
                                geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask);
     }
-    int rc = strip_exchange<lvl_t>(ctx, st, b.lvl, lvl_t(-1));   // the neighbours' seeds
+    int rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;
-    rc = strip_exchange<lvl_t>(ctx, st, b.rq, lvl_t(-1));
+    rc = strip_exchange<LV>(ctx, st, b.rq, LV(-1));
     if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
     static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;
-    if (!st.multi() && !ctx->kernel_timing && !no_pair) {
+    static const bool strips_sequential = getenv("TDX_FLATS_STRIPS_SEQUENTIAL") != nullptr;   // (A/B hook: one field after the other in a multi-strip run)
+    if (!(st.multi() && strips_sequential) && !ctx->kernel_timing && !no_pair) {
         // the two level fields are independent: relax them side by side on two streams (own flags / list / counts each)
         uint32_t* flagsB = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS)));
         unsigned long long* countsB = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
@@ -471,29 +488,47 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         // two round schedules on two HIP streams; TDX_FLATS_FUSED=1 (read per call): one launch per round for both fields on one stream - 0.5 ms slower at 16384^2
         // (a round ends when the slower field's does), but independent of how the runtime schedules two streams
         const bool two_streams = getenv("TDX_FLATS_FUSED") == nullptr || getenv("TDX_RELAX_LDS") != nullptr;
-        rc = two_streams ? tile_relax_run_pair(ctx, flatk::LevelOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
-                                               flatk::LevelOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches)
-                         : tile_relax_run_fused(ctx, flatk::LevelOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
-                                                flatk::LevelOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
-        if (rc != TDX_OK) return rc;
+        // Multi-strip: both fields to their strip-local fixed points side by side, then BOTH boundary rows are exchanged and one vote decides - the outer
+        // rounds are those of the deeper field instead of the sum of both, and the shallower field's relaxation hides behind the deeper one's
+        // (profiles/r05b_*: incrise's 6.7 + 1.5 ms of the critical path at BASELINE.json configs[3] ran after incfall's 27 ms).
+        for (;;) {
+            rc = two_streams ? tile_relax_run_pair(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
+                                                   LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches)
+                             : tile_relax_run_fused(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
+                                                    LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
+            if (rc != TDX_OK) return rc;
+            if (!st.multi()) break;
+            int64_t ch_fall = 0, ch_rise = 0;
+            rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1), flags, geom.tiles_x, &ch_fall);
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange<LV>(ctx, st, b.rq, LV(-1), flagsB, geom.tiles_x, &ch_rise);
+            if (rc != TDX_OK) return rc;
+            int64_t changed = ch_fall + ch_rise;
+            rc = strip_allreduce(ctx, st, &changed, 1, TDX_OP_SUM);
+            if (rc != TDX_OK) return rc;
+            if (changed == 0) break;
+        }
     } else {
         // ---- incfall ----
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches, tmask);
+        rc = flats_relax_field<LOp>(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches, tmask);
         if (rc != TDX_OK) return rc;
         // ---- incrise ----
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
+        rc = flats_relax_field<LOp>(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
         if (rc != TDX_OK) return rc;
     }
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    if (nq && qlist) hipLaunchKernelGGL(flatk::flat_stats_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
+    if (nq && qlist) hipLaunchKernelGGL((flatk::flat_stats_kernel<LV>), dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
     else if (nq) {   // no list (dense first queue of D8FlowDir): one pass over the owned rows
         const size_t first = size_t(st.y0) * size_t(nx), count = size_t(st.y1 - st.y0) * size_t(nx);
-        if (first % 8 == 0 && count % 8 == 0)
-            hipLaunchKernelGGL(flatk::flat_stats_stream8_kernel, dim3(std::min(tdx_blocks_for(count / 8, 256 * 4), 2048u)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
-        else
-            hipLaunchKernelGGL(flatk::flat_stats_stream_kernel, dim3(tdx_blocks_for(count, 256 * 16)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
+        if constexpr (sizeof(LV) == 2) {
+            if (first % 8 == 0 && count % 8 == 0)
+                hipLaunchKernelGGL(flatk::flat_stats_stream8_kernel, dim3(std::min(tdx_blocks_for(count / 8, 256 * 4), 2048u)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
+            else
+                hipLaunchKernelGGL((flatk::flat_stats_stream_kernel<LV>), dim3(tdx_blocks_for(count, 256 * 16)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
+        } else
+            hipLaunchKernelGGL((flatk::flat_stats_stream_kernel<LV>), dim3(tdx_blocks_for(count, 256 * 16)), dim3(256), 0, s, b.lvl, b.rq, first, count, d_cnt);
     }
     rc = flats_read_counters(ctx, 3);
     if (rc != TDX_OK) return rc;
@@ -503,8 +538,13 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     rc = strip_allreduce(ctx, st, &unvisited, 1, TDX_OP_SUM);
     if (rc != TDX_OK) return rc;
     const int L = int(mx[0]), Qmax = int(mx[1]);
-    if (L >= 32767 || Qmax >= 32767)
-        return tdx_fail(ctx, TDX_ERR_ARG, "flat resolution deeper than the reference's int16 level counter allows");
+    // int16 fields (the reference's layout, src/d8.cpp:483,486) hold levels up to 32 766; a deeper flat - where the reference's short counters wrap -
+    // makes the caller start over on int32 fields (TDX_FLATS_TOO_DEEP; every rank sees the same maxima, so every rank does).  TDX_LEVELS_LIMIT: test hook.
+    if (sizeof(LV) == 2) {
+        static const int limit = getenv("TDX_LEVELS_LIMIT") ? std::max(2, std::min(atoi(getenv("TDX_LEVELS_LIMIT")), 32767)) : 32767;
+        if (L >= limit || Qmax >= limit) { ctx->abort_call(); return TDX_FLATS_TOO_DEEP; }
+    } else if (L >= 0x3ffffff0 || Qmax >= 0x3ffffff0)
+        return tdx_fail(ctx, TDX_ERR_ARG, "flat resolution deeper than 2^30 levels");
     out->T = (L == 1 && unvisited == 0) ? 1 : ((L > 1 ? L : 1) + 1);
     out->has_pits = unvisited > 0 ? 1 : 0;
     out->Tr = Qmax + 1;

@@ -209,33 +209,81 @@ struct PitOp {
 
 }  // namespace
 
-// Tightens the start surface W (seed surface of an nx x ny raster, 8-neighbour fill) through coarser levels.
-static int pit_coarse_start(tdx_context* ctx, const float* Z, float* W, int nx, int ny, tilek::Sched sc, int depth, int64_t* rounds, int64_t* launches) {
-    if (depth >= 3 || size_t(nx) * size_t(ny) < (size_t(1) << 18)) return TDX_OK;
+static int pit_finish_level(tdx_context* ctx, const Strip& ls, float* Zc, float* Wc, int nxc, int nyc, int64_t cells_all, tilek::Sched sc, int depth,
+                            int64_t* rounds, int64_t* launches);
+
+// The strip of a coarse level: the rows the rank's owned rows coarsen to, stacked in rank order, ARE a coarsening of the whole raster (a rank's last
+// block row may be lower than CF rows; blocks that touch in the fine raster are neighbours in the stacked coarse raster and vice versa), so a
+// coarse level of a multi-strip run is a row-partitioned raster like the fine one: one halo row each side, the neighbours' boundary rows exchanged.
+// A single strip keeps arrays without halo rows (cells outside the array are inaccessible, like the raster's edge).
+static inline Strip pit_level_strip(const Strip& st, int nxc, int nyc) {
+    Strip ls;
+    ls.nx = nxc; ls.comm = st.comm;
+    if (st.multi()) { ls.ny_arr = nyc + 2; ls.y0 = 1; ls.y1 = nyc + 1; ls.up = st.up; ls.down = st.down; }
+    else { ls.ny_arr = nyc; ls.y0 = 0; ls.y1 = nyc; }
+    return ls;
+}
+
+// One level (fine or coarse) to its fixed point.  Multi-strip: every rank relaxes its strip to the local fixed point with the neighbours' boundary
+// rows frozen in its halo rows, then boundary rows are exchanged and the tiles that see a changed halo cell are re-activated; repeat until no halo
+// cell changed on any rank (the roles of share() + ringTerm() in src/flood.cpp:344-355,457-468).
+template <int NBR>
+static int pit_relax_level(tdx_context* ctx, const Strip& ls, const float* Z, float* W, tilek::Sched sc, int64_t* rounds, int64_t* launches, int64_t* outer) {
     hipStream_t s = ctx->stream;
-    const int nxc = (nx + CF - 1) / CF, nyc = (ny + CF - 1) / CF;
-    const size_t nc = size_t(nxc) * size_t(nyc);
+    const tilek::TileGeom g = tilek::make_geom(ls.nx, ls.ny_arr, ls.y0, ls.y1);
+    const int ntiles = g.tiles_x * g.tiles_y;
+    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));   // round 0: every tile is active
+    for (;;) {
+        int rc = tile_relax_run(ctx, PitOp<NBR>{Z, W}, g, sc, rounds, launches);
+        if (rc != TDX_OK) return rc;
+        if (outer) (*outer)++;
+        if (!ls.multi()) break;
+        int64_t changed = 0;
+        rc = strip_exchange<float>(ctx, ls, W, TDX_FEL_NODATA, sc.flags, g.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
+        if (rc != TDX_OK) return rc;
+        if (changed == 0) break;
+    }
+    return TDX_OK;
+}
+
+// Tightens the start surface of level `depth` (Z, W: its owned rows; 8-neighbour fill) through coarser levels: coarsen, recurse, relax the coarse
+// level ACROSS THE STRIPS, prolong.  cells_all = cells of this level in all strips (every rank passes the same number, so every rank builds the
+// same levels).  In a multi-strip run the coarse levels are what keeps the fine relaxation local: a strip that relaxes on its own from the seed
+// surface can only drain through the raster's edges it owns - an inner strip fills up to its lowest pass to the left / right edge, and the true
+// levels then arrive one strip per exchange, each time re-lowering most of the strip (profiles/r05a_*: 104 ms on the critical path of eight
+// 65536 x 8192 strips against 8.5 ms for a lone strip).  The coarsest level is a few tiles per rank; its exchanges cost microseconds.
+static int pit_coarse_start(tdx_context* ctx, const Strip& st, const float* Z, float* W, int nx, int nyo, int64_t cells_all, tilek::Sched sc, int depth,
+                            int64_t* rounds, int64_t* launches) {
+    if (depth >= 3 || cells_all < (int64_t(1) << 18) || nyo < 1) return TDX_OK;
+    hipStream_t s = ctx->stream;
+    const int nxc = (nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
+    const Strip ls = pit_level_strip(st, nxc, nyc);
+    const size_t nc = size_t(nxc) * size_t(ls.ny_arr), off = size_t(ls.y0) * size_t(nxc);
     float* Zc = static_cast<float*>(ctx->scratch(TDX_S_D + 2 * depth, nc * 4));
     float* Wc = static_cast<float*>(ctx->scratch(TDX_S_E + 2 * depth, nc * 4));
     if (!Zc || !Wc) return TDX_ERR_NOMEM;
     const dim3 gc((nxc + 63) / 64, (nyc + 3) / 4);
-    hipLaunchKernelGGL(pit_coarsen_kernel, gc, dim3(256), 0, s, Z, W, nx, ny, nxc, nyc, Zc, Wc);
-    int rc = pit_coarse_start(ctx, Zc, Wc, nxc, nyc, sc, depth + 1, rounds, launches);
+    hipLaunchKernelGGL(pit_coarsen_kernel, gc, dim3(256), 0, s, Z, W, nx, nyo, nxc, nyc, Zc + off, Wc + off);
+    int rc = pit_finish_level(ctx, ls, Zc, Wc, nxc, nyc, cells_all / (CF * CF), sc, depth, rounds, launches);
     if (rc != TDX_OK) return rc;
-    const tilek::TileGeom g = tilek::make_geom(nxc, nyc, 0, nyc);
-    const int ntiles = g.tiles_x * g.tiles_y;
-    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));
-    rc = tile_relax_run(ctx, PitOp<8>{Zc, Wc}, g, sc, rounds, launches);
-    if (rc != TDX_OK) return rc;
-    const dim3 gf((nx + 63) / 64, (ny + 3) / 4);
-    hipLaunchKernelGGL(pit_prolong_kernel, gf, dim3(256), 0, s, W, nx, ny, Wc, nxc);
+    const dim3 gf((nx + 63) / 64, (nyo + 3) / 4);
+    hipLaunchKernelGGL(pit_prolong_kernel, gf, dim3(256), 0, s, W, nx, nyo, Wc + off, nxc);
     return TDX_OK;
 }
+// a coarse level whose owned rows hold the coarsened seed surface: halo rows, coarser levels, relaxation
+static int pit_finish_level(tdx_context* ctx, const Strip& ls, float* Zc, float* Wc, int nxc, int nyc, int64_t cells_all, tilek::Sched sc, int depth,
+                            int64_t* rounds, int64_t* launches) {
+    const size_t off = size_t(ls.y0) * size_t(nxc);
+    int rc = pit_coarse_start(ctx, ls, Zc + off, Wc + off, nxc, nyc, cells_all, sc, depth + 1, rounds, launches);
+    if (rc != TDX_OK) return rc;
+    rc = strip_exchange<float>(ctx, ls, Zc, TDX_FEL_NODATA);   // (a block without valid cells is a nodata cell of its level, and so is everything beyond the raster)
+    if (rc != TDX_OK) return rc;
+    rc = strip_exchange<float>(ctx, ls, Wc, TDX_FEL_NODATA);
+    if (rc != TDX_OK) return rc;
+    return pit_relax_level<8>(ctx, ls, Zc, Wc, sc, rounds, launches, nullptr);
+}
 
-// One strip (src/flood.cpp:132-482).  Multi-strip: every rank relaxes its strip to the local fixed point
-// with the neighbours' boundary rows frozen in its halo rows, then boundary rows are exchanged and the
-// tiles that see a changed halo cell are re-activated; repeat until no halo cell changed on any rank
-// (the roles of share() + ringTerm() in src/flood.cpp:344-355,457-468).
+// One strip (src/flood.cpp:132-482).
 static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const int16_t* d_mask, int fourway, float dem_nodata, float* d_fel,
                           tdx_stats* stats) {
     TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -246,6 +294,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     uint32_t* list = static_cast<uint32_t*>(ctx->scratch(TDX_S_B, size_t(ntiles) * 4 * tilek::SCHED_LIST_WORDS));
     unsigned long long* counts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_C, size_t(tilek::COUNT_RING) * 16));
     if (!flags || !list || !counts) return TDX_ERR_NOMEM;
+    const tilek::Sched sched{flags, list, counts};
 
     ctx->begin_call(stats);
     strip_mark(ctx, st, "pitremove");
@@ -255,32 +304,32 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     const int sbx = (st.nx + 63) / 64, sxmap = 0;   // (64-column blocks on line boundaries: the XCD-aware order of d8flowdir.hip gains nothing here)
     const dim3 sgrid(unsigned(sbx), (st.y1 - st.y0 + 4 * SEED_ROWS - 1) / (4 * SEED_ROWS));
     const bool no_coarse = getenv("TDX_PIT_NO_COARSE") != nullptr;   // (test hook: read per call)
-    const int nyo = st.y1 - st.y0;   // the coarse-to-fine start works on the OWNED rows: paths that leave the strip are ignored, which only loosens the bound
-    if (!fourway && !no_coarse && size_t(st.nx) * size_t(nyo) >= (size_t(1) << 18)) {
-        // seed surface -> first coarse level -> (coarser levels, relaxed coarse to fine) -> start surface, without a W0 in between
+    const int nyo = st.y1 - st.y0;
+    int64_t cells_all = int64_t(st.nx) * int64_t(nyo);   // every rank takes the same path: the decision is made on the whole raster's size
+    rc = strip_allreduce(ctx, st, &cells_all, 1, TDX_OP_SUM);
+    if (rc != TDX_OK) return rc;
+    if (!fourway && !no_coarse && cells_all >= (int64_t(1) << 18)) {
+        // seed surface -> first coarse level -> (coarser levels, relaxed coarse to fine, each across the strips) -> start surface, without a W0 in between
         const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
-        const size_t nc = size_t(nxc) * size_t(nyc);
+        const Strip ls = pit_level_strip(st, nxc, nyc);
+        const size_t nc = size_t(nxc) * size_t(ls.ny_arr), off = size_t(ls.y0) * size_t(nxc);
         float* Zc = static_cast<float*>(ctx->scratch(TDX_S_D, nc * 4));
         float* Wc = static_cast<float*>(ctx->scratch(TDX_S_E, nc * 4));
         if (!Zc || !Wc) return TDX_ERR_NOMEM;
         {
             TdxSpan sp(ctx, TDX_K_STENCIL);
-            hipLaunchKernelGGL(pit_seed_kernel<1>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc, sbx, sxmap);
+            hipLaunchKernelGGL(pit_seed_kernel<1>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc + off, Wc + off, nxc, nyc, sbx, sxmap);
             if (stats) stats->launches[TDX_K_STENCIL]++;
         }
         {
             TdxSpan sp(ctx, TDX_K_RELAX);
-            rc = pit_coarse_start(ctx, Zc, Wc, nxc, nyc, tilek::Sched{flags, list, counts}, 1, &rounds, &launches);
-            if (rc != TDX_OK) return rc;
-            const tilek::TileGeom gc = tilek::make_geom(nxc, nyc, 0, nyc);
-            const int ntc = gc.tiles_x * gc.tiles_y;
-            hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntc), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntc));
-            rc = tile_relax_run(ctx, PitOp<8>{Zc, Wc}, gc, tilek::Sched{flags, list, counts}, &rounds, &launches);
+            ctx->phase = "coarse levels";
+            rc = pit_finish_level(ctx, ls, Zc, Wc, nxc, nyc, cells_all / (CF * CF), sched, 0, &rounds, &launches);
             if (rc != TDX_OK) return rc;
         }
         {
             TdxSpan sp(ctx, TDX_K_STENCIL);
-            hipLaunchKernelGGL(pit_seed_kernel<2>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc, Wc, nxc, nyc, sbx, sxmap);
+            hipLaunchKernelGGL(pit_seed_kernel<2>, sgrid, dim3(256), 0, s, d_dem, d_mask, d_fel, st.nx, st.ny_arr, st.y0, st.y1, dem_nodata, 1, Zc + off, Wc + off, nxc, nyc, sbx, sxmap);
             if (stats) stats->launches[TDX_K_STENCIL]++;
         }
     } else {
@@ -289,23 +338,13 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
                            static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, 0, sbx, sxmap);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
+    ctx->phase = "fine level";
     rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA);   // start surface halo rows
     if (rc != TDX_OK) return rc;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
-        // round 0: every tile is active
-        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
-        for (;;) {
-            rc = fourway ? tile_relax_run(ctx, PitOp<4>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches)
-                         : tile_relax_run(ctx, PitOp<8>{d_dem, d_fel}, geom, tilek::Sched{flags, list, counts}, &rounds, &launches);
-            if (rc != TDX_OK) return rc;
-            outer++;
-            if (!st.multi()) break;
-            int64_t changed = 0;
-            rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA, flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
-            if (rc != TDX_OK) return rc;
-            if (changed == 0) break;
-        }
+        rc = fourway ? pit_relax_level<4>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer) : pit_relax_level<8>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer);
+        if (rc != TDX_OK) return rc;
         if (stats) stats->launches[TDX_K_RELAX] += launches;
     }
     TDX_HIP_CHECK(ctx, hipGetLastError());

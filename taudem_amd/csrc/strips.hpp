@@ -111,24 +111,30 @@ static inline int strip_allreduce_device(tdx_context* ctx, const Strip& st, unsi
     hipStream_t s = ctx->stream;
     if (st.multi()) { ctx->comm_allreduces++; ctx->comm_allreduces_total++; }
     if (st.multi() && st.comm->allreduce_dev) {
+        ctx->seg_end(1);   // (segment trace: the collective and the read-back of its result lie between two segments)
         if (st.comm->allreduce_dev(st.comm->user, reinterpret_cast<int64_t*>(d_v), count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce_dev failed");
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
         if (int rcw = strip_wait(ctx, st, "a device all-reduce (termination vote)")) return rcw;
         for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[TDX_MAIL_STRIP_REDUCE + i]);
+        ctx->seg_begin();
         return TDX_OK;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, size_t(count) * 8, hipMemcpyDeviceToHost, s));
     if (int rcw = strip_wait(ctx, st, "the counters of a vote")) return rcw;
     for (int i = 0; i < count; i++) host_out[i] = int64_t(ctx->h_mail[TDX_MAIL_STRIP_REDUCE + i]);
     if (!st.multi()) return TDX_OK;
+    ctx->seg_end(1);
     if (st.comm->allreduce(st.comm->user, host_out, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
+    ctx->seg_begin();
     return TDX_OK;
 }
 
 static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v, int count, int op) {
     if (!st.multi()) return TDX_OK;
     ctx->comm_allreduces++; ctx->comm_allreduces_total++;
+    ctx->seg_end(1);
     if (st.comm->allreduce(st.comm->user, v, count, op) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm allreduce failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
+    ctx->seg_begin();
     return TDX_OK;
 }
 
@@ -153,7 +159,10 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, arr + size_t(st.y1 - 1) * nx, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
     ctx->comm_exchanges++; ctx->comm_exchanges_total++;
-    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
+    ctx->seg_end(0);
+    const int rce = c->exchange(c->user, bytes);
+    if (rce == 0) ctx->seg_begin();
+    if (rce != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (!tile_flags && !nchanged) {
         if (st.up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y0 - 1) * nx, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
         if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(arr + size_t(st.y1) * nx, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
@@ -196,7 +205,10 @@ static inline int strip_exchange_buffers(tdx_context* ctx, const Strip& st, cons
     if (st.down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(c->send_down, down_src, bytes, hipMemcpyDeviceToDevice, s));
     if (int rcs = strip_pre_exchange_sync(ctx, st)) return rcs;
     ctx->comm_exchanges++; ctx->comm_exchanges_total++;
-    if (c->exchange(c->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
+    ctx->seg_end(0);
+    const int rce = c->exchange(c->user, bytes);
+    if (rce == 0) ctx->seg_begin();
+    if (rce != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm exchange failed" + (g_tdx_thread_error.empty() ? std::string() : ": " + g_tdx_thread_error));
     if (st.up && up_dst != c->recv_up) TDX_HIP_CHECK(ctx, hipMemcpyAsync(up_dst, c->recv_up, bytes, hipMemcpyDeviceToDevice, s));
     if (st.down && down_dst != c->recv_down) TDX_HIP_CHECK(ctx, hipMemcpyAsync(down_dst, c->recv_down, bytes, hipMemcpyDeviceToDevice, s));
     return TDX_OK;

@@ -22,6 +22,7 @@
 // HBM traffic per activation of a tile: one tile image of v (+ the per-cell constant) in, changed
 // cells out.  Critical path: (longest dependency path measured in tiles) rounds x one launch.
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -53,8 +54,11 @@ struct TileGeom {
     // Where a round reports its size to the host (set per batch by RoundRunner::enqueue; null = nobody listens): the first workgroup of the round
     // launched with the counter `count` stores count[0] to cnt_host[count - cnt_dev] - pinned host memory - so that the host needs no copy
     // kernel between two batches of rounds (61 of them per 16384^2 pipeline step, ~6 us each: profiles/r04m_timeline_*).
+    // The report carries the batch's sequence number (cnt_tag, upper 32 bits; the count is below 2^32): a batch of empty rounds that is still in flight
+    // when its runner ends writes into the same host slots as the next runner's first batch, and the host must not take those late zeros for its own.
     unsigned long long* cnt_host;
     const unsigned long long* cnt_dev;
+    unsigned long long cnt_tag;
     int act_filter;         // 1: a moved rim cell raises a neighbour's flag only if it can improve a cell of it (relax_tile_reg; TDX_ACT_FILTER_OFF=1: every moved rim cell does)
 };
 
@@ -67,7 +71,7 @@ static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
     g.max_sweeps = ms;
     static const int cm = getenv("TDX_SOLO_CHAIN") ? atoi(getenv("TDX_SOLO_CHAIN")) : 256;
     g.chain_max = cm;
-    g.cnt_host = nullptr; g.cnt_dev = nullptr;
+    g.cnt_host = nullptr; g.cnt_dev = nullptr; g.cnt_tag = 0ull;
     static const int af = getenv("TDX_ACT_FILTER_OFF") ? 0 : 1;
     g.act_filter = af;
     return g;
@@ -830,7 +834,7 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
     const int chain_max = g.chain_max;
     const unsigned nact = unsigned(count[0]);
     if (g.cnt_host != nullptr && bid == 0u && threadIdx.x == 0)   // this round's size, for the host (final: the previous round's launch has ended)
-        __hip_atomic_store(g.cnt_host + (count - g.cnt_dev), (unsigned long long)count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(g.cnt_host + (count - g.cnt_dev), g.cnt_tag | (unsigned long long)count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t entry0 = list[bid];                 // for a small round (below); fetched together with the count: nblocks <= number of tiles
     unsigned long long* cursor = count + COUNT_RING;   // per-round work cursor: blocks pull tiles, so the load balances itself
     unsigned pull = nact / (2u * nblocks);
@@ -1176,6 +1180,7 @@ struct RoundRunner {
     int r = 0, parity = 0, batch = 4;
     int r_enq = 0, parity_enq = 0, n_enq = 0, n_col = 0, fl_batch[2] = {0, 0};
     bool polled[2] = {false, false};     // the slot's batch reports through the host slot itself (no copy, no event)
+    uint64_t fl_tag[2] = {0, 0};         // ... tagged with the batch's sequence number (TileGeom::cnt_tag)
     int ev_base = 0;                     // ctx->ev_batch[ev_base + slot]
     int batch_max = 64;                  // drive() / the pair lower it: with two batches in flight a whole batch of empty rounds follows the last one
     bool done = false;
@@ -1231,10 +1236,16 @@ struct RoundRunner {
         // the rounds of this batch report their sizes straight into the host slot (TDX_RELAX_COUNT_COPY=1: a copy after the batch instead - A/B hook)
         static const bool count_copy = getenv("TDX_RELAX_COUNT_COPY") != nullptr;
         if (!count_copy) {
+            // Every batch of the context has its own sequence number: the last batch of an EARLIER runner (empty rounds, left in flight when that runner
+            // saw its first empty round) may still be storing zeros into this slot; they carry an older number and are not taken for this batch's reports.
+            uint32_t seq = ++ctx->run_seq;
+            if (seq == 0xffffffffu) seq = ++ctx->run_seq;   // (never the pattern of an unwritten slot)
+            fl_tag[slot] = uint64_t(seq) << 32;
             for (int b = 0; b < batch; b++) hs[b] = ~0ull;   // (the slot's previous batch has been collected)
             g.cnt_host = reinterpret_cast<unsigned long long*>(hs);
             g.cnt_dev = sc.counts + r;
-        } else { g.cnt_host = nullptr; g.cnt_dev = nullptr; }
+            g.cnt_tag = fl_tag[slot];
+        } else { g.cnt_host = nullptr; g.cnt_dev = nullptr; g.cnt_tag = 0ull; }
         for (int b = 0; b < batch; b++) {
             const int p = (parity + b) & 1;
             const int sp = timed ? ctx->span_begin(TDX_K_TILEK) : -1;   // this kernel alone: what bench.py's roofline is computed from
@@ -1279,26 +1290,31 @@ struct RoundRunner {
         // the batch's rounds wrote their sizes themselves (round_driver): once its LAST round has reported - it has started, so every earlier round has
         // ended - the batch's counts are complete.  No event, no barrier packet in the stream; bounded like every other wait of the library.
         const volatile uint64_t* last = h + slot * TDX_MAIL_RUN_SLOT + (fl_batch[slot] - 1);
+        const uint64_t tag = fl_tag[slot];
+        auto mine = [&]() { return (*last & 0xffffffff00000000ull) == tag; };
+        static const double limit_s = getenv("TDX_COMM_TIMEOUT") ? atof(getenv("TDX_COMM_TIMEOUT")) : 600.0;   // the library's bound for every wait
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0; *last == ~0ull; spins++) {
+        for (unsigned spins = 0; !mine(); spins++) {
             if ((spins & 1023u) == 1023u) {
-                if (hipStreamQuery(s) == hipSuccess && *last == ~0ull)
+                if (hipStreamQuery(s) == hipSuccess && !mine())
                     return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: a round ended without reporting its size");
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0)
-                    return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no report from a batch of rounds after 600 s");
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+                    return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no report from a batch of rounds after " + std::to_string(int(limit_s)) + " s");
             }
             __builtin_ia32_pause();
         }
+        std::atomic_thread_fence(std::memory_order_acquire);   // the earlier rounds' reports (read by collect()) were stored before the last one's
         return TDX_OK;
     }
     void collect() {   // the oldest batch in flight; its counts must have arrived (wait_oldest() or a synchronised stream)
         const int slot = n_col & 1, nb = fl_batch[slot];
-        const uint64_t* hs = h + slot * TDX_MAIL_RUN_SLOT;
+        const volatile uint64_t* hs = h + slot * TDX_MAIL_RUN_SLOT;
         for (int b = 0; b < nb; b++) {
-            if (hs[b] == 0) { done = true; break; }
-            last_count = hs[b];
+            const uint64_t cnt = polled[slot] ? (hs[b] & 0xffffffffull) : hs[b];   // (a polled slot carries the batch's sequence number above the count)
+            if (cnt == 0) { done = true; break; }
+            last_count = cnt;
             rounds++;
-            if (print_counts) fprintf(stderr, " %llu", (unsigned long long)hs[b]);   // TDX_DEBUG_ROUNDS: active tiles per round
+            if (print_counts) fprintf(stderr, " %llu", (unsigned long long)cnt);   // TDX_DEBUG_ROUNDS: active tiles per round
         }
         r += nb;
         parity = (parity + nb) & 1;

@@ -205,8 +205,14 @@ class StripGroup:
         self.comms = [_GroupComm(C.c_void_p(self._lib.tdx_group_comm(g, r)), self.transport) for r in range(self.size)]
 
     def run(self, fn):
+        """fn(rank, context, comm) on one thread per rank; returns the list of results.  A rank that raises ABORTS THE GROUP (tdx_group_abort: the other
+        ranks' pending and future collectives fail at once instead of waiting for TDX_COMM_TIMEOUT) - whatever it raised, communication error or
+        not - and an aborted group is dead: its barrier and its RCCL communicators are gone for good.  run() on a dead group raises at once; build
+        a new StripGroup to go on."""
         import threading
 
+        if getattr(self, "_dead", False):
+            raise RuntimeError("this StripGroup was aborted by a failed rank in an earlier run(): the rank group is one-shot after a failure - create a new StripGroup")
         out, err = [None] * self.size, []
 
         def main(r):
@@ -224,7 +230,8 @@ class StripGroup:
         for t in th:
             t.join()
         if err:
-            raise RuntimeError("StripGroup rank(s) failed:\n" + "\n".join(f"[rank {r}] {m}" for r, m in sorted(err)))
+            self._dead = True
+            raise RuntimeError("StripGroup rank(s) failed (the group is now dead - create a new one to continue):\n" + "\n".join(f"[rank {r}] {m}" for r, m in sorted(err)))
         return out
 
     def close(self):
@@ -239,6 +246,39 @@ class StripGroup:
 
     def __exit__(self, *a):
         self.close()
+
+
+def project_critical_path(logs, exchange_us: float = 10.0, vote_us: float = 30.0, use: str = "wall"):
+    """The critical path of an N-GPU strip run from the ranks' SEGMENT TRACES (Context.segments(), option "segment_trace" = 2: ranks that share a
+    GPU take turns on it, so that every segment is timed as on a GPU of its own).  A strip run is, on every rank, the same sequence of
+    segments of rank-local work separated by collectives (the outer loop of src/aread8.cpp:282-303 with share() / MPI_Allreduce,
+    src/linearpart.h:313-384): a collective completes when the slowest rank arrives, so
+
+        projected time = sum over segments of (max over ranks of the segment's time) + exchanges x exchange_us + all-reduces x vote_us.
+
+    logs[r] = [(stage, phase, kind, device_ms, wall_ms), ...] of rank r.  Returns {"total_ms", "per_stage": {stage: {"ms", "work_ms", "latency_ms",
+    "segments", "exchanges", "allreduces", "sum_over_ranks_ms", "phases": {phase: ms}}}, "assumed": {...}}.  A PROJECTION, not a measurement."""
+    n = len(logs[0])
+    for r, lg in enumerate(logs):
+        if len(lg) != n or any(a[:3] != b[:3] for a, b in zip(lg, logs[0])):
+            raise ValueError(f"rank {r} went through a different sequence of collectives than rank 0: the protocol is not rank-symmetric")
+    col = 4 if use == "wall" else 3
+    per, total = {}, 0.0
+    for i in range(n):
+        stage, phase, kind = logs[0][i][:3]
+        work = max(lg[i][col] for lg in logs)
+        lat = (exchange_us if kind == 0 else vote_us if kind == 1 else 0.0) * 1e-3
+        st = per.setdefault(stage, {"ms": 0.0, "work_ms": 0.0, "latency_ms": 0.0, "segments": 0, "exchanges": 0, "allreduces": 0, "sum_over_ranks_ms": 0.0,
+                                    "slowest_rank_histogram": [0] * len(logs), "phases": {}})
+        st["ms"] += work + lat; st["work_ms"] += work; st["latency_ms"] += lat; st["segments"] += 1
+        st["exchanges"] += kind == 0; st["allreduces"] += kind == 1
+        st["sum_over_ranks_ms"] += sum(lg[i][col] for lg in logs)
+        st["slowest_rank_histogram"][max(range(len(logs)), key=lambda r: logs[r][i][col])] += 1
+        st["phases"][phase or "-"] = st["phases"].get(phase or "-", 0.0) + work + lat
+        total += work + lat
+    return {"total_ms": total, "per_stage": per,
+            "assumed": {"exchange_us": exchange_us, "vote_us": vote_us, "segment_time": use,
+                        "note": "projection from one-GPU segment traces (one rank on the device at a time), not an N-GPU measurement"}}
 
 
 def _tptr(t, dtype, shape, name):

@@ -313,3 +313,142 @@ def test_aread8_walk_beyond_count_limit(ctx, oracle, monkeypatch):
     exercised here through its test hook."""
     monkeypatch.setenv("TDX_AD8_COUNT_LIMIT", "1000")
     assert _comb_check(ctx, 4200, None) > 2 ** 24
+
+
+def test_aread8_tiled_path_counts_the_participating_cells(ctx, oracle, monkeypatch):
+    """A raster of more cells than the 32-bit exact counts hold (65536 x 65536 is exactly 2^32 cells) keeps the tile contraction as long as its PARTICIPATING
+    cells stay below 2^32 (4 294 700 699 at BASELINE.json configs[3]): the limit hook is put between the two numbers of a small raster with a nodata hole."""
+    dem = oracle.synth_dem((300, 400), 21)
+    dem[40:220, 60:330] = -9999.0
+    fel = oracle.pitremove(dem, -9999.0)
+    p, _, _ = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    npart = int(((p >= 0) & (p <= 8)).sum())
+    assert npart < p.size - 1000
+    a_o = oracle.aread8(p, -32768, contcheck=False)
+    monkeypatch.setenv("TDX_AD8_COUNT_LIMIT", str(npart + 10))          # cells > limit >= participating cells: tile contraction
+    a, st = ctx.aread8(p, -32768, contcheck=False, stats=True)
+    assert bits_equal(a, a_o), describe_diff(a, a_o, "ad8 (tile contraction below the participating-cell limit)")
+    assert st["launches_accum"] <= 3, "the tile dependency sweep ran instead of the tile contraction"
+    monkeypatch.setenv("TDX_AD8_COUNT_LIMIT", str(npart - 10))          # participating cells above the limit: the dependency sweep
+    a, st = ctx.aread8(p, -32768, contcheck=False, stats=True)
+    assert bits_equal(a, a_o), describe_diff(a, a_o, "ad8 (dependency sweep above the limit)")
+    assert st["launches_accum"] > 3
+
+
+def _canal(n):
+    """one flat canal of n cells inside walls, draining at its west end: a flat whose deepest incfall level is n"""
+    dem = np.full((5, n + 2), 100.0, np.float32)
+    dem[2, 1:n + 1] = 10.0
+    dem[2, 0] = 5.0
+    return dem
+
+
+@pytest.mark.parametrize("env", [{"TDX_LEVELS_INT32": "1"}, {"TDX_LEVELS_LIMIT": "40"}])
+def test_int32_level_fields_give_the_reference_bits(g, ctx, monkeypatch, env):
+    """The int32 level fields - the fallback for flats deeper than the reference's short counters hold - on inputs the reference can do: forced from the
+    start (TDX_LEVELS_INT32) and entered through the fallback itself (TDX_LEVELS_LIMIT=40: the int16 pass gives up at level 40 and the call starts over),
+    both must reproduce the REAL tools' p / sd8 / ang / slp."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p, sd8, st = ctx.d8flowdir(np.ascontiguousarray(g["fel"]), -3.0e38, g["dxc"], g["dyc"], stats=True)
+    assert bits_equal(sd8, g["sd8"]), describe_diff(sd8, g["sd8"], "sd8")
+    assert bits_equal(p, g["p"]), describe_diff(p, g["p"], "p")
+    assert f"All slopes evaluated. {st['flats_initial']} flats to resolve." in str(g["d8_stderr"])
+    ang, slp = ctx.dinfflowdir(np.ascontiguousarray(g["fel"]), -3.0e38, g["dxc"], g["dyc"])
+    assert bits_equal(slp, g["slp"]), describe_diff(slp, g["slp"], "slp")
+    assert bits_equal(ang, g["ang"]), describe_diff(ang, g["ang"], "ang")
+
+
+@pytest.mark.slow
+def test_flat_deeper_than_int16(ctx, oracle, monkeypatch):
+    """A flat of 70 000 levels.  The reference's `short` elev2 / dn partitions wrap at 32 767 (src/d8.cpp:483-486: the real algorithm leaves 37 233 of
+    the canal's cells without a direction - the restatement with 16-bit counters shows it), so there is nothing to be bit-equal WITH; the product
+    starts the call over on int32 level fields and must give what the algorithm means - the restatement built with 32-bit counters
+    (oracle/libtaudem_oracle_l32.so, ORC_LVL_T): every canal cell drains west.  A superset of the reference, not a parity claim.  One strip and two."""
+    import torch
+
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+
+    n = 70000
+    dem = _canal(n)
+    fel = oracle.pitremove(dem, -9999.0)
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    p_o, sd8_o, st_o = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0, levels32=True)
+    ang_o, slp_o, _ = oracle.dinfflowdir(fel, -3.0e38, 30.0, 30.0, levels32=True)
+    monkeypatch.delenv("ORC_FLATS")
+    assert int((p_o[2, 1:n + 1] == 5).sum()) == n
+    p, sd8, st = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    assert st["levels_fall_max"] >= n - 1 and st["flats_left"] == 0
+    assert bits_equal(p, p_o), describe_diff(p, p_o, "p (70 000 levels)")
+    assert bits_equal(sd8, sd8_o), describe_diff(sd8, sd8_o, "sd8")
+    ang, slp = ctx.dinfflowdir(fel, -3.0e38, 30.0, 30.0)
+    assert bits_equal(ang, ang_o), describe_diff(ang, ang_o, "ang (70 000 levels)")
+    assert bits_equal(slp, slp_o), describe_diff(slp, slp_o, "slp")
+    # two strips: the canal's row belongs to the second one, its walls to both - every rank must take the same turn to the int32 fields
+    ny, nx = fel.shape
+    parts = partition_rows(ny, 2)
+    with StripGroup(2, nx, [0, 0]) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            pipe = StripPipeline(c, comm, nx, y1 - y0)
+            f = pipe.empty(torch.float32)
+            f[1:y1 - y0 + 1] = torch.from_numpy(fel[y0:y1]).cuda()
+            pp, ss, _ = pipe.d8flowdir(f, -3.0e38, 30.0, 30.0)
+            return pp[1:y1 - y0 + 1].cpu().numpy(), ss[1:y1 - y0 + 1].cpu().numpy()
+        res = grp.run(rank_main)
+    p2 = np.concatenate([r[0] for r in res], axis=0)
+    s2 = np.concatenate([r[1] for r in res], axis=0)
+    assert bits_equal(p2, p_o), describe_diff(p2, p_o, "p in two strips")
+    assert bits_equal(s2, sd8_o), describe_diff(s2, sd8_o, "sd8 in two strips")
+
+
+@pytest.mark.slow
+def test_many_big_cells_in_one_three_and_eight_strips(ctx, oracle, monkeypatch):
+    """The exact k-ordered re-evaluation of the cells above the float32-exact range (src/aread8.cpp:231-256) as the eight strips of BASELINE.json configs[3]
+    see it - ~10^5 such cells per strip, main stems that cross the strip boundaries again and again, outer rounds that only re-visit what the
+    neighbouring strips still block (ad8_big_compact_kernel) - at a size the restatement does in seconds: 2048^2 with the threshold lowered to 6
+    (TDX_AD8_BIG_THRESHOLD; below 2^24 the float32 adds are exact whatever their order, so the restatement's raster is the answer).  >= 10^5 cells take
+    the path; one strip, three and eight must give the same bits."""
+    import os
+
+    import torch
+
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+
+    n = 2048
+    dem = oracle.synth_dem((n, n), 77)
+    fel = oracle.pitremove(dem, -9999.0)
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    oracle.set_threads(os.cpu_count() or 1)
+    try:
+        p_o, _, _ = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    finally:
+        oracle.set_threads(1)
+        monkeypatch.delenv("ORC_FLATS")
+    a_o = oracle.aread8(p_o, -32768, contcheck=False)
+    monkeypatch.setenv("TDX_AD8_BIG_THRESHOLD", "6")
+    assert int((a_o > 6).sum()) >= 100000
+    a, st = ctx.aread8(p_o, -32768, contcheck=False, stats=True)
+    assert st["cells_evaluated"] >= 100000, "the big-cell path was not taken"
+    assert bits_equal(a, a_o), describe_diff(a, a_o, "ad8, one strip")
+    a_c = oracle.aread8(p_o, -32768, contcheck=True)
+    a = ctx.aread8(p_o, -32768, contcheck=True)
+    assert bits_equal(a, a_c), describe_diff(a, a_c, "ad8 with contamination, one strip")
+    for world in (3, 8):
+        parts = partition_rows(n, world)
+        with StripGroup(world, n, [0] * world) as grp:
+            def rank_main(r, c, comm):
+                y0, y1 = parts[r]
+                pipe = StripPipeline(c, comm, n, y1 - y0)
+                pp = pipe.empty(torch.int16)
+                pp[1:y1 - y0 + 1] = torch.from_numpy(p_o[y0:y1]).cuda()
+                out = []
+                for cc in (False, True):
+                    aa, s = pipe.aread8(pp, -32768, contcheck=cc)
+                    out.append(aa[1:y1 - y0 + 1].cpu().numpy())
+                return out + [s["rounds"]]
+            res = grp.run(rank_main)
+        for i, ref in ((0, a_o), (1, a_c)):
+            got = np.concatenate([r[i] for r in res], axis=0)
+            assert bits_equal(got, ref), describe_diff(got, ref, f"ad8 in {world} strips (contcheck={bool(i)})")
+        assert res[0][2] > 2, "no outer rounds: the strips never exchanged a big cell"
