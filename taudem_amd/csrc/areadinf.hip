@@ -585,21 +585,21 @@ __global__ __launch_bounds__(256) void verify_kernel(Eval ev, const float* __res
     }
 }
 
-// activation flags between the two tile geometries (a 64 x 64 tile = 2 x 2 tiles of 32 x 32)
+// activation flags between the two tile geometries (a 64 x 64 tile = 2 x 2 tiles of 32 x 32, sh = 1, or 4 x 4 tiles of 16 x 16, sh = 2)
 static __global__ __launch_bounds__(256) void flags_down_kernel(const uint32_t* __restrict__ f64, int tiles_x64, uint32_t* __restrict__ f32, int tiles_x32,
-                                                                int tiles_y32) {
+                                                                int tiles_y32, int sh) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles_x32 * tiles_y32) return;
     const int tx = t % tiles_x32, ty = t / tiles_x32;
-    f32[t] = f64[(ty >> 1) * tiles_x64 + (tx >> 1)] ? tilek::FLAG_FULL : 0u;
+    f32[t] = f64[(ty >> sh) * tiles_x64 + (tx >> sh)] ? tilek::FLAG_FULL : 0u;
 }
-static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restrict__ f32, int tiles_x32, int tiles_y32, uint32_t* __restrict__ f64, int tiles_x64) {
+static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restrict__ f32, int tiles_x32, int tiles_y32, uint32_t* __restrict__ f64, int tiles_x64, int sh) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles_x32 * tiles_y32) return;
     if (f32[t]) {
         f32[t] = 0u;
         const int tx = t % tiles_x32, ty = t / tiles_x32;
-        f64[(ty >> 1) * tiles_x64 + (tx >> 1)] = tilek::FLAG_HALO;   // walks only: the bulk sweeps have run
+        f64[(ty >> sh) * tiles_x64 + (tx >> sh)] = tilek::FLAG_HALO;   // walks only: the bulk sweeps have run
     }
 }
 }  // namespace dsweep
@@ -614,6 +614,15 @@ static __global__ __launch_bounds__(256) void flags_up_kernel(uint32_t* __restri
 #define DSWEEP_NS dsweep32
 #define DSWEEP_TS 32
 #define DSWEEP_NT 256
+#include "dinf_sweep_tile.inc"
+#undef DSWEEP_NS
+#undef DSWEEP_TS
+#undef DSWEEP_NT
+// 16 x 16 tiles, ONE wave per tile (no workgroup barrier in the hop loop, 10 KB of LDS: fifteen tiles per CU) - the variant VERDICT r04 asked to be
+// measured for the bulk rounds (TDX_DINF_BULK_TILE=16; docs/experiments_r05.md has what it did)
+#define DSWEEP_NS dsweep16
+#define DSWEEP_TS 16
+#define DSWEEP_NT 64
 #include "dinf_sweep_tile.inc"
 #undef DSWEEP_NS
 #undef DSWEEP_TS
@@ -698,8 +707,10 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         // rounds, 64 x 64 tiles for the tail (dinf_sweep_tile.inc)
         tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
         geom.max_sweeps = dsweep64::BULK_SWEEPS;
+        static const int bulk_ts = (getenv("TDX_DINF_BULK_TILE") && atoi(getenv("TDX_DINF_BULK_TILE")) == 16) ? 16 : 32;   // (A/B hook: edge of the bulk rounds' tiles)
+        const int bulk_sh = bulk_ts == 16 ? 2 : 1;
         tilek::TileGeom geom32 = geom;
-        geom32.tiles_x = (inx + 31) / 32; geom32.tiles_y = (iny + 31) / 32;
+        geom32.tiles_x = (inx + bulk_ts - 1) / bulk_ts; geom32.tiles_y = (iny + bulk_ts - 1) / bulk_ts;
         // lockstep sweeps of a fresh tile before the walks take over (dinf_sweep_tile.inc)
         static const int bulk_sweeps = getenv("TDX_DINF_BULK_SWEEPS") ? std::max(0, atoi(getenv("TDX_DINF_BULK_SWEEPS"))) : dsweep32::BULK_SWEEPS;
         geom32.max_sweeps = bulk_sweeps;
@@ -733,7 +744,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             hipLaunchKernelGGL((NS::sweep_kernel<dsweep::DecayEval, false, true>), dim3(grid), dim3(NS::NT), 0, ls, dsweep::DecayEval{alg.dm_nodata}, gg, list, \
                                count, fcur, fnext, lnext, pull_max, d_P, nullptr, alg.DM, info32, d_rows, d_out, out_nodata, contcheck, dbg);                   \
     }
-            if (small) { TDX_DSWEEP_LAUNCH(dsweep32) } else { TDX_DSWEEP_LAUNCH(dsweep64) }
+            if (small && bulk_ts == 16) { TDX_DSWEEP_LAUNCH(dsweep16) } else if (small) { TDX_DSWEEP_LAUNCH(dsweep32) } else { TDX_DSWEEP_LAUNCH(dsweep64) }
 #undef TDX_DSWEEP_LAUNCH
         };
         int64_t launches = 0;
@@ -741,11 +752,11 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         // tiles are still active (their flags of the next round are then in run.flags_of(run.parity))
         auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
             RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
-            if (small) { run.grid_full = unsigned(std::min(run.ntiles, 16 * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
+            if (small) { run.grid_full = unsigned(std::min(run.ntiles, (bulk_ts == 16 ? 48 : 16) * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
             run.custom_launch = [&](const tilek::TileGeom& rg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext,
                                     uint32_t* lnext, unsigned pull_max) { launch(small, rg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
             run.print_counts = dbg_rounds;
-            if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%d tiles of %d):", run.ntiles, small ? 32 : 64);
+            if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%d tiles of %d):", run.ntiles, small ? bulk_ts : 64);
             if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
             int last_printed = -1;
             int rcl = run.start();
@@ -779,14 +790,14 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
             if (bulk) {
                 // bulk phase on 32 x 32 tiles: every 32-tile under an active 64-tile starts active
                 hipLaunchKernelGGL(dsweep::flags_down_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, flags, geom.tiles_x, flags32, geom32.tiles_x,
-                                   geom32.tiles_y);
+                                   geom32.tiles_y, bulk_sh);
                 TDX_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, ntiles * 4, s));
                 rc = run_rounds(true, geom32, sched32, bulk_until, &left, &par);
                 if (rc != TDX_OK) return rc;
                 if (left) {   // what is still active goes on in 64 x 64 tiles
                     uint32_t* f32next = par ? sched32.list + 2 * ntiles32 : sched32.flags;
                     hipLaunchKernelGGL(dsweep::flags_up_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, f32next, geom32.tiles_x, geom32.tiles_y, flags,
-                                       geom.tiles_x);
+                                       geom.tiles_x, bulk_sh);
                 }
                 bulk = false;   // (strip re-activations are few tiles: 64 x 64)
             } else left = true;

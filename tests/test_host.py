@@ -106,3 +106,30 @@ def test_new_tools_report_missing_files(tmp_path):
     assert tools.threshold(nope, nope) == _lib.TDX_ERR_FILE
     assert tools.d8flowpathextremeup(nope, nope, nope) == _lib.TDX_ERR_FILE
     assert tools.gridnet(nope, nope, nope, nope, useOutlets=1) == _lib.TDX_ERR_FILE
+
+
+def test_critical_path_projection_from_segment_traces():
+    """taudem_amd.distributed.project_critical_path: sum over the segments between collectives of the slowest rank + collectives x assumed latencies
+    (the role of the outer loops with share() / MPI_Allreduce, src/aread8.cpp:282-303, src/linearpart.h:313-384); a rank that went through another
+    sequence of collectives is an error (the protocol is rank-symmetric)."""
+    import pytest
+
+    from taudem_amd.distributed import project_critical_path
+
+    # (stage, phase, kind, device_ms, wall_ms): kind 0 = ended by an exchange, 1 = by an all-reduce, 2 = by the end of the call
+    r0 = [("pitremove", "", 0, 1.0, 1.5), ("pitremove", "fine level", 1, 4.0, 4.0), ("pitremove", "fine level", 2, 0.5, 0.5), ("aread8", "forest", 0, 2.0, 2.0), ("aread8", "", 2, 0.1, 0.1)]
+    r1 = [("pitremove", "", 0, 2.0, 2.0), ("pitremove", "fine level", 1, 1.0, 1.0), ("pitremove", "fine level", 2, 0.7, 0.7), ("aread8", "forest", 0, 3.0, 3.5), ("aread8", "", 2, 0.1, 0.2)]
+    p = project_critical_path([r0, r1], exchange_us=10.0, vote_us=30.0)
+    pit, ad8 = p["per_stage"]["pitremove"], p["per_stage"]["aread8"]
+    assert pit["work_ms"] == pytest.approx(2.0 + 4.0 + 0.7) and pit["latency_ms"] == pytest.approx(0.010 + 0.030)
+    assert (pit["segments"], pit["exchanges"], pit["allreduces"]) == (3, 1, 1)
+    assert pit["sum_over_ranks_ms"] == pytest.approx(1.5 + 4.0 + 0.5 + 2.0 + 1.0 + 0.7)
+    assert pit["phases"]["fine level"] == pytest.approx(4.0 + 0.030 + 0.7)
+    assert ad8["ms"] == pytest.approx(3.5 + 0.010 + 0.2)
+    assert p["total_ms"] == pytest.approx(pit["ms"] + ad8["ms"])
+    assert project_critical_path([r0, r1], use="device")["per_stage"]["aread8"]["work_ms"] == pytest.approx(3.0 + 0.1)
+    with pytest.raises(ValueError):
+        project_critical_path([r0, r1[:-1]])
+    bad = list(r1); bad[1] = ("pitremove", "fine level", 0, 1.0, 1.0)      # an exchange where rank 0 voted
+    with pytest.raises(ValueError):
+        project_critical_path([r0, bad])
