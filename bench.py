@@ -52,7 +52,7 @@ FETCH_FACTOR = {"LevelOp": 1.5, "PitOp": 2.0, "ad8_tile": 2.0}
 
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries of this same command: the newest
-    profiles/rNN?_pmc_{fetch,write}_summary.json pair (scripts/gpu_r04_profile.sh + scripts/pmc_summary.py; round 1's pair has no
+    profiles/rNN?_pmc_{fetch,write}_summary.json pair (scripts/gpu_profile.sh + scripts/pmc_summary.py; round 1's pair has no
     prefix).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is corrected with the factor calibrated for the kernel's access width
     (FETCH_FACTOR above; MI355X_MICROARCH.md's factor 2 holds for 128-B requests only).  Returns (bytes, note) or (None, reason)."""
     import glob

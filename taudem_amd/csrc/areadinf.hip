@@ -707,7 +707,10 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         // rounds, 64 x 64 tiles for the tail (dinf_sweep_tile.inc)
         tilek::TileGeom geom = tilek::make_geom(inx, iny, st.y0, st.y1);
         geom.max_sweeps = dsweep64::BULK_SWEEPS;
-        static const int bulk_ts = (getenv("TDX_DINF_BULK_TILE") && atoi(getenv("TDX_DINF_BULK_TILE")) == 16) ? 16 : 32;   // (A/B hook: edge of the bulk rounds' tiles)
+        // edge of the bulk rounds' tiles: 16 x 16 one-wave tiles gain 5 % at 32768^2 and nothing at 16384^2 (docs/experiments_r05.md), so they take the large
+        // rasters (>= 2^29 cells per strip) of AreaDinf; DinfDecayAccum stays on 32 x 32 (its decay rows in LDS); TDX_DINF_BULK_TILE=16|32 decides otherwise
+        static const int bulk_env = getenv("TDX_DINF_BULK_TILE") ? atoi(getenv("TDX_DINF_BULK_TILE")) : 0;
+        const int bulk_ts = bulk_env == 16 ? 16 : (bulk_env == 32 ? 32 : ((std::is_same<Alg, AreaAlg>::value && n >= (size_t(1) << 29)) ? 16 : 32));
         const int bulk_sh = bulk_ts == 16 ? 2 : 1;
         tilek::TileGeom geom32 = geom;
         geom32.tiles_x = (inx + bulk_ts - 1) / bulk_ts; geom32.tiles_y = (iny + bulk_ts - 1) / bulk_ts;
@@ -750,8 +753,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         int64_t launches = 0;
         // runs one geometry until no tile is active, or (stop_at > 0) until a round has at most stop_at active tiles; returns whether
         // tiles are still active (their flags of the next round are then in run.flags_of(run.parity))
-        auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
+        // ... or (max_rounds > 0) until that many rounds have run: a multi-strip tail exchanges its boundary rows every few rounds instead of running
+        // every strip to its local fixed point first
+        auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out,
+                              int max_rounds = 0) -> int {
             RoundRunner<flatk::LevelOp> run(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
+            if (max_rounds > 0) { run.batch = max_rounds; run.batch_max = max_rounds; }
             if (small) { run.grid_full = unsigned(std::min(run.ntiles, (bulk_ts == 16 ? 48 : 16) * ctx->num_cus)); run.grid_small = unsigned(std::min(run.ntiles, 4 * ctx->num_cus)); }
             run.custom_launch = [&](const tilek::TileGeom& rg, unsigned grid, hipStream_t ls, const uint32_t* list, unsigned long long* count, uint32_t* fcur, uint32_t* fnext,
                                     uint32_t* lnext, unsigned pull_max) { launch(small, rg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
@@ -777,6 +784,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                     last_printed = int(run.rounds) - 1;
                 }
                 if (!run.done && stop_at > 0 && run.last_count <= stop_at) { *active_left = true; *parity_out = run.parity; break; }
+                if (!run.done && max_rounds > 0 && run.rounds >= max_rounds) { *active_left = true; *parity_out = run.parity; break; }
             }
             rounds += run.rounds;
             launches += run.launches;
@@ -802,14 +810,21 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 bulk = false;   // (strip re-activations are few tiles: 64 x 64)
             } else left = true;
             if (left) {
-                rc = run_rounds(false, geom, sched, 0, &left, &par);
+                // Multi-strip tail: at most `eager` rounds between two exchanges.  A strip that runs to its local fixed point first makes every flow path
+                // that crosses a strip boundary wait for the longest chain ANYWHERE in the strip it enters - at BASELINE.json configs[4] 47 crossings x
+                // ~10 ms (profiles/r05b_projection_decay.txt); with frequent exchanges the paths advance side by side, as on one GPU.
+                static const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
+                const int eager = st.multi() ? eager_env : 0;
+                rc = run_rounds(false, geom, sched, 0, &left, &par, eager);
                 if (rc != TDX_OK) return rc;
+                if (left && par)   // stopped with tiles still active: the next schedule starts from the first flag half
+                    hipLaunchKernelGGL(tilek::flags_fold_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, sched.flags, sched.list + 2 * ntiles, int(ntiles));
             }
             if (!st.multi()) break;
             // the neighbours' boundary rows: cells finished there release the owned cells they drain into (addBorders() + queue
             // refill of src/areadinf.cpp:241-262); tiles that see a changed halo cell run again
             int64_t changed = 0;
-            rc = strip_exchange<float>(ctx, st, d_out, out_nodata, flags, geom.tiles_x, &changed, true);
+            rc = strip_exchange<float>(ctx, st, d_out, out_nodata, flags, geom.tiles_x, &changed, true, left ? 1 : 0);
             if (rc != TDX_OK) return rc;
             if (changed == 0) break;
             outer++;

@@ -655,8 +655,11 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
     const tilek::Sched sched{flags, flags + ntiles, counts}, sched32{flags32, flags32 + ntiles32, counts};
     // rounds run on 32 x 32 tiles while more than this many are active (policy constant; TDX_D8_BULK_UNTIL overrides it for every policy)
     static const unsigned long long bulk_until = getenv("TDX_D8_BULK_UNTIL") ? strtoull(getenv("TDX_D8_BULK_UNTIL"), nullptr, 10) : (unsigned long long)Alg::kBulkUntil;
-    auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out) -> int {
+    // (max_rounds > 0: stop after that many rounds with the active tiles' flags left in the schedule's flag half `*parity_out` - the multi-strip tail)
+    auto run_rounds = [&](bool small, const tilek::TileGeom& gg, const tilek::Sched& sc, unsigned long long stop_at, bool* active_left, int* parity_out,
+                          int max_rounds = 0) -> int {
         RoundRunner<flatk::LevelOp> runner(ctx, s, flatk::LevelOp{nullptr, nullptr}, gg, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
+        if (max_rounds > 0) { runner.batch = max_rounds; runner.batch_max = max_rounds; }
         if (small) { runner.grid_full = unsigned(std::min(runner.ntiles, 16 * ctx->num_cus)); runner.grid_small = unsigned(std::min(runner.ntiles, 4 * ctx->num_cus)); }
         static const bool print_rounds = getenv("TDX_DEBUG_ROUNDS") != nullptr;   // active tiles per round on stderr
         runner.print_counts = print_rounds;
@@ -675,6 +678,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             runner.collect();
             if (!runner.done && stop_at > 0 && runner.last_count <= stop_at) { *active_left = true; *parity_out = runner.parity; break; }
+            if (!runner.done && max_rounds > 0 && runner.rounds >= max_rounds) { *active_left = true; *parity_out = runner.parity; break; }
         }
         if (rounds_out) *rounds_out += runner.rounds;
         if (launches_out) *launches_out += runner.launches;
@@ -698,8 +702,13 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
             bulk = false;   // (strip re-activations are few tiles: 64 x 64)
         } else left = true;
         if (left) {
-            rc = run_rounds(false, geom, sched, 0, &left, &par);
+            // Multi-strip tail: at most `eager` rounds between two exchanges (areadinf.hip has the reasoning and the measurement): the flow paths that
+            // cross strip boundaries advance side by side instead of each waiting for the longest chain of the strip it enters.
+            static const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
+            rc = run_rounds(false, geom, sched, 0, &left, &par, st.multi() ? eager_env : 0);
             if (rc != TDX_OK) return rc;
+            if (left && par)   // stopped with tiles still active: the next schedule starts from the first flag half
+                hipLaunchKernelGGL(tilek::flags_fold_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, sched.flags, sched.list + 2 * ntiles, int(ntiles));
         }
         if (!st.multi()) break;
         // the neighbours' boundary rows (as bit patterns: a pending record must compare equal to itself): cells finished there
@@ -709,7 +718,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         Bits outside_bits;
         const typename Alg::Cell oc = Alg::outside();
         memcpy(&outside_bits, &oc, sizeof(Bits));
-        rc = strip_exchange<Bits>(ctx, st, reinterpret_cast<Bits*>(A.v), outside_bits, flags, geom.tiles_x, &changed, true);
+        rc = strip_exchange<Bits>(ctx, st, reinterpret_cast<Bits*>(A.v), outside_bits, flags, geom.tiles_x, &changed, true, left ? 1 : 0);
         if (rc != TDX_OK) return rc;
         if (changed == 0) break;
         if (outer_out) (*outer_out)++;

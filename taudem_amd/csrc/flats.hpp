@@ -415,16 +415,19 @@ static inline int flats_overwrite_elevation(tdx_context* ctx, size_t n, const LV
 // (the per-level share() + MPI_Allreduce of src/d8.cpp:549-550,620-630, once per strip crossing instead
 // of once per level).
 template <class Op = flatk::LevelOp>
+// eager_rounds > 0 (multi-strip only): at most that many rounds between two exchanges instead of strip-local fixed points - for fields whose fronts are many
+// and independent (reach_closure); a single front (a lake's level field) gains nothing and would only pay for the extra exchanges.
 static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::TileGeom geom, typename Op::Raw* field, const uint8_t* mask, tilek::Sched sc,
-                                    int64_t* rounds, int64_t* launches, const uint8_t* tile_masked = nullptr) {
+                                    int64_t* rounds, int64_t* launches, const uint8_t* tile_masked = nullptr, int eager_rounds = 0) {
     Op op{field, mask};
     if constexpr (Op::kHasPlain) op.TM = tile_masked;
     for (;;) {
-        int rc = tile_relax_run(ctx, op, geom, sc, rounds, launches);
+        bool left = false;
+        int rc = (st.multi() && eager_rounds > 0) ? tile_relax_run_bounded(ctx, op, geom, sc, eager_rounds, &left, rounds, launches) : tile_relax_run(ctx, op, geom, sc, rounds, launches);
         if (rc != TDX_OK) return rc;
         if (!st.multi()) return TDX_OK;
         int64_t changed = 0;
-        rc = strip_exchange<typename Op::Raw>(ctx, st, field, typename Op::Raw(-1), sc.flags, geom.tiles_x, &changed, true);   // halo exchange + the termination vote in one step
+        rc = strip_exchange<typename Op::Raw>(ctx, st, field, typename Op::Raw(-1), sc.flags, geom.tiles_x, &changed, true, left ? 1 : 0);   // halo exchange + the termination vote in one step
         if (rc != TDX_OK) return rc;
         if (changed == 0) return TDX_OK;
     }
@@ -568,5 +571,7 @@ static inline int reach_closure(tdx_context* ctx, const Strip& st, int32_t* reac
                                 unsigned long long* counts, int64_t* rounds, int64_t* launches) {
     // halo rows start at 0: the first exchange after the local pass brings in the neighbours' marks and flags the tiles
     const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
-    return flats_relax_field<flatk::ReachOp>(ctx, st, geom, reach, mask, tilek::Sched{flags, list, counts}, rounds, launches);
+    // (the closure of many outlets spreads upstream along every tributary at once: bounded rounds between the exchanges; TDX_REACH_EAGER_ROUNDS=0: fixed points)
+    static const int eager = getenv("TDX_REACH_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_REACH_EAGER_ROUNDS"))) : 32;
+    return flats_relax_field<flatk::ReachOp>(ctx, st, geom, reach, mask, tilek::Sched{flags, list, counts}, rounds, launches, nullptr, eager);
 }

@@ -142,9 +142,11 @@ static inline int strip_allreduce(tdx_context* ctx, const Strip& st, int64_t* v,
 // tile_flags != nullptr only differing cells are written, the tiles that see them are flagged, and
 // *nchanged (host) receives this rank's number of changed halo cells - or, with global_vote, the number summed over
 // all ranks (the termination vote of the caller's loop, fused into this exchange: one collective, one synchronisation).
+// extra_vote (with global_vote): this rank's own "not done yet" (0 / 1), counted into the vote next to its changed halo cells - for callers that
+// exchange BEFORE their strip-local schedule has run dry (the dependency sweeps' bounded rounds between two exchanges).
 template <class T>
 static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, uint32_t* tile_flags = nullptr, int tiles_x = 0, int64_t* nchanged = nullptr,
-                          bool global_vote = false) {
+                          bool global_vote = false, int extra_vote = 0) {
     if (nchanged) *nchanged = 0;
     if (st.ny_arr == st.y1 - st.y0) return TDX_OK;   // single-strip array without halo rows
     hipStream_t s = ctx->stream;
@@ -170,6 +172,7 @@ static int strip_exchange(tdx_context* ctx, const Strip& st, T* arr, T outside, 
     }
     unsigned long long* d_n = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_STRIP_CHANGED;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), s));
+    if (extra_vote) TDX_HIP_CHECK(ctx, hipMemsetAsync(d_n, 1, 1, s));   // (little-endian: the counter starts at 1)
     if (st.up) {
         const int yh = st.y0 - 1;
         hipLaunchKernelGGL(stripk::merge_row_kernel<T>, dim3(g), dim3(256), 0, s, arr + size_t(yh) * nx, static_cast<const T*>(c->recv_up), st.nx, d_n,

@@ -1110,6 +1110,13 @@ static __global__ __launch_bounds__(256) void ring_wrap_kernel(unsigned long lon
     if (threadIdx.x == 0) counts[0] = pending;
 }
 
+// a schedule that was stopped with tiles still active: their flags (the schedule's second flag half) back into the first, where a new schedule starts
+static __global__ __launch_bounds__(256) void flags_fold_kernel(uint32_t* __restrict__ f_first, uint32_t* __restrict__ f_second, int ntiles) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t b = f_second[t];
+    if (b) { f_second[t] = 0u; if (b > f_first[t]) f_first[t] = b; }
+}
 static __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1441,6 +1448,33 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     if (rounds_out) *rounds_out += A.rounds + B.rounds;
     if (launches_out) *launches_out += A.launches + B.launches;
+    return TDX_OK;
+}
+
+// The round schedule for at most ~max_rounds rounds (one batch in flight, batches of max_rounds): on return *active_left says whether tiles are still
+// active - their flags are then in sc.flags, where the next schedule (this function again, after a halo exchange has added its own activations) starts.
+// For multi-strip callers whose fronts are many and independent (the upstream closure of outlets): exchanging every few dozen rounds lets the fronts of
+// all strips advance side by side instead of strip-local fixed point after strip-local fixed point.
+template <class Op>
+static int tile_relax_run_bounded(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sched sc, int max_rounds, bool* active_left, int64_t* rounds_out,
+                                  int64_t* launches_out) {
+    RoundRunner<Op> run(ctx, ctx->stream, op, g, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
+    run.batch = run.batch_max = std::max(2, std::min(max_rounds, 64));
+    *active_left = false;
+    int rc = run.start();
+    if (rc != TDX_OK) return rc;
+    while (!run.done) {
+        rc = run.enqueue();
+        if (rc != TDX_OK) return rc;
+        rc = run.wait_oldest();
+        if (rc != TDX_OK) return rc;
+        run.collect();
+        if (!run.done && run.rounds >= max_rounds) { *active_left = true; break; }
+    }
+    if (*active_left && run.parity)   // the active tiles' flags sit in the second flag half: back into the first
+        hipLaunchKernelGGL(tilek::flags_fold_kernel, dim3(tdx_blocks_for(size_t(run.ntiles), 256)), dim3(256), 0, ctx->stream, run.flags_of(0), run.flags_of(1), run.ntiles);
+    if (rounds_out) *rounds_out += run.rounds;
+    if (launches_out) *launches_out += run.launches;
     return TDX_OK;
 }
 
