@@ -70,7 +70,8 @@ typedef struct tdx_stats {
     int64_t levels_rise;    /* BFS levels of incrise (sum over iterations)                           */
     int64_t cells_evaluated;/* aread8/areadinf/decay: cells that received a value                    */
     int64_t levels_fall_max;/* largest incfall level of any one iteration (all strips): the level fields are int16 like the */
-    int64_t levels_rise_max;/* reference's elev2 / dn partitions (src/d8.cpp:483,486) - 32766 is the deepest flat they hold  */
+    int64_t levels_rise_max;/* reference's elev2 / dn partitions (src/d8.cpp:483,486); a flat deeper than 32766 levels - where */
+                            /* the reference's short counters wrap - restarts the call on int32 fields                       */
 } tdx_stats;
 
 /* kernel classes for ms_kernel[] / launches[] */

@@ -813,7 +813,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 // Multi-strip tail: at most `eager` rounds between two exchanges.  A strip that runs to its local fixed point first makes every flow path
                 // that crosses a strip boundary wait for the longest chain ANYWHERE in the strip it enters - at BASELINE.json configs[4] 47 crossings x
                 // ~10 ms (profiles/r05b_projection_decay.txt); with frequent exchanges the paths advance side by side, as on one GPU.
-                static const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
+                const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
                 const int eager = st.multi() ? eager_env : 0;
                 rc = run_rounds(false, geom, sched, 0, &left, &par, eager);
                 if (rc != TDX_OK) return rc;

@@ -704,7 +704,7 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         if (left) {
             // Multi-strip tail: at most `eager` rounds between two exchanges (areadinf.hip has the reasoning and the measurement): the flow paths that
             // cross strip boundaries advance side by side instead of each waiting for the longest chain of the strip it enters.
-            static const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
+            const int eager_env = getenv("TDX_SWEEP_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_SWEEP_EAGER_ROUNDS"))) : 8;   // (0: local fixed points)
             rc = run_rounds(false, geom, sched, 0, &left, &par, st.multi() ? eager_env : 0);
             if (rc != TDX_OK) return rc;
             if (left && par)   // stopped with tiles still active: the next schedule starts from the first flag half

@@ -572,6 +572,6 @@ static inline int reach_closure(tdx_context* ctx, const Strip& st, int32_t* reac
     // halo rows start at 0: the first exchange after the local pass brings in the neighbours' marks and flags the tiles
     const tilek::TileGeom geom = tilek::make_geom(st.nx, st.ny_arr, st.y0, st.y1);
     // (the closure of many outlets spreads upstream along every tributary at once: bounded rounds between the exchanges; TDX_REACH_EAGER_ROUNDS=0: fixed points)
-    static const int eager = getenv("TDX_REACH_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_REACH_EAGER_ROUNDS"))) : 32;
+    const int eager = getenv("TDX_REACH_EAGER_ROUNDS") ? std::max(0, atoi(getenv("TDX_REACH_EAGER_ROUNDS"))) : 32;
     return flats_relax_field<flatk::ReachOp>(ctx, st, geom, reach, mask, tilek::Sched{flags, list, counts}, rounds, launches, nullptr, eager);
 }
