@@ -180,6 +180,51 @@ __global__ __launch_bounds__(256) void pit_prolong_kernel(float* __restrict__ W,
     if (W[idx] == FLT_MAX) W[idx] = Wc[size_t(y / CF) * size_t(nxc) + size_t(x / CF)];
 }
 
+// ---- one coarse correction in the middle of the fine relaxation ("V-cycle") --------------------------------------------------------------
+// The coarse start is an UPPER bound: a lake stands at its block-level spill, which is the largest elevation of the spill's 8 x 8 block, not the spill
+// itself.  The fine rounds find the true spill at once - and then lower the whole lake by the difference at one tile per round: the long tail of
+// PitRemove (~130 rounds of 16 us at 16384^2) and, across strips, one strip-local fixed point per strip the lake covers.  But what the fine level has
+// found can be handed back: U(B) = max of the current fine W over block B bounds the true surface on B, min(Wc, U) is again an upper bound of the
+// per-block maxima, the coarse operator keeps that property (a path inside a block never climbs above the block's largest elevation), so the coarse
+// level - relaxed again, across the strips, at 1/8 of the rounds - spreads the lowered levels over the lakes, and W <- min(W, Wc[block]) brings them
+// back (never below Z: Wc[B] >= the largest elevation of B).  Any upper bound converges to the same bits; only the number of rounds changes.
+__global__ __launch_bounds__(256) void pit_restrict_kernel(const float* __restrict__ W, int nx, int ny, int nxc, int nyc, float* __restrict__ Wc) {
+    const int xc = blockIdx.x * 64 + (threadIdx.x & 63), yc = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xc >= nxc || yc >= nyc) return;
+    const size_t c = size_t(yc) * size_t(nxc) + size_t(xc);
+    const float wc = Wc[c];
+    if (wc == TDX_FEL_NODATA) return;   // a block without valid cells
+    float u = -FLT_MAX;
+    if ((nx & 3) == 0 && xc * CF + CF <= nx && yc * CF + CF <= ny) {
+        for (int j = 0; j < CF; j++) {
+            const size_t o = size_t(yc * CF + j) * size_t(nx) + size_t(xc * CF);
+            const float4 w0 = *reinterpret_cast<const float4*>(W + o), w1 = *reinterpret_cast<const float4*>(W + o + 4);
+            const float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (v[i] != TDX_FEL_NODATA) u = fmaxf(u, v[i]);
+        }
+    } else {
+        for (int j = 0; j < CF && yc * CF + j < ny; j++)
+            for (int i = 0; i < CF && xc * CF + i < nx; i++) {
+                const float v = W[size_t(yc * CF + j) * size_t(nx) + size_t(xc * CF + i)];
+                if (v != TDX_FEL_NODATA) u = fmaxf(u, v);
+            }
+    }
+    if (u < wc) Wc[c] = u;
+}
+// W <- min(W, Wc[block]) on the owned rows [first row of W = owned row 0]; the tiles that see a lowered cell are activated (ya0 = array row of owned row 0)
+__global__ __launch_bounds__(256) void pit_prolong_min_kernel(float* __restrict__ W, int nx, int nyo, const float* __restrict__ Wc, int nxc, int ya0, int ny_arr,
+                                                              int tiles_x, uint32_t* __restrict__ tile_flags) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= nyo) return;
+    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+    const float w = W[idx], wc = Wc[size_t(y / CF) * size_t(nxc) + size_t(x / CF)];
+    if (w != TDX_FEL_NODATA && wc != TDX_FEL_NODATA && wc < w) {
+        W[idx] = wc;
+        tilek::activate_tiles_around(x, ya0 + y, nx, ny_arr, tiles_x, tile_flags);
+    }
+}
+
 // minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
 template <int NBR>   // 8, or 4 for the -4way flag (k = 1,3,5,7)
 struct PitOp {
@@ -228,11 +273,13 @@ static inline Strip pit_level_strip(const Strip& st, int nxc, int nyc) {
 // rows frozen in its halo rows, then boundary rows are exchanged and the tiles that see a changed halo cell are re-activated; repeat until no halo
 // cell changed on any rank (the roles of share() + ringTerm() in src/flood.cpp:344-355,457-468).
 template <int NBR>
-static int pit_relax_level(tdx_context* ctx, const Strip& ls, const float* Z, float* W, tilek::Sched sc, int64_t* rounds, int64_t* launches, int64_t* outer) {
+static int pit_relax_level(tdx_context* ctx, const Strip& ls, const float* Z, float* W, tilek::Sched sc, int64_t* rounds, int64_t* launches, int64_t* outer,
+                           bool all_tiles = true) {
     hipStream_t s = ctx->stream;
     const tilek::TileGeom g = tilek::make_geom(ls.nx, ls.ny_arr, ls.y0, ls.y1);
     const int ntiles = g.tiles_x * g.tiles_y;
-    hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));   // round 0: every tile is active
+    if (all_tiles)   // round 0: every tile is active (otherwise: the tiles flagged in sc.flags)
+        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));
     for (;;) {
         int rc = tile_relax_run(ctx, PitOp<NBR>{Z, W}, g, sc, rounds, launches);
         if (rc != TDX_OK) return rc;
@@ -308,7 +355,8 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     int64_t cells_all = int64_t(st.nx) * int64_t(nyo);   // every rank takes the same path: the decision is made on the whole raster's size
     rc = strip_allreduce(ctx, st, &cells_all, 1, TDX_OP_SUM);
     if (rc != TDX_OK) return rc;
-    if (!fourway && !no_coarse && cells_all >= (int64_t(1) << 18)) {
+    const bool used_coarse = !fourway && !no_coarse && cells_all >= (int64_t(1) << 18);
+    if (used_coarse) {
         // seed surface -> first coarse level -> (coarser levels, relaxed coarse to fine, each across the strips) -> start surface, without a W0 in between
         const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
         const Strip ls = pit_level_strip(st, nxc, nyc);
@@ -343,7 +391,43 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     if (rc != TDX_OK) return rc;
     {
         TdxSpan sp(ctx, TDX_K_RELAX);
-        rc = fourway ? pit_relax_level<4>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer) : pit_relax_level<8>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer);
+        bool all_tiles = true;
+        // one coarse correction after the first fine rounds (see pit_restrict_kernel); TDX_PIT_VCYCLE_AFTER=n: after n rounds (0: never)
+        static const int vc_env = getenv("TDX_PIT_VCYCLE_AFTER") ? std::max(0, atoi(getenv("TDX_PIT_VCYCLE_AFTER"))) : 8;
+        if (used_coarse && vc_env > 0) {
+            hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
+            bool left = false;
+            rc = tile_relax_run_bounded(ctx, PitOp<8>{d_dem, d_fel}, geom, sched, vc_env, &left, &rounds, &launches);
+            if (rc != TDX_OK) return rc;
+            all_tiles = false;   // what is still active stays flagged
+            if (left || st.multi()) {   // (a single strip that has converged needs no correction; with neighbours every rank must take the same path)
+                const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
+                const Strip ls = pit_level_strip(st, nxc, nyc);
+                const size_t off = size_t(ls.y0) * size_t(nxc);
+                float* Zc = static_cast<float*>(ctx->scratch(TDX_S_D, size_t(nxc) * size_t(ls.ny_arr) * 4));
+                float* Wc = static_cast<float*>(ctx->scratch(TDX_S_E, size_t(nxc) * size_t(ls.ny_arr) * 4));
+                const tilek::TileGeom gc = tilek::make_geom(ls.nx, ls.ny_arr, ls.y0, ls.y1);
+                const size_t ntc = size_t(gc.tiles_x) * size_t(gc.tiles_y);
+                uint32_t* cflags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntc * 4 * (1 + tilek::SCHED_LIST_WORDS)));   // (the fine level's flags are in use)
+                unsigned long long* ccounts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
+                if (!Zc || !Wc || !cflags || !ccounts) return TDX_ERR_NOMEM;
+                ctx->phase = "coarse correction";
+                hipLaunchKernelGGL(pit_restrict_kernel, dim3((nxc + 63) / 64, (nyc + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, nxc, nyc, Wc + off);
+                rc = strip_exchange<float>(ctx, ls, Wc, TDX_FEL_NODATA);
+                if (rc != TDX_OK) return rc;
+                rc = pit_relax_level<8>(ctx, ls, Zc, Wc, tilek::Sched{cflags, cflags + ntc, ccounts}, &rounds, &launches, nullptr);
+                if (rc != TDX_OK) return rc;
+                hipLaunchKernelGGL(pit_prolong_min_kernel, dim3((st.nx + 63) / 64, (nyo + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, Wc + off, nxc,
+                                   st.y0, st.ny_arr, geom.tiles_x, flags);
+                ctx->phase = "fine level";
+                if (st.multi()) {   // the neighbours' lowered boundary rows (their tiles are flagged by the merge)
+                    int64_t changed = 0;
+                    rc = strip_exchange<float>(ctx, st, d_fel, TDX_FEL_NODATA, flags, geom.tiles_x, &changed);
+                    if (rc != TDX_OK) return rc;
+                }
+            }
+        }
+        rc = fourway ? pit_relax_level<4>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer, all_tiles) : pit_relax_level<8>(ctx, st, d_dem, d_fel, sched, &rounds, &launches, &outer, all_tiles);
         if (rc != TDX_OK) return rc;
         if (stats) stats->launches[TDX_K_RELAX] += launches;
     }
