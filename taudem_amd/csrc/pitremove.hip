@@ -188,11 +188,16 @@ __global__ __launch_bounds__(256) void pit_prolong_kernel(float* __restrict__ W,
 // per-block maxima, the coarse operator keeps that property (a path inside a block never climbs above the block's largest elevation), so the coarse
 // level - relaxed again, across the strips, at 1/8 of the rounds - spreads the lowered levels over the lakes, and W <- min(W, Wc[block]) brings them
 // back (never below Z: Wc[B] >= the largest elevation of B).  Any upper bound converges to the same bits; only the number of rounds changes.
-__global__ __launch_bounds__(256) void pit_restrict_kernel(const float* __restrict__ W, int nx, int ny, int nxc, int nyc, float* __restrict__ Wc) {
+// Ur keeps what the block was restricted to (= the block's largest fine W: the start surface never exceeds the coarse one): the coarse relaxation that
+// follows has work for the fine level exactly where it takes a block BELOW that (pit_prolong_min_kernel); the coarse tiles that see a lowered block are
+// flagged (ya0c = array row of the coarse level's first owned row).
+__global__ __launch_bounds__(256) void pit_restrict_kernel(const float* __restrict__ W, int nx, int ny, int nxc, int nyc, float* __restrict__ Wc, float* __restrict__ Ur,
+                                                           int ya0c, int ny_arr_c, int tiles_x_c, uint32_t* __restrict__ cflags) {
     const int xc = blockIdx.x * 64 + (threadIdx.x & 63), yc = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xc >= nxc || yc >= nyc) return;
     const size_t c = size_t(yc) * size_t(nxc) + size_t(xc);
     const float wc = Wc[c];
+    Ur[c] = wc;
     if (wc == TDX_FEL_NODATA) return;   // a block without valid cells
     float u = -FLT_MAX;
     if ((nx & 3) == 0 && xc * CF + CF <= nx && yc * CF + CF <= ny) {
@@ -210,19 +215,30 @@ __global__ __launch_bounds__(256) void pit_restrict_kernel(const float* __restri
                 if (v != TDX_FEL_NODATA) u = fmaxf(u, v);
             }
     }
-    if (u < wc) Wc[c] = u;
-}
-// W <- min(W, Wc[block]) on the owned rows [first row of W = owned row 0]; the tiles that see a lowered cell are activated (ya0 = array row of owned row 0)
-__global__ __launch_bounds__(256) void pit_prolong_min_kernel(float* __restrict__ W, int nx, int nyo, const float* __restrict__ Wc, int nxc, int ya0, int ny_arr,
-                                                              int tiles_x, uint32_t* __restrict__ tile_flags) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= nx || y >= nyo) return;
-    const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-    const float w = W[idx], wc = Wc[size_t(y / CF) * size_t(nxc) + size_t(x / CF)];
-    if (w != TDX_FEL_NODATA && wc != TDX_FEL_NODATA && wc < w) {
-        W[idx] = wc;
-        tilek::activate_tiles_around(x, ya0 + y, nx, ny_arr, tiles_x, tile_flags);
+    if (u < wc) {
+        Wc[c] = u; Ur[c] = u;
+        tilek::activate_tiles_around(xc, ya0c + yc, nxc, ny_arr_c, tiles_x_c, cflags);
     }
+}
+// W <- min(W, Wc[block]) wherever the coarse relaxation took a block below what it was restricted to (one thread per coarse block: 64 x fewer threads than
+// cells, and work only where there is some); the fine tiles that see a lowered cell are activated (ya0 = array row of the fine level's first owned row)
+__global__ __launch_bounds__(256) void pit_prolong_min_kernel(float* __restrict__ W, int nx, int nyo, const float* __restrict__ Wc, const float* __restrict__ Ur, int nxc, int nyc,
+                                                              int ya0, int ny_arr, int tiles_x, uint32_t* __restrict__ tile_flags) {
+    const int xc = blockIdx.x * 64 + (threadIdx.x & 63), yc = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xc >= nxc || yc >= nyc) return;
+    const size_t c = size_t(yc) * size_t(nxc) + size_t(xc);
+    const float wc = Wc[c];
+    if (wc == TDX_FEL_NODATA || !(wc < Ur[c])) return;
+    for (int j = 0; j < CF && yc * CF + j < nyo; j++)
+        for (int i = 0; i < CF && xc * CF + i < nx; i++) {
+            const int x = xc * CF + i, y = yc * CF + j;
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            const float w = W[idx];
+            if (w != TDX_FEL_NODATA && wc < w) {
+                W[idx] = wc;
+                tilek::activate_tiles_around(x, ya0 + y, nx, ny_arr, tiles_x, tile_flags);
+            }
+        }
 }
 
 // minimax-path operator of flood() (src/flood.cpp:295-330): W <- (Z >= m ? Z : min(W, m)) where W > Z
@@ -255,7 +271,7 @@ struct PitOp {
 }  // namespace
 
 static int pit_finish_level(tdx_context* ctx, const Strip& ls, float* Zc, float* Wc, int nxc, int nyc, int64_t cells_all, tilek::Sched sc, int depth,
-                            int64_t* rounds, int64_t* launches);
+                            int64_t* rounds, int64_t* launches, int64_t* own_rounds = nullptr);
 
 // The strip of a coarse level: the rows the rank's owned rows coarsen to, stacked in rank order, ARE a coarsening of the whole raster (a rank's last
 // block row may be lower than CF rows; blocks that touch in the fine raster are neighbours in the stacked coarse raster and vice versa), so a
@@ -319,7 +335,7 @@ static int pit_coarse_start(tdx_context* ctx, const Strip& st, const float* Z, f
 }
 // a coarse level whose owned rows hold the coarsened seed surface: halo rows, coarser levels, relaxation
 static int pit_finish_level(tdx_context* ctx, const Strip& ls, float* Zc, float* Wc, int nxc, int nyc, int64_t cells_all, tilek::Sched sc, int depth,
-                            int64_t* rounds, int64_t* launches) {
+                            int64_t* rounds, int64_t* launches, int64_t* own_rounds) {
     const size_t off = size_t(ls.y0) * size_t(nxc);
     int rc = pit_coarse_start(ctx, ls, Zc + off, Wc + off, nxc, nyc, cells_all, sc, depth + 1, rounds, launches);
     if (rc != TDX_OK) return rc;
@@ -327,7 +343,10 @@ static int pit_finish_level(tdx_context* ctx, const Strip& ls, float* Zc, float*
     if (rc != TDX_OK) return rc;
     rc = strip_exchange<float>(ctx, ls, Wc, TDX_FEL_NODATA);
     if (rc != TDX_OK) return rc;
-    return pit_relax_level<8>(ctx, ls, Zc, Wc, sc, rounds, launches, nullptr);
+    const int64_t before = *rounds;
+    rc = pit_relax_level<8>(ctx, ls, Zc, Wc, sc, rounds, launches, nullptr);
+    if (own_rounds) *own_rounds = *rounds - before;   // rounds of THIS level's relaxation: ~1/6 of what the next finer level's tail will need
+    return rc;
 }
 
 // One strip (src/flood.cpp:132-482).
@@ -356,6 +375,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
     rc = strip_allreduce(ctx, st, &cells_all, 1, TDX_OP_SUM);
     if (rc != TDX_OK) return rc;
     const bool used_coarse = !fourway && !no_coarse && cells_all >= (int64_t(1) << 18);
+    int64_t level1_rounds = 0;
     if (used_coarse) {
         // seed surface -> first coarse level -> (coarser levels, relaxed coarse to fine, each across the strips) -> start surface, without a W0 in between
         const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
@@ -372,7 +392,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
         {
             TdxSpan sp(ctx, TDX_K_RELAX);
             ctx->phase = "coarse levels";
-            rc = pit_finish_level(ctx, ls, Zc, Wc, nxc, nyc, cells_all / (CF * CF), sched, 0, &rounds, &launches);
+            rc = pit_finish_level(ctx, ls, Zc, Wc, nxc, nyc, cells_all / (CF * CF), sched, 0, &rounds, &launches, &level1_rounds);
             if (rc != TDX_OK) return rc;
         }
         {
@@ -400,7 +420,12 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
             rc = tile_relax_run_bounded(ctx, PitOp<8>{d_dem, d_fel}, geom, sched, vc_env, &left, &rounds, &launches);
             if (rc != TDX_OK) return rc;
             all_tiles = false;   // what is still active stays flagged
-            if (left || st.multi()) {   // (a single strip that has converged needs no correction; with neighbours every rank must take the same path)
+            // A correction costs a pass over the fine surface, a coarse relaxation and a restart of the fine schedule (~1 ms at 16384^2): it pays when the fine
+            // tail is long.  The first coarse level's own relaxation says how long - the fine level needs ~6 x its rounds (13 -> 67 on a 65536 x 8192 strip,
+            // 20 -> 123 at 16384^2, 36 -> 245 at 32768^2) -: corrected from 16 coarse rounds on; TDX_PIT_VCYCLE_MIN=n moves the bar.  With neighbours every
+            // rank must take the same path, and the strip-by-strip lowering of a shared lake is what the correction is for: always.
+            static const int vc_min = getenv("TDX_PIT_VCYCLE_MIN") ? atoi(getenv("TDX_PIT_VCYCLE_MIN")) : 16;
+            if (st.multi() || (left && level1_rounds >= vc_min)) {
                 const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
                 const Strip ls = pit_level_strip(st, nxc, nyc);
                 const size_t off = size_t(ls.y0) * size_t(nxc);
@@ -410,14 +435,20 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
                 const size_t ntc = size_t(gc.tiles_x) * size_t(gc.tiles_y);
                 uint32_t* cflags = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, ntc * 4 * (1 + tilek::SCHED_LIST_WORDS)));   // (the fine level's flags are in use)
                 unsigned long long* ccounts = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
-                if (!Zc || !Wc || !cflags || !ccounts) return TDX_ERR_NOMEM;
+                float* Ur = static_cast<float*>(ctx->scratch(TDX_S_N, size_t(nxc) * size_t(nyc) * 4));
+                if (!Zc || !Wc || !cflags || !ccounts || !Ur) return TDX_ERR_NOMEM;
                 ctx->phase = "coarse correction";
-                hipLaunchKernelGGL(pit_restrict_kernel, dim3((nxc + 63) / 64, (nyc + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, nxc, nyc, Wc + off);
-                rc = strip_exchange<float>(ctx, ls, Wc, TDX_FEL_NODATA);
+                TDX_HIP_CHECK(ctx, hipMemsetAsync(cflags, 0, ntc * 4, s));
+                hipLaunchKernelGGL(pit_restrict_kernel, dim3((nxc + 63) / 64, (nyc + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, nxc, nyc, Wc + off, Ur,
+                                   ls.y0, ls.ny_arr, gc.tiles_x, cflags);
+                {   // the neighbours' restricted boundary rows (the coarse tiles that see a change are flagged by the merge)
+                    int64_t changed = 0;
+                    rc = strip_exchange<float>(ctx, ls, Wc, TDX_FEL_NODATA, cflags, gc.tiles_x, &changed);
+                    if (rc != TDX_OK) return rc;
+                }
+                rc = pit_relax_level<8>(ctx, ls, Zc, Wc, tilek::Sched{cflags, cflags + ntc, ccounts}, &rounds, &launches, nullptr, false);
                 if (rc != TDX_OK) return rc;
-                rc = pit_relax_level<8>(ctx, ls, Zc, Wc, tilek::Sched{cflags, cflags + ntc, ccounts}, &rounds, &launches, nullptr);
-                if (rc != TDX_OK) return rc;
-                hipLaunchKernelGGL(pit_prolong_min_kernel, dim3((st.nx + 63) / 64, (nyo + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, Wc + off, nxc,
+                hipLaunchKernelGGL(pit_prolong_min_kernel, dim3((nxc + 63) / 64, (nyc + 3) / 4), dim3(256), 0, s, d_fel + size_t(st.y0) * size_t(st.nx), st.nx, nyo, Wc + off, Ur, nxc, nyc,
                                    st.y0, st.ny_arr, geom.tiles_x, flags);
                 ctx->phase = "fine level";
                 if (st.multi()) {   // the neighbours' lowered boundary rows (their tiles are flagged by the merge)
