@@ -413,7 +413,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
         TdxSpan sp(ctx, TDX_K_RELAX);
         bool all_tiles = true;
         // one coarse correction after the first fine rounds (see pit_restrict_kernel); TDX_PIT_VCYCLE_AFTER=n: after n rounds (0: never)
-        static const int vc_env = getenv("TDX_PIT_VCYCLE_AFTER") ? std::max(0, atoi(getenv("TDX_PIT_VCYCLE_AFTER"))) : 8;
+        const int vc_env = getenv("TDX_PIT_VCYCLE_AFTER") ? std::max(0, atoi(getenv("TDX_PIT_VCYCLE_AFTER"))) : 8;   // (read per call: test hook)
         if (used_coarse && vc_env > 0) {
             hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
             bool left = false;
@@ -424,7 +424,7 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
             // tail is long.  The first coarse level's own relaxation says how long - the fine level needs ~6 x its rounds (13 -> 67 on a 65536 x 8192 strip,
             // 20 -> 123 at 16384^2, 36 -> 245 at 32768^2) -: corrected from 16 coarse rounds on; TDX_PIT_VCYCLE_MIN=n moves the bar.  With neighbours every
             // rank must take the same path, and the strip-by-strip lowering of a shared lake is what the correction is for: always.
-            static const int vc_min = getenv("TDX_PIT_VCYCLE_MIN") ? atoi(getenv("TDX_PIT_VCYCLE_MIN")) : 16;
+            const int vc_min = getenv("TDX_PIT_VCYCLE_MIN") ? atoi(getenv("TDX_PIT_VCYCLE_MIN")) : 16;   // (read per call: test hook)
             if (st.multi() || (left && level1_rounds >= vc_min)) {
                 const int nxc = (st.nx + CF - 1) / CF, nyc = (nyo + CF - 1) / CF;
                 const Strip ls = pit_level_strip(st, nxc, nyc);

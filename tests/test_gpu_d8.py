@@ -452,3 +452,23 @@ def test_many_big_cells_in_one_three_and_eight_strips(ctx, oracle, monkeypatch):
             got = np.concatenate([r[i] for r in res], axis=0)
             assert bits_equal(got, ref), describe_diff(got, ref, f"ad8 in {world} strips (contcheck={bool(i)})")
         assert res[0][2] > 2, "no outer rounds: the strips never exchanged a big cell"
+
+
+@pytest.mark.parametrize("after", [1, 3, 8])
+def test_pitremove_coarse_correction_on_one_strip(ctx, oracle, monkeypatch, after):
+    """PitRemove's coarse correction (restrict the fine surface after `after` rounds, relax the coarse level again, W <- min(W, Wc[block])) is only taken on
+    one strip when the first coarse level needed >= 16 rounds - never at test sizes.  Forced here (TDX_PIT_VCYCLE_MIN=0) on rasters with lakes, nodata holes
+    and a spiral channel: any upper bound converges to flood()'s surface, so the bits must not move."""
+    import pathological as P
+
+    monkeypatch.setenv("TDX_PIT_VCYCLE_MIN", "0")
+    monkeypatch.setenv("TDX_PIT_VCYCLE_AFTER", str(after))
+    dems = [oracle.synth_dem((700, 900), 31), oracle.synth_dem((1100, 640), 32), P.spiral(640, 8), P.checkerboard_pits(600, 700)]
+    holes = oracle.synth_dem((800, 800), 33)
+    holes[100:300, 200:650] = -9999.0
+    holes[500:520, :] = -9999.0
+    dems.append(holes)
+    for i, dem in enumerate(dems):
+        fel_o = oracle.pitremove(dem, -9999.0)
+        fel, st = ctx.pitremove(dem, -9999.0, stats=True)
+        assert bits_equal(fel, fel_o), describe_diff(fel, fel_o, f"fel (raster {i}, correction after {after} rounds)")
