@@ -167,3 +167,41 @@ def test_bench_decay_workload_two_ranks_gloo():
     one = _bench(["--workload", "decay", "--nx", "512", "--ny", "512", "--steps", "1", "--warmup", "0"], {})
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["config"]["cells_in_the_outlets_catchments"] == one["config"]["cells_in_the_outlets_catchments"] > 0
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_segment_trace_of_a_strip_run(oracle, mode):
+    """Option "segment_trace" (include/taudem_amd.h: tdx_context_segments): every rank logs the same sequence of segments between collectives - the protocol is
+    rank-symmetric -, a call ends with a segment of kind 2, mode 2 (one rank on the device at a time) runs to the end, and the projection accepts the logs."""
+    import torch
+
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows, project_critical_path
+
+    ny, nx, world = 300, 260, 3
+    dem = oracle.synth_dem((ny, nx), 77)
+    fel_o = oracle.pitremove(dem, -9999.0)
+    parts = partition_rows(ny, world)
+    with StripGroup(world, nx, [0] * world) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            pipe = StripPipeline(c, comm, nx, y1 - y0)
+            d = pipe.empty(torch.float32)
+            d[1:y1 - y0 + 1] = torch.from_numpy(dem[y0:y1]).cuda()
+            c.set_option("segment_trace", mode)
+            fel, _ = pipe.pitremove(d, -9999.0)
+            p, _, _ = pipe.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+            a, _ = pipe.aread8(p, -32768)
+            seg = c.segments()
+            c.set_option("segment_trace", 0)
+            assert c.segments() == []
+            return seg, fel[1:y1 - y0 + 1].cpu().numpy()
+        res = grp.run(rank_main)
+    logs = [r[0] for r in res]
+    assert bits_equal(np.concatenate([r[1] for r in res], axis=0), fel_o)
+    assert len(logs[0]) > 10 and all([s[:3] for s in lg] == [s[:3] for s in logs[0]] for lg in logs)
+    stages = [s[0] for s in logs[0]]
+    assert stages[0] == "pitremove" and "d8flowdir" in stages and stages[-1] == "aread8"
+    assert [s[2] for s in logs[0]].count(2) == 3 and logs[0][-1][2] == 2          # three calls, each closed by an "end of call" segment
+    assert all(s[3] >= 0.0 and s[4] >= 0.0 for lg in logs for s in lg)
+    proj = project_critical_path(logs)
+    assert set(proj["per_stage"]) == {"pitremove", "d8flowdir", "aread8"} and proj["total_ms"] > 0
