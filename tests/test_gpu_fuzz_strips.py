@@ -1,6 +1,8 @@
 """Seeded fuzz of the strip protocol (round 5: coarse levels across strips, tree-wise big-cell folds on pending lists, bounded sweep / closure rounds between
 two exchanges, both level fields side by side): random raster shapes, rank counts (2 ... 8, strips shorter than a tile included), nodata holes, weights,
 outlets and a lowered big-cell threshold - every raster of every tool must equal the pinned restatement's, bit for bit, whatever the cut."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,8 +14,9 @@ ANG_ND = -3.402823466e38
 
 def _case(seed):
     rng = np.random.default_rng(1000 + seed)
-    ny = int(rng.integers(40, 700))
-    nx = int(rng.integers(40, 900))
+    scale = int(os.environ.get("TDX_FUZZ_SCALE", "1"))
+    ny = int(rng.integers(40, 700 * scale))
+    nx = int(rng.integers(40, 900 * scale))
     world = int(rng.integers(2, 9))
     world = max(2, min(world, ny // 3))
     holes = int(rng.integers(0, 4))
@@ -22,7 +25,8 @@ def _case(seed):
     return ny, nx, world, holes, thr, eager, rng
 
 
-@pytest.mark.parametrize("seed", range(32))
+# (TDX_FUZZ_SEEDS=n: a longer one-off sweep, e.g. after a change of the strip protocol; TDX_FUZZ_SCALE=k: rasters up to k x larger on each side)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDX_FUZZ_SEEDS", "32"))))
 def test_random_cut_random_raster(seed, oracle, monkeypatch):
     import torch
 
