@@ -399,7 +399,7 @@ __device__ __forceinline__ bool ring_cell(int j, int rv, int& hx, int& hy) {
 }
 
 __device__ unsigned long long g_ad8_dbg[8];   // TDX_AD8_DEBUG=1: phase cycles of ad8_tile_local_kernel summed over the tiles (thread 0)
-template <bool DBG>
+template <bool DBG, bool FLAT>
 __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, unsigned long long* __restrict__ node_acc,
                                                              uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next) {
@@ -482,6 +482,27 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     AD8_MARK(2);
     // Kahn sweep of the in-tile flows: one returning 32-bit LDS atomic per hop; the target of the NEXT hop is read alongside the
     // atomic (both only need the current target), so a hop is one LDS round trip, not two
+    if (FLAT) {
+        // ONE loop per lane: a lane whose walk has ended starts its next source in the very next step, whatever the other lanes of the wave are doing.  (With
+        // a walk loop nested in a loop over the lane's sources - the `else` branch, TDX_AD8_KAHN_NESTED=1 - a wave pays, source after source, for the LONGEST
+        // walk any of its lanes makes from its k-th source: 271 steps per tile against 165 in a step model of the schedule on a 2048^2 fractal raster's
+        // directions; the tile's longest in-tile path is 79 hops.)  Starting a source is a hop like any other: the lane "arrives" at the source cell itself with
+        // nothing (add = 0), finds arrivals == in-degree == 0 in the returned word and goes on with that word towards the cell's target.
+        int t = -1;
+        unsigned add = 0u;
+        while (t >= 0 || src != 0u) {
+            if (t < 0) {
+                const int r = __ffs(int(src)) - 1;
+                src &= src - 1u;
+                t = (ry0 + r) * TS + lx;
+                add = 0u;
+            }
+            const int tn = S_TGT(t);
+            const unsigned nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
+            add = lw_pack(lw_cnt(nw), 1u, lw_con(nw) ? 1u : 0u, lw_poi(nw) ? 1u : 0u, 0u);
+            t = lw_arr(nw) == lw_indeg(nw) ? tn : -1;   // not the last contributor: someone else will go on from here
+        }
+    } else {
     while (src) {
         const int r = __ffs(int(src)) - 1;
         src &= src - 1u;
@@ -495,6 +516,7 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
             if (lw_arr(nw) != lw_indeg(nw)) break;   // someone else will be the last contributor
             w = nw; t = tn;
         }
+    }
     }
     __syncthreads();
     AD8_MARK(3);
@@ -553,8 +575,10 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
 __device__ __forceinline__ void forest_walk_from(uint32_t u, unsigned long long w, const Ad8Geom& g, unsigned long long* __restrict__ node_acc,
                                                  const uint32_t* __restrict__ node_indeg, const uint32_t* __restrict__ node_next,
                                                  unsigned long long* __restrict__ outbox) {
+    // One memory round trip per hop: the node AFTER the next one (node_next[n], read-only during the walks) and the next node's in-degree are requested
+    // together with the returning atomic on the next node - read at the top of the loop they were a second, dependent round trip per hop.
+    uint32_t n = node_next[u];
     for (;;) {
-        const uint32_t n = node_next[u];
         if (n == NEXT_NONE) return;
         if (n == NEXT_REMOTE_UP || n == NEXT_REMOTE_DOWN) {
             // u is a perimeter node in the first / last tile row; its column is tile column * 64 + (pos & 63)
@@ -563,10 +587,11 @@ __device__ __forceinline__ void forest_walk_from(uint32_t u, unsigned long long 
             outbox[(n == NEXT_REMOTE_UP ? 0u : uint32_t(g.nx)) + gx] = (w & ~BOX_VALID) | BOX_VALID;
             return;
         }
+        const uint32_t nn = node_next[n], ind = node_indeg[n];
         const unsigned long long add = nw_pack(unsigned(w), 1u, nw_con(w) ? 1u : 0u, nw_poi(w) ? 1u : 0u);
         const unsigned long long nw = __hip_atomic_fetch_add(&node_acc[n], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-        if (nw_arr(nw) != node_indeg[n]) return;
-        u = n; w = nw;
+        if (nw_arr(nw) != ind) return;
+        u = n; w = nw; n = nn;
     }
 }
 
@@ -867,7 +892,7 @@ __global__ __launch_bounds__(256) void ad8_big_gather_kernel(const int16_t* __re
 // of the same chunk are handed on in list order.  A cell with a blocked contributor stays pending (BIG_MARK) for the
 // next outer round.
 constexpr unsigned BIG_LDS = 15360;
-__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
+__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int scan_min, const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
                                                           const uint32_t* __restrict__ segbeg, const unsigned long long* __restrict__ nseg_dev,
                                                           const float* __restrict__ vals, const uint32_t* __restrict__ deps,
                                                           const uint32_t* __restrict__ flags, float* __restrict__ bigval, float* __restrict__ A,
@@ -882,6 +907,7 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
     const unsigned long long b0 = segbeg ? (unsigned long long)segbeg[seg] : 0ull, nbig = segbeg ? (unsigned long long)segbeg[seg + 1] : *nbig_dev;   // this wave's part: [b0, nbig)
     for (unsigned long long i = lane; b0 + i < nbig && i < BIG_LDS; i += 64) s_big[i] = bigval[b0 + i];
     const bool spill = nbig - b0 > BIG_LDS;
+    float hint = 0.f;   // the value of the last cell folded in this tree: values ascend with the list, so its binade is the guess for the next chunk's scan
     // operands of the first chunk; the next chunk's are fetched while the current one is folded
     uint32_t f = 0, c = 0, dp[8];
     float ak[8];
@@ -957,6 +983,53 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
         }
         unsigned long long serial = __ballot(pending && !blocked && inchunk != 0u);
         const unsigned long long singles = __ballot(single);
+        // The serial steps as a SCAN.  Inside one binade [B, 2B) (ulp u) a float32 addition is RN(c + x) = c + R(x) where R(x) is x rounded to a multiple of u and
+        // depends on c only through the PARITY of c / u (ties go to the even sum).  So the fold of a cell with one contributor in the chunk, as a function of
+        // that contributor's value v, is v + D[parity(v)] as long as v and the result stay inside the binade - and D[0], D[1] are what the fold itself returns
+        // for the two representatives B and B + u (the reference's additions, in the reference's order).  Functions of this form compose
+        // ((g o f)[p] = f[p] + g[p ^ parity(f[p])], all sums exact: multiples of u below 2B), so the in-chunk dependencies - chains of main-stem cells, several
+        // of them interleaved - are resolved by pointer jumping over the wave (<= 6 steps) instead of one cell after the other (~0.12 us each).  B is a guess
+        // (values ascend with the list: the binade of the largest value known so far); every scanned cell then checks that its contributor's value and its own
+        // lie in [B, 2B) - if not (a chunk that straddles a power of two, a blocked or contaminated cell) the serial loop below does the chunk as before.
+        if (scan_min > 0 && serial != 0ull && (serial & ~singles) == 0ull && __popcll(serial) >= scan_min) {
+            const bool mine = ((serial >> lane) & 1ull) != 0ull;
+            float top = (!mine && result >= 1.0f) ? result : 0.f;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) top = fmaxf(top, __shfl_xor(top, o, 64));
+            top = fmaxf(top, hint);
+            if (top >= 1.0f) {   // (uniform)
+                const unsigned bB = __float_as_uint(top) & 0xFF800000u;
+                const float B = __uint_as_float(bB), B1 = __uint_as_float(bB + 1u), twoB = B + B;
+                float D0 = 0.f, D1 = 0.f;
+                if (mine) {
+                    float a0 = pre + B, a1 = pre + B1;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { a0 = a0 + suf[k]; a1 = a1 + suf[k]; }
+                    D0 = a0 - B; D1 = a1 - B1;
+                }
+                bool res = !mine;
+                float val = result;
+                int par = mine ? jdep : lane;
+                for (int it = 0; it < 8 && __ballot(!res) != 0ull; it++) {
+                    const int pres = __shfl(int(res), par, 64), pp = __shfl(par, par, 64);
+                    const float pv = __shfl(val, par, 64), pD0 = __shfl(D0, par, 64), pD1 = __shfl(D1, par, 64);
+                    if (!res) {
+                        if (pres) { val = pv + ((__float_as_uint(pv) & 1u) ? D1 : D0); res = true; }
+                        else {
+                            const bool o0 = (__float_as_uint(B + pD0) & 1u) != 0u, o1 = (__float_as_uint(B + pD1) & 1u) != 0u;
+                            const float n0 = pD0 + (o0 ? D1 : D0), n1 = pD1 + (o1 ? D0 : D1);
+                            D0 = n0; D1 = n1; par = pp;
+                        }
+                    }
+                }
+                const float pin = __shfl(val, mine ? jdep : lane, 64);   // the contributor's final value
+                const bool good = !mine || (res && !blkpre && !(c2pre && contcheck == 1) && pin >= B && pin < twoB && val < twoB);
+                if (__ballot(!good) == 0ull) {
+                    if (mine) result = val;
+                    serial = 0ull;
+                }
+            }
+        }
         while (serial) {
             const int i = __ffsll((long long)serial) - 1;
             serial &= serial - 1ull;
@@ -990,6 +1063,10 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, const u
             done++;
         }
         if (spill) drain_stores();   // later chunks read these values back through the L2
+        {
+            const float last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, result), 63));
+            if (last >= 1.0f) hint = last;
+        }
     }
     }   // trees
     if (done) atomicAdd(nfinal, done);
@@ -1187,13 +1264,15 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         if (ad8_debug) {
             unsigned long long z[8] = {};
             TDX_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_ad8_dbg), z, sizeof(z)));
-            hipLaunchKernelGGL(ad8_tile_local_kernel<true>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
+            hipLaunchKernelGGL((ad8_tile_local_kernel<true, true>), dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
             TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
             TDX_HIP_CHECK(ctx, hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ad8_dbg), sizeof(z)));
             fprintf(stderr, "ad8_tile_local: cycles per tile: stage %.0f, topology %.0f, targets %.0f, Kahn walks %.0f, entry walks %.0f, write-back %.0f\n",
                     double(z[0]) / double(ntiles), double(z[1]) / double(ntiles) , 0.0, double(z[2]) / double(ntiles), double(z[3]) / double(ntiles), double(z[4]) / double(ntiles));
-        } else
-            hipLaunchKernelGGL(ad8_tile_local_kernel<false>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
+        } else if (getenv("TDX_AD8_KAHN_NESTED"))   // (A/B hook, read per call: the walk loop nested in the loop over a lane's sources)
+            hipLaunchKernelGGL((ad8_tile_local_kernel<false, false>), dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
+        else
+            hipLaunchKernelGGL((ad8_tile_local_kernel<false, true>), dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, node_next);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     int64_t outer = 1;
@@ -1244,13 +1323,16 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         uint32_t *keys_sorted = keys + nb1, *sorted = keys_sorted + nb1, *rootA = sorted + nb1, *rootB = rootA + nb1, *grouped = rootB + nb1, *listB = grouped + nb1,
                  *segbeg = listB + nb1;
         uint32_t* pos = cellw;   // list position of every big cell (the per-cell words are no longer needed once the keys are out)
-        static const bool no_trees = getenv("TDX_AD8_BIG_ONE_WAVE") != nullptr;            // (A/B hook: one wave folds the whole list in count order)
+        const bool no_trees = getenv("TDX_AD8_BIG_ONE_WAVE") != nullptr;                   // (A/B hook, read per call: one wave folds the whole list in count order)
         // default: count order, one wave per tree.  TDX_AD8_BIG_LEVELS=1 (A/B hook): LEVEL order (distance to the tree's root, farthest first: no serial step
         // inside a chunk; ad8_big_fold_levels_kernel) - bit-identical, measured 3 - 5 x SLOWER: a level step is a chain of dependent LDS round trips
         // (~0.5 us) where the count-order fold hands a value on in registers (0.12 us per cell), and main stems are chains (docs/experiments_r05.md)
         static const bool by_levels = getenv("TDX_AD8_BIG_LEVELS") != nullptr;
         const bool levels = !no_trees && by_levels && nbig < (1ull << 22);   // (a record refers to a list position in 22 bits)
         static const bool no_incremental = getenv("TDX_AD8_BIG_FULL_ROUNDS") != nullptr;   // (A/B hook: every outer round on the whole list)
+        // in-chunk dependencies of the count-order fold by pointer jumping when at least this many cells of a 64-entry chunk wait for another cell of the chunk
+        // (TDX_AD8_BIG_SCAN=0: always one after the other - A/B hook; read per call)
+        const int big_scan = getenv("TDX_AD8_BIG_SCAN") ? std::max(0, atoi(getenv("TDX_AD8_BIG_SCAN"))) : 4;
         uint32_t *cur = sorted, *cur_root = rootA, *other = listB, *other_root = rootB;
         unsigned long long* n_cur = d_cnt;            // the apply pass's counter = the first list's length
         const unsigned gb = tdx_blocks_for(nb1, 256);
@@ -1310,11 +1392,11 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
                 hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, cur, n_cur, pos, d_ad8, big_vals,
                                    big_deps, big_flags, big_val);
                 if (no_trees)
-                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, cur, n_cur, static_cast<const uint32_t*>(nullptr),
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, big_scan, cur, n_cur, static_cast<const uint32_t*>(nullptr),
                                        static_cast<const unsigned long long*>(nullptr), big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
                 else {
                     hipLaunchKernelGGL(ad8_big_segments_kernel, dim3(1), dim3(1024), 0, s, cur_root, n_cur, segbeg, d_cnt + 6);
-                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, cur,
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, big_scan, cur,
                                        n_cur, segbeg, d_cnt + 6, big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
                 }
                 }

@@ -244,6 +244,29 @@ def test_aread8_tiles_quirks(ctx, oracle):
         assert bits_equal(a, a_o), describe_diff(a, a_o, f"quirks contcheck={cc}")
 
 
+def test_aread8_kahn_schedules_agree(ctx, oracle, monkeypatch):
+    """The in-tile Kahn walk of ad8_tile_local_kernel as ONE loop per lane (default) and as a walk loop nested in the loop over the lane's sources
+    (TDX_AD8_KAHN_NESTED=1): the same counts - the schedule is free (src/aread8.cpp:220-304) -, incl. the p == 0 quirk, holes and a cycle."""
+    rng = np.random.default_rng(5)
+    p = _p_field(oracle, (700, 900), 21).copy()
+    idx = rng.integers(5, 690, size=(30, 2))
+    for y, x in idx[:12]:
+        p[y, x] = 0
+    for y, x in idx[12:24]:
+        p[y, x] = -32768
+    y, x = idx[24]
+    p[y, x] = 1; p[y, x + 1] = 5
+    for cc in (True, False):
+        a_o = oracle.aread8(p, -32768, contcheck=cc)
+        for nested in (False, True):
+            if nested:
+                monkeypatch.setenv("TDX_AD8_KAHN_NESTED", "1")
+            a = ctx.aread8(p, -32768, contcheck=cc)
+            if nested:
+                monkeypatch.delenv("TDX_AD8_KAHN_NESTED")
+            assert bits_equal(a, a_o), describe_diff(a, a_o, f"kahn nested={nested} contcheck={cc}")
+
+
 @pytest.mark.slow
 def test_aread8_above_2_24_rounds_like_the_reference(ctx, oracle):
     """A comb-shaped direction field on 4200 x 4200 cells: every row drains east into the last interior
@@ -297,6 +320,41 @@ def _comb_check(ctx, n, oracle=None):
 
 def test_comb_analytic_matches_oracle(ctx, oracle):
     assert _comb_check(ctx, 4200, oracle) > 2 ** 24
+
+
+def _trunks_field(rows, lens):
+    """Teeth that flow east into several trunks (south); the trunks end in the bottom interior row, which flows east and collects them one after the other."""
+    nx = 1 + sum(lens) + 1
+    p = np.full((rows, nx), 1, dtype=np.int16)
+    x = 0
+    for length in lens:
+        x += length
+        p[:, x] = 7
+    p[rows - 2, :] = 1
+    p[0, :] = -32768; p[rows - 1, :] = -32768; p[:, 0] = -32768; p[:, nx - 1] = -32768
+    return p
+
+
+@pytest.mark.slow
+def test_aread8_interleaved_trunks_above_2_24(ctx, oracle, monkeypatch):
+    """Three trunks of slightly different tooth lengths pass 2^24 side by side and join in the bottom row (3000 x 18006 cells, 12 621 of them above 2^24,
+    up to 5.4e7: two powers of two are crossed): in count order the trunks' cells INTERLEAVE, so a 64-entry chunk of the big-cell fold holds several chains
+    whose float32 additions round (odd addends at ulp 2 and 4: ties) - what the in-binade scan of ad8_big_fold_kernel resolves by pointer jumping.  The scan,
+    the cell-after-cell loop it replaces (TDX_AD8_BIG_SCAN=0) and the one-wave fold of the whole list must all give the restatement's bits
+    (src/aread8.cpp:231-256)."""
+    p = _trunks_field(3000, (5990, 6003, 6011))
+    a_o = oracle.aread8(p, -32768, contcheck=False)
+    assert int((a_o > 2 ** 24).sum()) > 12000 and a_o.max() > 2 ** 25
+    for env in ({}, {"TDX_AD8_BIG_SCAN": "0"}, {"TDX_AD8_BIG_SCAN": "1"}, {"TDX_AD8_BIG_ONE_WAVE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = ctx.aread8(p, -32768, contcheck=False)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert bits_equal(a, a_o), describe_diff(a, a_o, f"interleaved trunks {env}")
+    a_c = oracle.aread8(p, -32768, contcheck=True)
+    a = ctx.aread8(p, -32768, contcheck=True)
+    assert bits_equal(a, a_c), describe_diff(a, a_c, "interleaved trunks with contamination")
 
 
 @pytest.mark.slow
