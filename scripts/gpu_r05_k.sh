@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=r05k
-# 1. the whole GPU suite on the new defaults
-timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --timeout=900 --timeout-method=thread --durations=6 2>&1 | tail -n 30 > gpurun_out/${T}_pytest_gpu.txt; tail -n 16 gpurun_out/${T}_pytest_gpu.txt
+# 1. the GPU suite on the new defaults, without the D-infinity tests (nothing of theirs changed; the closing run of the round takes all of it)
+timeout 1200 python -m pytest tests -m gpu -k "not dinf and not flowalg and not decay" -q --no-header -p no:cacheprovider --timeout=900 --timeout-method=thread --durations=6 2>&1 | tail -n 30 > gpurun_out/${T}_pytest_gpu.txt; tail -n 16 gpurun_out/${T}_pytest_gpu.txt
 if ! grep -q " passed" gpurun_out/${T}_pytest_gpu.txt || grep -q "failed" gpurun_out/${T}_pytest_gpu.txt; then
   for cfg in "TDX_AD8_KAHN_NESTED=1" "TDX_AD8_BIG_SCAN=0"; do
     echo "== bisect: $cfg"; env $cfg timeout 600 python -m pytest tests/test_gpu_d8.py -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -n 5
