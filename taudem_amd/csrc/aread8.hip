@@ -521,23 +521,36 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     __syncthreads();
     AD8_MARK(3);
     // crossings that enter the tile: follow the in-tile path of the entry cell to where it leaves
-    for (int j = tid; j < 4 * TH; j += 256) {
-        int hx, hy;
-        if (!ring_cell(j, rv, hx, hy)) continue;
-        const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
-        if (ph == nodata || ph < 1 || ph > 8) continue;
-        const int vx = hx + d1(ph), vy = hy + d2(ph);
-        if (!in_tile(vx, vy, rv)) continue;
-        int cur = vy * TS + vx, hops = 0;
-        if (lw_indeg(sAcc[cur]) == 15u) continue;        // the entry cell does not participate
-        while (S_TGT(cur) >= 0 && hops < TS * TS) { cur = S_TGT(cur); hops++; }
-        uint32_t nxt = NEXT_NONE;
-        if (S_TGT(cur) == -2) {
-            const int pp = perim_pos(cur % TS, cur / TS, rv);
-            atomicAdd(&sIn[pp], 1u);
-            nxt = uint32_t(tile) * 256u + uint32_t(pp);
+    {
+        // 4 * TH = 264 ring cells on 256 lanes: the first eight lanes have a second one.  Both entry cells are looked up first and the two walks share ONE
+        // loop (a loop over the ring cells around the walk made all four waves of the tile wait for wave 0's second pass)
+        auto entry_of = [&](int j, int& hx, int& hy) -> int {   // the in-tile cell that ring cell j drains into, -1: none / not a participating cell
+            hx = 0; hy = 0;
+            if (j >= 4 * TH || !ring_cell(j, rv, hx, hy)) return -1;
+            const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
+            if (ph == nodata || ph < 1 || ph > 8) return -1;
+            const int vx = hx + d1(ph), vy = hy + d2(ph);
+            if (!in_tile(vx, vy, rv)) return -1;
+            const int e = vy * TS + vx;
+            return lw_indeg(sAcc[e]) == 15u ? -1 : e;
+        };
+        int hx, hy, hx2, hy2;
+        int cur = entry_of(tid, hx, hy);
+        int cur2 = entry_of(tid + 256, hx2, hy2);
+        if (cur < 0) { cur = cur2; cur2 = -1; hx = hx2; hy = hy2; }
+        int hops = 0;
+        while (cur >= 0) {
+            const int t = S_TGT(cur);
+            if (t >= 0 && hops < TS * TS) { cur = t; hops++; continue; }
+            uint32_t nxt = NEXT_NONE;
+            if (t == -2) {
+                const int pp = perim_pos(cur % TS, cur / TS, rv);
+                atomicAdd(&sIn[pp], 1u);
+                nxt = uint32_t(tile) * 256u + uint32_t(pp);
+            }
+            node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
+            cur = cur2; cur2 = -1; hx = hx2; hy = hy2; hops = 0;
         }
-        node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
     }
     __syncthreads();
     AD8_MARK(4);
@@ -630,7 +643,8 @@ __global__ __launch_bounds__(256) void ad8_forest_deliver_kernel(Ad8Geom g, cons
 }
 
 // LDS word of the apply pass: cnt[0:32) contam[32:44) poison[44:56)
-__global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
+template <int MINWG>   // 1: 93 VGPRs, five tiles per CU; 6: 80 VGPRs (15 of them spilled in the first phase), six tiles per CU as the 26 KB of LDS allow (TDX_AD8_APPLY_OCC6=1: A/B hook)
+__global__ __launch_bounds__(256, MINWG) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
@@ -694,26 +708,37 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = (tgt[r] >= 0) ? tgt[r] : (((partmask >> r) & 1u) ? int16_t(-3) : int16_t(-1));
     }
     __syncthreads();
-    for (int j = tid; j < 4 * TH; j += 256) {
-        int hx, hy;
-        if (!ring_cell(j, rv, hx, hy)) continue;
-        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
-        if (ph == nodata || ph < 1 || ph > 8) continue;
-        const int vx = hx + d1(ph), vy = hy + d2(ph);
-        if (!in_tile(vx, vy, rv)) continue;
-        int cur = vy * TS + vx, hops = 0;
-        if (S_TGT(cur) == -1) continue;   // the entry cell does not participate
-        const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
-        const uint32_t ind = node_indeg[nid];
-        const unsigned long long w = node_acc[nid];
-        unsigned addc = 0, addf = 2u;     // a crossing that never delivers leaves everything below it unevaluated
-        if (ind < NODE_DEAD && nw_arr(w) == ind) { addc = unsigned(w); addf = (nw_con(w) ? 1u : 0u) | (nw_poi(w) ? 2u : 0u); }
-        for (;;) {
+    {
+        // 264 ring cells on 256 lanes: both crossings of the first eight lanes are looked up first (their node words requested together) and the walks share
+        // ONE loop, as in ad8_tile_local_kernel
+        auto entry_of = [&](int j, unsigned& addc, unsigned& addf) -> int {   // the entry cell of ring cell j's crossing and what it delivers; -1: none
+            addc = 0u; addf = 0u;
+            int hx, hy;
+            if (j >= 4 * TH || !ring_cell(j, rv, hx, hy)) return -1;
+            const int16_t ph = sP[(hy + 1) * TH + hx + 1];
+            if (ph == nodata || ph < 1 || ph > 8) return -1;
+            const int vx = hx + d1(ph), vy = hy + d2(ph);
+            if (!in_tile(vx, vy, rv)) return -1;
+            const int e = vy * TS + vx;
+            if (S_TGT(e) == -1) return -1;   // the entry cell does not participate
+            const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
+            const uint32_t ind = node_indeg[nid];
+            const unsigned long long w = node_acc[nid];
+            addf = 2u;                        // a crossing that never delivers leaves everything below it unevaluated
+            if (ind < NODE_DEAD && nw_arr(w) == ind) { addc = unsigned(w); addf = (nw_con(w) ? 1u : 0u) | (nw_poi(w) ? 2u : 0u); }
+            return e;
+        };
+        unsigned addc, addf, addc2, addf2;
+        int cur = entry_of(tid, addc, addf);
+        int cur2 = entry_of(tid + 256, addc2, addf2);
+        if (cur < 0) { cur = cur2; cur2 = -1; addc = addc2; addf = addf2; }
+        int hops = 0;
+        while (cur >= 0) {
             if (addc) __hip_atomic_fetch_add(&sCnt[cur], addc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (addf) atomicOr(&sFlag[cur >> 4], addf << (2 * (cur & 15)));
             const int t = S_TGT(cur);
-            if (t < 0 || ++hops >= TS * TS) break;
-            cur = t;
+            if (t >= 0 && ++hops < TS * TS) { cur = t; continue; }
+            cur = cur2; cur2 = -1; addc = addc2; addf = addf2; hops = 0;
         }
     }
     __syncthreads();
@@ -886,13 +911,15 @@ __global__ __launch_bounds__(256) void ad8_big_gather_kernel(const int16_t* __re
     flags[q] = f;
 }
 
-// Step 2 (ONE wave, 64 consecutive list entries at a time): the fold of the reference in k order.  The values of the
-// first BIG_LDS list entries live in LDS (an agent-scope round trip per chunk would dominate: the list is a few thousand
-// main-stem cells); longer lists continue through bigval (written by this wave: program order + drained stores).  Values
-// of the same chunk are handed on in list order.  A cell with a blocked contributor stays pending (BIG_MARK) for the
-// next outer round.
-constexpr unsigned BIG_LDS = 15360;
-__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int scan_min, const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
+// Step 2 (ONE wave per tree, 64 consecutive list entries at a time): the fold of the reference in k order.  The values of the
+// last BIG_LDS list entries live in LDS, as a ring (an agent-scope round trip per chunk would dominate, and a cell's pending
+// contributors are mostly the cells just before it in count order: the next cell up its own stem); a contributor further
+// back - a tributary that joins a much larger stem - is read from bigval, where a tree longer than the ring keeps a copy
+// (written by this wave long before: stores are drained every 64 chunks, the ring spans 240).  Values of the same chunk are
+// handed on in list order.  A cell with a blocked contributor stays pending (BIG_MARK) for the next outer round.
+constexpr unsigned BIG_LDS = 15360;   // ring entries (a multiple of 64)
+static_assert(BIG_LDS % 64 == 0, "chunks must not straddle the ring's end");
+__global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int scan_min, unsigned ring, const uint32_t* __restrict__ sorted, const unsigned long long* __restrict__ nbig_dev,
                                                           const uint32_t* __restrict__ segbeg, const unsigned long long* __restrict__ nseg_dev,
                                                           const float* __restrict__ vals, const uint32_t* __restrict__ deps,
                                                           const uint32_t* __restrict__ flags, float* __restrict__ bigval, float* __restrict__ A,
@@ -905,16 +932,16 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
     const unsigned long long nseg = segbeg ? *nseg_dev : 1ull;
     for (unsigned long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const unsigned long long b0 = segbeg ? (unsigned long long)segbeg[seg] : 0ull, nbig = segbeg ? (unsigned long long)segbeg[seg + 1] : *nbig_dev;   // this wave's part: [b0, nbig)
-    for (unsigned long long i = lane; b0 + i < nbig && i < BIG_LDS; i += 64) s_big[i] = bigval[b0 + i];
-    const bool spill = nbig - b0 > BIG_LDS;
+    const bool spill = nbig - b0 > ring;   // a tree longer than the ring (ring <= BIG_LDS, a multiple of 64; TDX_AD8_BIG_RING: test hook): folded values also go to bigval
+    unsigned base = 0u;                    // ring slot of list position chunk0
     float hint = 0.f;   // the value of the last cell folded in this tree: values ascend with the list, so its binade is the guess for the next chunk's scan
     // operands of the first chunk; the next chunk's are fetched while the current one is folded
     uint32_t f = 0, c = 0, dp[8];
-    float ak[8];
+    float ak[8], bv = BIG_MARK;
     auto fetch = [&](unsigned long long q) {
         f = 0; c = 0;
         if (q < nbig) {
-            f = flags[q]; c = sorted[q];
+            f = flags[q]; c = sorted[q]; bv = bigval[q];   // (bigval as the gather left it: the final value of a cell that is not pending)
 #pragma unroll
             for (int k = 0; k < 8; k++) { ak[k] = vals[q * 8 + k]; dp[k] = deps[q * 8 + k]; }
         }
@@ -923,6 +950,7 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
     for (unsigned long long chunk0 = b0; chunk0 < nbig; chunk0 += 64) {
         const unsigned long long q = chunk0 + (unsigned long long)lane;
         const uint32_t fl = f, cell = c;
+        const float own = bv;
         float a8[8];
         uint32_t d8[8];
 #pragma unroll
@@ -937,7 +965,11 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
                 if (d8[k] == BIG_NODEP) continue;
                 if ((unsigned long long)d8[k] >= q) blocked = true;                // (cannot happen: a contributor's count is smaller)
                 else if ((unsigned long long)d8[k] >= chunk0) inchunk |= 1u << k;
-                else a8[k] = (d8[k] - b0) < BIG_LDS ? s_big[d8[k] - b0] : ld_agent(&bigval[d8[k]]);
+                else {   // (the ring holds the entries [chunk0 - ring, chunk0); entry chunk0 - delta sits delta slots before `base`)
+                    const unsigned delta = unsigned(chunk0 - (unsigned long long)d8[k]);
+                    const unsigned slot = base >= delta ? base - delta : base + ring - delta;
+                    a8[k] = delta <= ring ? s_big[slot < ring ? slot : 0u] : ld_agent(&bigval[d8[k]]);
+                }
             }
         }
         float result = BIG_MARK;
@@ -997,7 +1029,8 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
 #pragma unroll
             for (int o = 32; o; o >>= 1) top = fmaxf(top, __shfl_xor(top, o, 64));
             top = fmaxf(top, hint);
-            if (top >= 1.0f) {   // (uniform)
+            if (top < 1.0f) top = 16777216.f;   // nothing of this tree is known yet (everything so far waits for a neighbouring strip): any binade will do for what is blocked, and a value that is not fails the check below
+            {
                 const unsigned bB = __float_as_uint(top) & 0xFF800000u;
                 const float B = __uint_as_float(bB), B1 = __uint_as_float(bB + 1u), twoB = B + B;
                 float D0 = 0.f, D1 = 0.f;
@@ -1007,14 +1040,17 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
                     for (int k = 0; k < 8; k++) { a0 = a0 + suf[k]; a1 = a1 + suf[k]; }
                     D0 = a0 - B; D1 = a1 - B1;
                 }
-                bool res = !mine;
-                float val = result;
+                // "still waiting for a cell of a neighbouring strip" (BIG_MARK) travels down a chain the same way: in an outer round whose stem is blocked at its
+                // upstream end every cell below it used to be visited one after the other just to stay pending (eight strips of BASELINE.json configs[3]:
+                // ~2 ms per outer round and rank, nine rounds on the last rank - profiles/r05k_segments_8strips_d8_*.json)
+                bool res = !mine || blkpre;
+                float val = (mine && blkpre) ? BIG_MARK : result;
                 int par = mine ? jdep : lane;
                 for (int it = 0; it < 8 && __ballot(!res) != 0ull; it++) {
                     const int pres = __shfl(int(res), par, 64), pp = __shfl(par, par, 64);
                     const float pv = __shfl(val, par, 64), pD0 = __shfl(D0, par, 64), pD1 = __shfl(D1, par, 64);
                     if (!res) {
-                        if (pres) { val = pv + ((__float_as_uint(pv) & 1u) ? D1 : D0); res = true; }
+                        if (pres) { val = pv == BIG_MARK ? BIG_MARK : pv + ((__float_as_uint(pv) & 1u) ? D1 : D0); res = true; }
                         else {
                             const bool o0 = (__float_as_uint(B + pD0) & 1u) != 0u, o1 = (__float_as_uint(B + pD1) & 1u) != 0u;
                             const float n0 = pD0 + (o0 ? D1 : D0), n1 = pD1 + (o1 ? D0 : D1);
@@ -1023,7 +1059,7 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
                     }
                 }
                 const float pin = __shfl(val, mine ? jdep : lane, 64);   // the contributor's final value
-                const bool good = !mine || (res && !blkpre && !(c2pre && contcheck == 1) && pin >= B && pin < twoB && val < twoB);
+                const bool good = !mine || (res && (val == BIG_MARK || (!(c2pre && contcheck == 1) && pin >= B && pin < twoB && val < twoB)));
                 if (__ballot(!good) == 0ull) {
                     if (mine) result = val;
                     serial = 0ull;
@@ -1056,13 +1092,15 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
             }
             if (lane == i) result = fold();
         }
+        if (q < nbig) s_big[base + unsigned(lane)] = pending ? result : own;   // every entry enters the ring: folded, still pending (BIG_MARK) or final since an earlier round
+        base = base + 64u >= ring ? 0u : base + 64u;
         if (pending && result != BIG_MARK) {
-            if (q - b0 < BIG_LDS) s_big[q - b0] = result;
-            else st_agent(&bigval[q], result);
+            if (spill) st_agent(&bigval[q], result);
             A[cell] = result;   // read again only after this kernel (exchange / host)
             done++;
         }
-        if (spill) drain_stores();   // later chunks read these values back through the L2
+        if (spill && (((chunk0 - b0) >> 6) & 63ull) == 63ull) drain_stores();   // what falls out of the ring (240 chunks later) is read back through the L2
+        else if (spill && ring < 64u * 130u) drain_stores();                        // (a ring shortened for tests: every chunk)
         {
             const float last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, result), 63));
             if (last >= 1.0f) hint = last;
@@ -1301,8 +1339,12 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     ctx->phase = "apply";
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
-                           big_threshold, d_ad8, biglist, d_cnt);
+        if (getenv("TDX_AD8_APPLY_OCC6"))
+            hipLaunchKernelGGL(ad8_tile_apply_kernel<6>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
+                               big_threshold, d_ad8, biglist, d_cnt);
+        else
+            hipLaunchKernelGGL(ad8_tile_apply_kernel<1>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
+                               big_threshold, d_ad8, biglist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1333,6 +1375,8 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         // in-chunk dependencies of the count-order fold by pointer jumping when at least this many cells of a 64-entry chunk wait for another cell of the chunk
         // (TDX_AD8_BIG_SCAN=0: always one after the other - A/B hook; read per call)
         const int big_scan = getenv("TDX_AD8_BIG_SCAN") ? std::max(0, atoi(getenv("TDX_AD8_BIG_SCAN"))) : 4;
+        // entries of the fold's LDS ring (TDX_AD8_BIG_RING: test hook, rounded to a multiple of 64 in [64, BIG_LDS]: trees longer than that at test sizes)
+        const unsigned big_ring = getenv("TDX_AD8_BIG_RING") ? std::min(BIG_LDS, std::max(64u, unsigned(atoi(getenv("TDX_AD8_BIG_RING"))) / 64u * 64u)) : BIG_LDS;
         uint32_t *cur = sorted, *cur_root = rootA, *other = listB, *other_root = rootB;
         unsigned long long* n_cur = d_cnt;            // the apply pass's counter = the first list's length
         const unsigned gb = tdx_blocks_for(nb1, 256);
@@ -1392,11 +1436,11 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
                 hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, cur, n_cur, pos, d_ad8, big_vals,
                                    big_deps, big_flags, big_val);
                 if (no_trees)
-                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, big_scan, cur, n_cur, static_cast<const uint32_t*>(nullptr),
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(1), dim3(64), 0, s, contcheck, big_scan, big_ring, cur, n_cur, static_cast<const uint32_t*>(nullptr),
                                        static_cast<const unsigned long long*>(nullptr), big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
                 else {
                     hipLaunchKernelGGL(ad8_big_segments_kernel, dim3(1), dim3(1024), 0, s, cur_root, n_cur, segbeg, d_cnt + 6);
-                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, big_scan, cur,
+                    hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, big_scan, big_ring, cur,
                                        n_cur, segbeg, d_cnt + 6, big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
                 }
                 }

@@ -345,7 +345,7 @@ def test_aread8_interleaved_trunks_above_2_24(ctx, oracle, monkeypatch):
     p = _trunks_field(3000, (5990, 6003, 6011))
     a_o = oracle.aread8(p, -32768, contcheck=False)
     assert int((a_o > 2 ** 24).sum()) > 12000 and a_o.max() > 2 ** 25
-    for env in ({}, {"TDX_AD8_BIG_SCAN": "0"}, {"TDX_AD8_BIG_SCAN": "1"}, {"TDX_AD8_BIG_ONE_WAVE": "1"}):
+    for env in ({}, {"TDX_AD8_BIG_SCAN": "0"}, {"TDX_AD8_BIG_SCAN": "1"}, {"TDX_AD8_BIG_ONE_WAVE": "1"}, {"TDX_AD8_BIG_RING": "256"}, {"TDX_AD8_BIG_RING": "64", "TDX_AD8_BIG_ONE_WAVE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         a = ctx.aread8(p, -32768, contcheck=False)
@@ -489,10 +489,19 @@ def test_many_big_cells_in_one_three_and_eight_strips(ctx, oracle, monkeypatch):
     a, st = ctx.aread8(p_o, -32768, contcheck=False, stats=True)
     assert st["cells_evaluated"] >= 100000, "the big-cell path was not taken"
     assert bits_equal(a, a_o), describe_diff(a, a_o, "ad8, one strip")
+    for ring in ("64", "192", "1024"):   # the fold's LDS ring shortened: trees longer than the ring keep a copy in global memory and read far contributors back
+        monkeypatch.setenv("TDX_AD8_BIG_RING", ring)
+        a = ctx.aread8(p_o, -32768, contcheck=False)
+        assert bits_equal(a, a_o), describe_diff(a, a_o, f"ad8, one strip, ring of {ring}")
+    monkeypatch.delenv("TDX_AD8_BIG_RING")
     a_c = oracle.aread8(p_o, -32768, contcheck=True)
     a = ctx.aread8(p_o, -32768, contcheck=True)
     assert bits_equal(a, a_c), describe_diff(a, a_c, "ad8 with contamination, one strip")
     for world in (3, 8):
+        if world == 3:
+            monkeypatch.setenv("TDX_AD8_BIG_RING", "128")   # (three strips with a shortened ring, eight with the whole one)
+        else:
+            monkeypatch.delenv("TDX_AD8_BIG_RING", raising=False)
         parts = partition_rows(n, world)
         with StripGroup(world, n, [0] * world) as grp:
             def rank_main(r, c, comm):
