@@ -521,36 +521,23 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     __syncthreads();
     AD8_MARK(3);
     // crossings that enter the tile: follow the in-tile path of the entry cell to where it leaves
-    {
-        // 4 * TH = 264 ring cells on 256 lanes: the first eight lanes have a second one.  Both entry cells are looked up first and the two walks share ONE
-        // loop (a loop over the ring cells around the walk made all four waves of the tile wait for wave 0's second pass)
-        auto entry_of = [&](int j, int& hx, int& hy) -> int {   // the in-tile cell that ring cell j drains into, -1: none / not a participating cell
-            hx = 0; hy = 0;
-            if (j >= 4 * TH || !ring_cell(j, rv, hx, hy)) return -1;
-            const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
-            if (ph == nodata || ph < 1 || ph > 8) return -1;
-            const int vx = hx + d1(ph), vy = hy + d2(ph);
-            if (!in_tile(vx, vy, rv)) return -1;
-            const int e = vy * TS + vx;
-            return lw_indeg(sAcc[e]) == 15u ? -1 : e;
-        };
-        int hx, hy, hx2, hy2;
-        int cur = entry_of(tid, hx, hy);
-        int cur2 = entry_of(tid + 256, hx2, hy2);
-        if (cur < 0) { cur = cur2; cur2 = -1; hx = hx2; hy = hy2; }
-        int hops = 0;
-        while (cur >= 0) {
-            const int t = S_TGT(cur);
-            if (t >= 0 && hops < TS * TS) { cur = t; hops++; continue; }
-            uint32_t nxt = NEXT_NONE;
-            if (t == -2) {
-                const int pp = perim_pos(cur % TS, cur / TS, rv);
-                atomicAdd(&sIn[pp], 1u);
-                nxt = uint32_t(tile) * 256u + uint32_t(pp);
-            }
-            node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
-            cur = cur2; cur2 = -1; hx = hx2; hy = hy2; hops = 0;
+    for (int j = tid; j < 4 * TH; j += 256) {
+        int hx, hy;
+        if (!ring_cell(j, rv, hx, hy)) continue;
+        const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
+        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const int vx = hx + d1(ph), vy = hy + d2(ph);
+        if (!in_tile(vx, vy, rv)) continue;
+        int cur = vy * TS + vx, hops = 0;
+        if (lw_indeg(sAcc[cur]) == 15u) continue;        // the entry cell does not participate
+        while (S_TGT(cur) >= 0 && hops < TS * TS) { cur = S_TGT(cur); hops++; }
+        uint32_t nxt = NEXT_NONE;
+        if (S_TGT(cur) == -2) {
+            const int pp = perim_pos(cur % TS, cur / TS, rv);
+            atomicAdd(&sIn[pp], 1u);
+            nxt = uint32_t(tile) * 256u + uint32_t(pp);
         }
+        node_next[node_id(g, x0 + hx, ya0 + hy)] = nxt;
     }
     __syncthreads();
     AD8_MARK(4);
@@ -643,8 +630,8 @@ __global__ __launch_bounds__(256) void ad8_forest_deliver_kernel(Ad8Geom g, cons
 }
 
 // LDS word of the apply pass: cnt[0:32) contam[32:44) poison[44:56)
-template <int MINWG>   // 1: 93 VGPRs, five tiles per CU; 6: 80 VGPRs (15 of them spilled in the first phase), six tiles per CU as the 26 KB of LDS allow (TDX_AD8_APPLY_OCC6=1: A/B hook)
-__global__ __launch_bounds__(256, MINWG) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
+// (93 VGPRs: five tiles per CU.  Held to 80 - six tiles, as the LDS allows - it spills 15 registers in the first phase and is 13 % slower: profiles/r05l_*)
+__global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __restrict__ P, Ad8Geom g, int16_t nodata,
                                                              uint32_t* __restrict__ cellw, const unsigned long long* __restrict__ node_acc,
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
@@ -708,37 +695,26 @@ __global__ __launch_bounds__(256, MINWG) void ad8_tile_apply_kernel(const int16_
         if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = (tgt[r] >= 0) ? tgt[r] : (((partmask >> r) & 1u) ? int16_t(-3) : int16_t(-1));
     }
     __syncthreads();
-    {
-        // 264 ring cells on 256 lanes: both crossings of the first eight lanes are looked up first (their node words requested together) and the walks share
-        // ONE loop, as in ad8_tile_local_kernel
-        auto entry_of = [&](int j, unsigned& addc, unsigned& addf) -> int {   // the entry cell of ring cell j's crossing and what it delivers; -1: none
-            addc = 0u; addf = 0u;
-            int hx, hy;
-            if (j >= 4 * TH || !ring_cell(j, rv, hx, hy)) return -1;
-            const int16_t ph = sP[(hy + 1) * TH + hx + 1];
-            if (ph == nodata || ph < 1 || ph > 8) return -1;
-            const int vx = hx + d1(ph), vy = hy + d2(ph);
-            if (!in_tile(vx, vy, rv)) return -1;
-            const int e = vy * TS + vx;
-            if (S_TGT(e) == -1) return -1;   // the entry cell does not participate
-            const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
-            const uint32_t ind = node_indeg[nid];
-            const unsigned long long w = node_acc[nid];
-            addf = 2u;                        // a crossing that never delivers leaves everything below it unevaluated
-            if (ind < NODE_DEAD && nw_arr(w) == ind) { addc = unsigned(w); addf = (nw_con(w) ? 1u : 0u) | (nw_poi(w) ? 2u : 0u); }
-            return e;
-        };
-        unsigned addc, addf, addc2, addf2;
-        int cur = entry_of(tid, addc, addf);
-        int cur2 = entry_of(tid + 256, addc2, addf2);
-        if (cur < 0) { cur = cur2; cur2 = -1; addc = addc2; addf = addf2; }
-        int hops = 0;
-        while (cur >= 0) {
+    for (int j = tid; j < 4 * TH; j += 256) {
+        int hx, hy;
+        if (!ring_cell(j, rv, hx, hy)) continue;
+        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
+        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const int vx = hx + d1(ph), vy = hy + d2(ph);
+        if (!in_tile(vx, vy, rv)) continue;
+        int cur = vy * TS + vx, hops = 0;
+        if (S_TGT(cur) == -1) continue;   // the entry cell does not participate
+        const uint32_t nid = node_id(g, x0 + hx, ya0 + hy);
+        const uint32_t ind = node_indeg[nid];
+        const unsigned long long w = node_acc[nid];
+        unsigned addc = 0, addf = 2u;     // a crossing that never delivers leaves everything below it unevaluated
+        if (ind < NODE_DEAD && nw_arr(w) == ind) { addc = unsigned(w); addf = (nw_con(w) ? 1u : 0u) | (nw_poi(w) ? 2u : 0u); }
+        for (;;) {
             if (addc) __hip_atomic_fetch_add(&sCnt[cur], addc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (addf) atomicOr(&sFlag[cur >> 4], addf << (2 * (cur & 15)));
             const int t = S_TGT(cur);
-            if (t >= 0 && ++hops < TS * TS) { cur = t; continue; }
-            cur = cur2; cur2 = -1; addc = addc2; addf = addf2; hops = 0;
+            if (t < 0 || ++hops >= TS * TS) break;
+            cur = t;
         }
     }
     __syncthreads();
@@ -1022,7 +998,7 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
         // ((g o f)[p] = f[p] + g[p ^ parity(f[p])], all sums exact: multiples of u below 2B), so the in-chunk dependencies - chains of main-stem cells, several
         // of them interleaved - are resolved by pointer jumping over the wave (<= 6 steps) instead of one cell after the other (~0.12 us each).  B is a guess
         // (values ascend with the list: the binade of the largest value known so far); every scanned cell then checks that its contributor's value and its own
-        // lie in [B, 2B) - if not (a chunk that straddles a power of two, a blocked or contaminated cell) the serial loop below does the chunk as before.
+        // lie in [B, 2B) - if not (a chunk that straddles a power of two, a contaminated cell, two contributors in the chunk) the serial loop below does the chunk as before.
         if (scan_min > 0 && serial != 0ull && (serial & ~singles) == 0ull && __popcll(serial) >= scan_min) {
             const bool mine = ((serial >> lane) & 1ull) != 0ull;
             float top = (!mine && result >= 1.0f) ? result : 0.f;
@@ -1339,12 +1315,8 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     ctx->phase = "apply";
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
-        if (getenv("TDX_AD8_APPLY_OCC6"))
-            hipLaunchKernelGGL(ad8_tile_apply_kernel<6>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
-                               big_threshold, d_ad8, biglist, d_cnt);
-        else
-            hipLaunchKernelGGL(ad8_tile_apply_kernel<1>, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
-                               big_threshold, d_ad8, biglist, d_cnt);
+        hipLaunchKernelGGL(ad8_tile_apply_kernel, dim3(unsigned(ntiles)), dim3(256), 0, s, d_p, g, p_nodata, cellw, node_acc, node_indeg, contcheck,
+                           big_threshold, d_ad8, biglist, d_cnt);
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
