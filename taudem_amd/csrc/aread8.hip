@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict
 // =====================================================================================================
 constexpr int TS = 64;
 constexpr int TH = TS + 2;
+static_assert(TS == 64, "S_TGT() shifts by 6");
 // node_indeg == 0xFFFFFFFF: perimeter / halo cell that is not (yet) a node
 constexpr uint32_t NODE_DEAD = 0xFFFFFFFEu;      // node whose cell never completes (cycle / poisoned): never fires
 constexpr uint32_t NEXT_NONE = 0xFFFFFFFFu;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
         }
     }
     __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
-#define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
+#define S_TGT(c) sP[__umul24(unsigned(c) >> 6, unsigned(TH)) + (unsigned(c) & 63u) + unsigned(TH + 1)]   // (c >= 0; TS = 64: a shift, a mask and one full-rate 24-bit multiply-add - the signed / and % with a 32-bit multiply were a third of a hop's address arithmetic)
 #pragma unroll
     for (int r = 0; r < 16; r++)
         if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = tgt[r];   // row rv is the bottom ring row of a partial tile: keep it
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
             }
             const int tn = S_TGT(t);
             const unsigned nw = __hip_atomic_fetch_add(&sAcc[t], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + add;
-            add = lw_pack(lw_cnt(nw), 1u, lw_con(nw) ? 1u : 0u, lw_poi(nw) ? 1u : 0u, 0u);
+            // what this cell hands on: its count, one arrival, "contaminated" / "not evaluated" as 0 / 1 (min(field, 1 << shift): the fields count contributors)
+            add = (nw & 0x1FFFu) | (1u << 13) | min(nw & (15u << 17), 1u << 17) | min(nw & (15u << 21), 1u << 21);
             t = lw_arr(nw) == lw_indeg(nw) ? tn : -1;   // not the last contributor: someone else will go on from here
         }
     } else {
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
         }
     }
     __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
-#define S_TGT(c) sP[((c) / TS + 1) * TH + ((c) % TS) + 1]
+#define S_TGT(c) sP[__umul24(unsigned(c) >> 6, unsigned(TH)) + (unsigned(c) & 63u) + unsigned(TH + 1)]   // (c >= 0; TS = 64: a shift, a mask and one full-rate 24-bit multiply-add - the signed / and % with a 32-bit multiply were a third of a hop's address arithmetic)
     // entry cells are looked up through the ring directions, which stay in place
 #pragma unroll
     for (int r = 0; r < 16; r++) {
