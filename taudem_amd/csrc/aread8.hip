@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
         // the lane's window of directions in registers (four quarter bands of 4 rows: 3 x 6 unconditional LDS reads each, so that
         // 6 workgroups per CU still fit the register file), then branch-free topology: initNeighborD8up
         // (src/commonLib.cpp:251-282) and the contamination test of src/aread8.cpp:241-242
+        const unsigned colmask = (lx > 0 ? 0xFFu : 0xC7u) & (lx < TS - 1 ? 0xFFu : 0x7Cu);   // neighbours 4 5 6 lie left of the tile's first column, 1 2 8 right of its last
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             int win[3][6];
@@ -442,22 +443,36 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
                 const int pc = (p >= 1 && p <= 8) ? p : 1;
                 ptgt[q] = sP[(ry0 + 4 * h + q + d2(pc) + 1) * TH + lx + d1(pc) + 1];
             }
+            // One-hot form of the window: bit c for a direction code c in 0 .. 8, bit 15 for nodata, nothing for what else the outlets mode writes
+            // (16 + p, 32) or a raster may hold.  "Neighbour k drains into the cell" is then bit opposite(k) of the neighbour's word, the eight tests
+            // one and-or chain per side of the compass, the in-degree a population count under the mask of the neighbours that lie in the tile - instead
+            // of eight compare / select chains on lane masks per cell (~100 vector and 50 scalar instructions per cell row, a fifth of the kernel's
+            // issue slots: the kernel is issue-bound, profiles/r05m_*).
+            unsigned oh[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int v = win[i][j];
+                    const unsigned sel = v == int(nodata) ? 15u : min(unsigned(v), 31u);
+                    oh[i][j] = (1u << sel) & 0x81FFu;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int r = 4 * h + q, ly = ry0 + r;
                 const int p = win[1][q + 1];
-                const bool part = ly < rv && p_part(int16_t(p), nodata);
-                unsigned indeg = 0;
-                bool con = false, poison = false;
-#pragma unroll
-                for (int k = 1; k <= 8; k++) {
-                    const int pn = win[1 + d1(k)][q + 1 + d2(k)];   // (static indices after unrolling)
-                    const bool nod = pn == int(nodata);
-                    const bool drains = !nod && (k <= 4 ? (pn == k + 4 || (k == 4 && pn == 0)) : pn == k - 4);
-                    con |= nod;
-                    poison |= drains && pn == 0;   // k == 4: counted in the in-degree but never decremented (src/aread8.cpp:262)
-                    if (drains && pn != 0 && in_tile(lx + d1(k), ly + d2(k), rv)) indeg++;
-                }
+                const bool part = ly < rv && ((oh[1][q + 1] & 0x1FFu) != 0u || (p == int(P_SINK) && p != int(nodata)));   // p_part()
+                // neighbours 1 .. 8 = E NE N NW W SW S SE (src/commonLib.h:83-84); k <= 4 drains into the cell with code k + 4, k >= 5 with k - 4
+                const unsigned oE = oh[2][q + 1], oNE = oh[2][q], oN = oh[1][q], oNW = oh[0][q], oW = oh[0][q + 1], oSW = oh[0][q + 2], oS = oh[1][q + 2],
+                               oSE = oh[2][q + 2];
+                const unsigned hi = (oE & 0x20u) | (oNE & 0x40u) | (oN & 0x80u) | (oNW & 0x100u);   // codes 5 6 7 8 of neighbours 1 2 3 4
+                const unsigned lo = (oW & 0x2u) | (oSW & 0x4u) | (oS & 0x8u) | (oSE & 0x10u);       // codes 1 2 3 4 of neighbours 5 6 7 8
+                const unsigned drain = (hi >> 5) | (lo << 3);                                        // bit k - 1: neighbour k drains into the cell
+                const unsigned rowmask = (ly > 0 ? 0xFFu : 0xF1u) & (ly + 1 < rv ? 0xFFu : 0x1Fu);  // neighbours 2 3 4 lie above the tile's first row, 6 7 8 below its last
+                const unsigned indeg = unsigned(__popc(drain & colmask & rowmask));
+                const bool con = (((oE | oNE | oN) | (oNW | oW | oSW) | (oS | oSE)) & 0x8000u) != 0u;
+                const bool poison = (oNW & 1u) != 0u;   // k == 4 with p == 0: counted in the in-degree but never decremented (src/commonLib.cpp:257-266, src/aread8.cpp:262)
                 int t = -1;
                 if (part && p >= 1 && p <= 8 && p_part(int16_t(ptgt[q]), nodata)) {
                     const int tlx = lx + d1(p), tly = ly + d2(p);
