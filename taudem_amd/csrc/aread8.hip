@@ -359,6 +359,39 @@ __device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, i
         if (e < TH * TH) sP[e] = ((ok >> i) & 1u) ? v[i] : nodata;
     }
 }
+// One-hot form of a direction code (ad8_tile_local_kernel): bit c for c in 0 .. 8, OH_SINK for the pure sink of the outlets mode, OH_NODATA for nodata and for
+// what lies outside the array, nothing for anything else (16 + p: a cell outside the outlets' closure - it neither takes part nor contributes nor contaminates).
+constexpr unsigned OH_NODATA = 0x8000u, OH_SINK = 0x4000u, OH_DIRS = 0x1FEu, OH_PART = 0x1FFu | OH_SINK;
+__device__ __forceinline__ unsigned p_onehot(int v, int nodata) {
+    const unsigned sel = v == nodata ? 15u : (v == int(P_SINK) ? 14u : min(unsigned(v), 31u));
+    return (1u << sel) & (0x1FFu | OH_SINK | OH_NODATA);
+}
+// stage_p with every cell converted once (each cell is in the 3 x 3 window of nine cells: converted where it is used it cost a quarter of the topology pass)
+__device__ __forceinline__ void stage_p_onehot(const int16_t* __restrict__ P, int nx, int ny_arr, int x0, int ya0, int16_t nodata, uint16_t* sO) {
+    constexpr int NIT = (TH * TH + 255) / 256, HALF = (NIT + 1) / 2;
+    // two batches of loads (a converted value needs a register of its own where two raw int16 shared one: all 17 in flight at once spilled eleven registers;
+    // six tiles per CU hide the second memory latency)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        int16_t v[HALF];
+        unsigned ok = 0;
+#pragma unroll
+        for (int i = 0; i < HALF; i++) {
+            const int e = int(threadIdx.x) + (b * HALF + i) * 256, ec = e < TH * TH ? e : TH * TH - 1;
+            const int ly = ec / TH, lx = ec - ly * TH;
+            const int gx = x0 + lx - 1, gy = ya0 + ly - 1;
+            const int gxc = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= ny_arr ? ny_arr - 1 : gy);
+            v[i] = P[size_t(gyc) * size_t(nx) + size_t(gxc)];
+            if (gx == gxc && gy == gyc) ok |= 1u << i;
+        }
+#pragma unroll
+        for (int i = 0; i < HALF; i++) {
+            const int e = int(threadIdx.x) + (b * HALF + i) * 256;
+            if (b * HALF + i < NIT && e < TH * TH) sO[e] = uint16_t(((ok >> i) & 1u) ? p_onehot(int(v[i]), int(nodata)) : OH_NODATA);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 __device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && ((p >= 0 && p <= 8) || p == P_SINK); }
 __device__ __forceinline__ bool in_tile(int lx, int ly, int rv) { return lx >= 0 && lx < TS && ly >= 0 && ly < rv; }
 
@@ -409,17 +442,25 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     AD8_MARK(0);
     // 26 KB of LDS per tile (6 workgroups per CU): the in-tile targets overwrite the interior of the staged P tile
     // once every lane has derived its topology from it; the ring cells keep their directions for the entry search
-    __shared__ int16_t sP[TH * TH];
+    // (the staged tile holds ONE-HOT direction codes, 66-pitch with the ring; the target table that replaces it is 64-pitch - a hop addresses it and sAcc
+    // with the same cell index, two shifts - so the ring cells' codes are set aside first: sRing, in ring_cell() order)
+    __shared__ uint16_t sO[TH * TH];
     __shared__ unsigned sAcc[TS * TS];
     __shared__ unsigned sIn[256];   // crossings that end at each perimeter cell
+    __shared__ uint16_t sRing[4 * TH];
+    int16_t* const sT = reinterpret_cast<int16_t*>(sO);
     const int tile = blockIdx.x;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, ya0 = g.y0 + ty * TS, rv = rows_valid(g, ty);
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
-    stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
+    stage_p_onehot(P, g.nx, g.ny_arr, x0, ya0, nodata, sO);
     sIn[tid] = 0u;
     __syncthreads();
     AD8_MARK(1);
+    for (int j = tid; j < 4 * TH; j += 256) {
+        int hx, hy;
+        sRing[j] = ring_cell(j, rv, hx, hy) ? sO[(hy + 1) * TH + hx + 1] : uint16_t(0);
+    }
     unsigned src = 0;       // rows of this lane that start a walk
     unsigned exit_up = 0, exit_down = 0;   // rows whose crossing leaves towards the row above / below the cell
     int16_t tgt[16];
@@ -430,39 +471,29 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
         const unsigned colmask = (lx > 0 ? 0xFFu : 0xC7u) & (lx < TS - 1 ? 0xFFu : 0x7Cu);   // neighbours 4 5 6 lie left of the tile's first column, 1 2 8 right of its last
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            int win[3][6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) win[i][j] = sP[(ry0 + 4 * h + j) * TH + lx + i];
-            }
-            int ptgt[4];   // direction of the cell the row drains to (speculative read, address from a clamped direction)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int p = win[1][q + 1];
-                const int pc = (p >= 1 && p <= 8) ? p : 1;
-                ptgt[q] = sP[(ry0 + 4 * h + q + d2(pc) + 1) * TH + lx + d1(pc) + 1];
-            }
-            // One-hot form of the window: bit c for a direction code c in 0 .. 8, bit 15 for nodata, nothing for what else the outlets mode writes
-            // (16 + p, 32) or a raster may hold.  "Neighbour k drains into the cell" is then bit opposite(k) of the neighbour's word, the eight tests
-            // one and-or chain per side of the compass, the in-degree a population count under the mask of the neighbours that lie in the tile - instead
-            // of eight compare / select chains on lane masks per cell (~100 vector and 50 scalar instructions per cell row, a fifth of the kernel's
-            // issue slots: the kernel is issue-bound, profiles/r05m_*).
+            // The window in one-hot form (p_onehot): "neighbour k drains into the cell" is bit opposite(k) of the neighbour's word, the eight tests one
+            // and-or chain per side of the compass, the in-degree a population count under the mask of the neighbours that lie in the tile - instead of
+            // eight compare / select chains on lane masks per cell (~100 vector and 50 scalar instructions per cell row; the kernel is issue-bound:
+            // profiles/r05m_*, r05n_*).
             unsigned oh[3][6];
 #pragma unroll
             for (int j = 0; j < 6; j++) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int v = win[i][j];
-                    const unsigned sel = v == int(nodata) ? 15u : min(unsigned(v), 31u);
-                    oh[i][j] = (1u << sel) & 0x81FFu;
-                }
+                for (int i = 0; i < 3; i++) oh[i][j] = sO[(ry0 + 4 * h + j) * TH + lx + i];
+            }
+            unsigned ohtgt[4];   // code of the cell the row drains to (speculative read, address from a clamped direction)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned dirs = oh[1][q + 1] & OH_DIRS;
+                const int pc = dirs ? __ffs(int(dirs)) - 1 : 1;
+                ohtgt[q] = sO[(ry0 + 4 * h + q + d2(pc) + 1) * TH + lx + d1(pc) + 1];
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int r = 4 * h + q, ly = ry0 + r;
-                const int p = win[1][q + 1];
-                const bool part = ly < rv && ((oh[1][q + 1] & 0x1FFu) != 0u || (p == int(P_SINK) && p != int(nodata)));   // p_part()
+                const unsigned dirs = oh[1][q + 1] & OH_DIRS;
+                const int p = dirs ? __ffs(int(dirs)) - 1 : 0;   // 1 .. 8, or 0: no direction
+                const bool part = ly < rv && (oh[1][q + 1] & OH_PART) != 0u;   // p_part()
                 // neighbours 1 .. 8 = E NE N NW W SW S SE (src/commonLib.h:83-84); k <= 4 drains into the cell with code k + 4, k >= 5 with k - 4
                 const unsigned oE = oh[2][q + 1], oNE = oh[2][q], oN = oh[1][q], oNW = oh[0][q], oW = oh[0][q + 1], oSW = oh[0][q + 2], oS = oh[1][q + 2],
                                oSE = oh[2][q + 2];
@@ -471,10 +502,10 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
                 const unsigned drain = (hi >> 5) | (lo << 3);                                        // bit k - 1: neighbour k drains into the cell
                 const unsigned rowmask = (ly > 0 ? 0xFFu : 0xF1u) & (ly + 1 < rv ? 0xFFu : 0x1Fu);  // neighbours 2 3 4 lie above the tile's first row, 6 7 8 below its last
                 const unsigned indeg = unsigned(__popc(drain & colmask & rowmask));
-                const bool con = (((oE | oNE | oN) | (oNW | oW | oSW) | (oS | oSE)) & 0x8000u) != 0u;
+                const bool con = (((oE | oNE | oN) | (oNW | oW | oSW) | (oS | oSE)) & OH_NODATA) != 0u;
                 const bool poison = (oNW & 1u) != 0u;   // k == 4 with p == 0: counted in the in-degree but never decremented (src/commonLib.cpp:257-266, src/aread8.cpp:262)
                 int t = -1;
-                if (part && p >= 1 && p <= 8 && p_part(int16_t(ptgt[q]), nodata)) {
+                if (part && p >= 1 && (ohtgt[q] & OH_PART) != 0u) {
                     const int tlx = lx + d1(p), tly = ly + d2(p);
                     t = in_tile(tlx, tly, rv) ? tly * TS + tlx : -2;
                     if (t == -2) {
@@ -490,10 +521,10 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
         }
     }
     __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
-#define S_TGT(c) sP[__umul24(unsigned(c) >> 6, unsigned(TH)) + (unsigned(c) & 63u) + unsigned(TH + 1)]   // (c >= 0; TS = 64: a shift, a mask and one full-rate 24-bit multiply-add - the signed / and % with a 32-bit multiply were a third of a hop's address arithmetic)
+#define S_TGT(c) sT[c]
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = tgt[r];   // row rv is the bottom ring row of a partial tile: keep it
+        if (ry0 + r < rv) sT[(ry0 + r) * TS + lx] = tgt[r];
     __syncthreads();
     AD8_MARK(2);
     // Kahn sweep of the in-tile flows: one returning 32-bit LDS atomic per hop; the target of the NEXT hop is read alongside the
@@ -541,8 +572,9 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     for (int j = tid; j < 4 * TH; j += 256) {
         int hx, hy;
         if (!ring_cell(j, rv, hx, hy)) continue;
-        const int16_t ph = sP[(hy + 1) * TH + hx + 1];   // ring cells still hold directions
-        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const unsigned dirs = sRing[j] & OH_DIRS;   // the ring cell's direction, set aside before the table took the tile's place
+        if (!dirs) continue;
+        const int ph = __ffs(int(dirs)) - 1;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
         if (!in_tile(vx, vy, rv)) continue;
         int cur = vy * TS + vx, hops = 0;
