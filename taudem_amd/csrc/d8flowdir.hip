@@ -250,10 +250,17 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
         z[j] = Z[o];
         pw[j] = P[o];
     }
+    // The direction codes in ONE-HOT form (bit c for a code c in 0 .. 8, nothing for nodata / outside): "in the queue" is bit 0, "has a direction" bits 1 .. 8,
+    // dontCross two bit tests - and the per-neighbour case analysis below integer and / or on 0 / 1 values.  (As nested if / else on comparisons it compiled to
+    // ~145 vector and ~200 scalar instructions per cell row - lane-mask algebra and branches - and the pass waited for its instructions, not for memory:
+    // profiles/r04zzzz_pmc_sq_summary.json.)
+    unsigned ow[SLOPE_ROWS + 2];
 #pragma unroll
     for (int j = 0; j < SLOPE_ROWS + 2; j++) {
         const int y = ybase - 1 + j;
-        if (!inx || y < 0 || y >= ny) { z[j] = 0.f; pw[j] = TDX_P_NODATA; }   // (never looked at from a flat cell: flat cells are interior cells)
+        const bool in = inx && y >= 0 && y < ny;   // (never looked at from a flat cell: flat cells are interior cells)
+        if (!in) z[j] = 0.f;
+        ow[j] = in ? (1u << min(unsigned(pw[j]), 31u)) & 0x1FFu : 0u;
     }
     int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
     int masked_row = -1;                  // ... a flat cell whose incfall mask shuts out an in-queue neighbour (flatk::LevelPlainT)
@@ -261,39 +268,43 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
         const float zn1 = z[r], zc1 = z[r + 1], zs1 = z[r + 2];
-        const int pn1 = pw[r], pc1 = pw[r + 1], ps1 = pw[r + 2];
+        const unsigned on1 = ow[r], oc1 = ow[r + 1], os1 = ow[r + 2];
         const float zn0 = lane_left(zn1, 0.f), zn2 = lane_right(zn1, 0.f), zc0 = lane_left(zc1, 0.f), zc2 = lane_right(zc1, 0.f);
         const float zs0 = lane_left(zs1, 0.f), zs2 = lane_right(zs1, 0.f);
-        const int pn0 = lane_left(pn1, 0), pn2 = lane_right(pn1, 0), pc0 = lane_left(pc1, 0), pc2 = lane_right(pc1, 0);
-        const int ps0 = lane_left(ps1, 0), ps2 = lane_right(ps1, 0);
+        const unsigned on0 = lane_left(on1, 0u), on2 = lane_right(on1, 0u), oc0 = lane_left(oc1, 0u), oc2 = lane_right(oc1, 0u);
+        const unsigned os0 = lane_left(os1, 0u), os2 = lane_right(os1, 0u);
         if (mine && y < y_own1) {
             const size_t idx = size_t(y) * size_t(nx) + size_t(x);
             LV l = -1, q = -1;
             unsigned fm = 0, rm = 0;
-            if (pc1 == 0) {   // a flat cell: interior, all eight neighbours valid
+            if (oc1 & 1u) {   // a flat cell: interior, all eight neighbours valid
                 const float z0 = zc1;
-                bool low = false, quirk = false, higher = false;
-                // neighbour k: value, direction code, dontCross(k) from the cardinal neighbours' codes (src/d8.cpp:54-100)
-#define TDX_CLS(K, ZN, PN, CROSS)                                                     \
-    {                                                                                  \
-        const float zd = z0 - (ZN);                                                    \
-        const bool inq = (PN) == 0;                                                    \
-        if (zd < 0) higher = true;                                                     \
-        if (inq) rm |= 1u << ((K) - 1);                                                \
-        if (!(CROSS)) {                                                                \
-            if (zd >= 0 && (PN) > 0 && (PN) < 9) low = true;                           \
-            else if (zd == 0) { if (inq) fm |= 1u << ((K) - 1); else quirk = true; }   \
-        }                                                                              \
+                bool higher = false;
+                unsigned lowi = 0, fmq = 0;   // fmq: bits 0-7 the incfall mask, bit 8 the quirk (an equal neighbour that is neither in the queue nor has a direction)
+                // neighbour k: elevation, one-hot code, "does not cross" (0 / 1; dontCross(k), src/d8.cpp:54-100, from the cardinal neighbours' codes).  Per neighbour,
+                // as in flatk::classify_kernel: higher |= zd < 0; rm bit if in the queue; and unless the step crosses a flow path:
+                // zd >= 0 towards a cell with a direction -> low; else zd == 0 -> fm bit (in the queue) or the quirk.  zd == 0 implies zd >= 0, so the
+                // second case only sees cells without a direction.
+#define TDX_CLS(K, ZN, ON, NC)                                                                                   \
+    {                                                                                                             \
+        const float zd = z0 - (ZN);                                                                               \
+        const unsigned inq = (ON) & 1u, isdir = min((ON) & 0x1FEu, 1u), oth = ((ON) & 0x1FFu) ? 0u : 1u;          \
+        higher |= zd < 0;                                                                                         \
+        rm |= inq << ((K) - 1);                                                                                   \
+        lowi |= zd >= 0 ? ((NC) & isdir) : 0u;                                                                    \
+        fmq |= zd == 0 ? ((0u - (NC)) & ((inq << ((K) - 1)) | (oth << 8))) : 0u;                                  \
     }
-                TDX_CLS(1, zc2, pc2, false)
-                TDX_CLS(2, zn2, pn2, (pc2 == 4 || pn1 == 8))
-                TDX_CLS(3, zn1, pn1, false)
-                TDX_CLS(4, zn0, pn0, (pn1 == 6 || pc0 == 2))
-                TDX_CLS(5, zc0, pc0, false)
-                TDX_CLS(6, zs0, ps0, (ps1 == 4 || pc0 == 8))
-                TDX_CLS(7, zs1, ps1, false)
-                TDX_CLS(8, zs2, ps2, (pc2 == 6 || ps1 == 2))
+                TDX_CLS(1, zc2, oc2, 1u)
+                TDX_CLS(2, zn2, on2, (((oc2 >> 4) | (on1 >> 8)) & 1u) ^ 1u)
+                TDX_CLS(3, zn1, on1, 1u)
+                TDX_CLS(4, zn0, on0, (((on1 >> 6) | (oc0 >> 2)) & 1u) ^ 1u)
+                TDX_CLS(5, zc0, oc0, 1u)
+                TDX_CLS(6, zs0, os0, (((os1 >> 4) | (oc0 >> 8)) & 1u) ^ 1u)
+                TDX_CLS(7, zs1, os1, 1u)
+                TDX_CLS(8, zs2, os2, (((oc2 >> 6) | (os1 >> 2)) & 1u) ^ 1u)
 #undef TDX_CLS
+                const bool low = lowi != 0u, quirk = (fmq >> 8) != 0u;
+                fm = fmq & 0xFFu;
                 l = low ? 1 : (quirk ? 2 : 0);
                 q = higher ? 1 : 0;
                 const int tr = y / tilek::TS;
