@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
                 int16_t dir = (fl.has_pits && ((pit >> (r + 1)) & 1u)) ? TDX_P_NODATA : int16_t(0);   // enclosed pit (src/d8.cpp:559-585)
                 bool done = false;
                 // candidate order 1,3,5,7,2,4,6,8; the first non-marked neighbour that is not higher ends the search (src/d8.cpp:444-451)
+                // (as straight-line selects instead of branches the compiler interleaves all sixteen rows' fp64 products: 242 VGPRs, twice the instructions - not kept)
 #define TDX_SF2(K)                                                                     \
     if (!done) {                                                                        \
         if (rk[K] > 0) {                                                                \
