@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
             __builtin_amdgcn_sched_barrier(0);   // (keeps the next quarter's reads behind this quarter's arithmetic)
         }
     }
-    __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
+    __syncthreads();   // every lane is done reading directions: the target table takes the tile's place
 #define S_TGT(c) sT[c]
 #pragma unroll
     for (int r = 0; r < 16; r++)
@@ -685,24 +685,30 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
                                                              const uint32_t* __restrict__ node_indeg, int contcheck, unsigned big_threshold,
                                                              float* __restrict__ A, uint32_t* __restrict__ biglist,
                                                              unsigned long long* __restrict__ nbig) {
-    // 26 KB of LDS per tile: counts (32 bit), the two flags as a bit set, and the staged P tile whose interior is
-    // overwritten with the in-tile targets once the topology has been derived
-    __shared__ int16_t sP[TH * TH];
+    // 26 KB of LDS per tile: counts (32 bit), the two flags as a bit set, and the staged tile of one-hot direction codes, which the 64-pitch table of
+    // in-tile targets replaces once the topology has been derived (the ring's codes set aside in sRing) - as in ad8_tile_local_kernel
+    __shared__ uint16_t sO[TH * TH];
     __shared__ unsigned sCnt[TS * TS];
     __shared__ unsigned sFlag[TS * TS / 16];   // 2 bits per cell: contaminated, not evaluated
+    __shared__ uint16_t sRing[4 * TH];
+    int16_t* const sT = reinterpret_cast<int16_t*>(sO);
     const int tile = blockIdx.x;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, ya0 = g.y0 + ty * TS, rv = rows_valid(g, ty);
     const int tid = threadIdx.x, lx = tid & 63, ry0 = (tid >> 6) * 16;
-    stage_p(P, g.nx, g.ny_arr, x0, ya0, nodata, sP);
+    stage_p_onehot(P, g.nx, g.ny_arr, x0, ya0, nodata, sO);
     sFlag[tid] = 0u;
     __syncthreads();
+    for (int j = tid; j < 4 * TH; j += 256) {
+        int hx, hy;
+        sRing[j] = ring_cell(j, rv, hx, hy) ? sO[(hy + 1) * TH + hx + 1] : uint16_t(0);
+    }
     int16_t tgt[16];
     unsigned partmask = 0;
     {
         // the 16 words of phase A and the directions (own cell, cell drained to) are fetched unconditionally, back to back
         uint32_t cw[16];
-        int pown[16], ptgt[16];
+        unsigned oown[16], otgt[16];
         const int gx = x0 + lx, gxc = gx < g.nx ? gx : g.nx - 1;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -710,22 +716,24 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
             cw[r] = cellw[size_t(ya0 + lyc) * size_t(g.nx) + size_t(gxc)];
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) pown[r] = sP[(ry0 + r + 1) * TH + lx + 1];
+        for (int r = 0; r < 16; r++) oown[r] = sO[(ry0 + r + 1) * TH + lx + 1];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int pc = (pown[r] >= 1 && pown[r] <= 8) ? pown[r] : 1;
-            ptgt[r] = sP[(ry0 + r + d2(pc) + 1) * TH + lx + d1(pc) + 1];
+            const unsigned dirs = oown[r] & OH_DIRS;
+            const int pc = dirs ? __ffs(int(dirs)) - 1 : 1;
+            otgt[r] = sO[(ry0 + r + d2(pc) + 1) * TH + lx + d1(pc) + 1];
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ly = ry0 + r;
-            const int p = pown[r];
+            const unsigned dirs = oown[r] & OH_DIRS;
+            const int p = dirs ? __ffs(int(dirs)) - 1 : 0;   // 1 .. 8, or 0: no direction
             int t = -1;
-            if (ly < rv && p_part(int16_t(p), nodata)) {
+            if (ly < rv && (oown[r] & OH_PART) != 0u) {
                 partmask |= 1u << r;
-                if (p >= 1 && p <= 8) {
+                if (p >= 1) {
                     const int tlx = lx + d1(p), tly = ly + d2(p);
-                    if (in_tile(tlx, tly, rv) && p_part(int16_t(ptgt[r]), nodata)) t = tly * TS + tlx;
+                    if (in_tile(tlx, tly, rv) && (otgt[r] & OH_PART) != 0u) t = tly * TS + tlx;
                 }
             }
             tgt[r] = int16_t(t);
@@ -735,20 +743,21 @@ __global__ __launch_bounds__(256) void ad8_tile_apply_kernel(const int16_t* __re
             if (fl) atomicOr(&sFlag[(ly * TS + lx) >> 4], fl << (2 * ((ly * TS + lx) & 15)));
         }
     }
-    __syncthreads();   // every lane is done reading directions: the interior of sP becomes the target table
-#define S_TGT(c) sP[__umul24(unsigned(c) >> 6, unsigned(TH)) + (unsigned(c) & 63u) + unsigned(TH + 1)]   // (c >= 0; TS = 64: a shift, a mask and one full-rate 24-bit multiply-add - the signed / and % with a 32-bit multiply were a third of a hop's address arithmetic)
-    // entry cells are looked up through the ring directions, which stay in place
+    __syncthreads();   // every lane is done reading directions: the target table takes the tile's place
+#define S_TGT(c) sT[c]
+    // (entry cells are looked up through the ring's codes in sRing)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         // participation of an entry cell: remembered as target code -3 ("participates, leaves the tile or ends") vs -1
-        if (ry0 + r < rv) sP[(ry0 + r + 1) * TH + lx + 1] = (tgt[r] >= 0) ? tgt[r] : (((partmask >> r) & 1u) ? int16_t(-3) : int16_t(-1));
+        if (ry0 + r < rv) sT[(ry0 + r) * TS + lx] = (tgt[r] >= 0) ? tgt[r] : (((partmask >> r) & 1u) ? int16_t(-3) : int16_t(-1));
     }
     __syncthreads();
     for (int j = tid; j < 4 * TH; j += 256) {
         int hx, hy;
         if (!ring_cell(j, rv, hx, hy)) continue;
-        const int16_t ph = sP[(hy + 1) * TH + hx + 1];
-        if (ph == nodata || ph < 1 || ph > 8) continue;
+        const unsigned dirs = sRing[j] & OH_DIRS;
+        if (!dirs) continue;
+        const int ph = __ffs(int(dirs)) - 1;
         const int vx = hx + d1(ph), vy = hy + d2(ph);
         if (!in_tile(vx, vy, rv)) continue;
         int cur = vy * TS + vx, hops = 0;
