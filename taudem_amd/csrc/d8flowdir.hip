@@ -473,10 +473,13 @@ __global__ __launch_bounds__(256) void d8_setflow2_stream_kernel(const float* __
                 // (as straight-line selects instead of branches the compiler interleaves all sixteen rows' fp64 products: 242 VGPRs, twice the instructions - not kept)
 #define TDX_SF2(K)                                                                     \
     if (!done) {                                                                        \
-        if (rk[K] > 0) {                                                                \
-            const float slope = (float)(f[K] * (double)(e2c - ek[K]));                 \
-            if (slope > smax) { dir = int16_t(K); smax = slope; }                       \
-        } else if (z0 - zk[K] >= 0) { dir = int16_t(K); done = true; }                  \
+        const float slope = (float)(f[K] * (double)(e2c - ek[K]));                      \
+        const bool marked = rk[K] > 0;                                                  \
+        const bool take = marked && slope > smax;                                       \
+        const bool stop = !marked && z0 - zk[K] >= 0;                                   \
+        dir = (take || stop) ? int16_t(K) : dir;                                        \
+        smax = take ? slope : smax;                                                     \
+        done = stop;                                                                    \
     }
                 TDX_SF2(1) TDX_SF2(3) TDX_SF2(5) TDX_SF2(7) TDX_SF2(2) TDX_SF2(4) TDX_SF2(6) TDX_SF2(8)
 #undef TDX_SF2
