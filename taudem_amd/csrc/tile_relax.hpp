@@ -1433,15 +1433,8 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     if (rc != TDX_OK) return rc;
     rc = B.start();
     if (rc != TDX_OK) return rc;
-    // Both first lists before either first round.  The first round of a field is a launch that fills every CU; the other field's list kernel (a few hundred
-    // small workgroups) that arrives a microsecond AFTER it waits for that whole round, and the two first rounds then run one after the other instead of
-    // side by side (profiles/r05zzz_timeline_d8_16384.txt, second flat iteration: first_list_kernel 510 us behind a 945 us round; in the first iteration it
-    // got in 0.1 us ahead).  Which one happened was a race between two streams.
-    static const bool no_join = getenv("TDX_PAIR_NO_LIST_JOIN") != nullptr;   // (A/B hook)
-    if (!no_join) {
-        TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream2));
-        TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
-    }
+    // (Making both first lists run before either first round - the second field's list kernel can get stuck for a whole round behind the first field's
+    // first launch, profiles/r05zzz_timeline_d8_16384.txt - changes nothing: 12.59-12.66 ms of d8flowdir either way, the device is busy in both orders.)
     rc = A.enqueue();
     if (rc != TDX_OK) return rc;
     rc = B.enqueue();
