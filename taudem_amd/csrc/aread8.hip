@@ -332,33 +332,7 @@ __device__ __forceinline__ uint32_t node_id(const Ad8Geom& g, int gx, int gy) {
     return uint32_t(ty * g.tiles_x + gx / TS) * 256u + uint32_t(perim_pos(gx % TS, ly, rows_valid(g, ty)));
 }
 
-struct TileTopo {   // what both tile kernels derive from the staged P tile
-    int16_t tgt;    // >= 0 in-tile target, -1 terminal, -2 leaves the tile towards a participating cell
-    bool part, con, poison;
-    unsigned indeg;
-};
 
-// stage P (tile + ring, outside the array = nodata) into LDS; ya0 = array row of the tile's first row.  All loads of a lane are
-// issued back to back (addresses clamped, validity applied afterwards: loads inside a loop with a bounds branch wait for each other).
-__device__ __forceinline__ void stage_p(const int16_t* __restrict__ P, int nx, int ny_arr, int x0, int ya0, int16_t nodata, int16_t* sP) {
-    constexpr int NIT = (TH * TH + 255) / 256;
-    int16_t v[NIT];
-    unsigned ok = 0;
-#pragma unroll
-    for (int i = 0; i < NIT; i++) {
-        const int e = int(threadIdx.x) + i * 256, ec = e < TH * TH ? e : TH * TH - 1;
-        const int ly = ec / TH, lx = ec - ly * TH;
-        const int gx = x0 + lx - 1, gy = ya0 + ly - 1;
-        const int gxc = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= ny_arr ? ny_arr - 1 : gy);
-        v[i] = P[size_t(gyc) * size_t(nx) + size_t(gxc)];
-        if (gx == gxc && gy == gyc) ok |= 1u << i;
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; i++) {
-        const int e = int(threadIdx.x) + i * 256;
-        if (e < TH * TH) sP[e] = ((ok >> i) & 1u) ? v[i] : nodata;
-    }
-}
 // One-hot form of a direction code (ad8_tile_local_kernel): bit c for c in 0 .. 8, OH_SINK for the pure sink of the outlets mode, OH_NODATA for nodata and for
 // what lies outside the array, nothing for anything else (16 + p: a cell outside the outlets' closure - it neither takes part nor contributes nor contaminates).
 constexpr unsigned OH_NODATA = 0x8000u, OH_SINK = 0x4000u, OH_DIRS = 0x1FEu, OH_PART = 0x1FFu | OH_SINK;
@@ -366,7 +340,9 @@ __device__ __forceinline__ unsigned p_onehot(int v, int nodata) {
     const unsigned sel = v == nodata ? 15u : (v == int(P_SINK) ? 14u : min(unsigned(v), 31u));
     return (1u << sel) & (0x1FFu | OH_SINK | OH_NODATA);
 }
-// stage_p with every cell converted once (each cell is in the 3 x 3 window of nine cells: converted where it is used it cost a quarter of the topology pass)
+// Stage P (tile + ring; ya0 = array row of the tile's first row; outside the array = nodata) into LDS, every cell converted ONCE (each cell is in the 3 x 3 window of
+// nine cells: converted where it is used, the conversion cost a quarter of the topology pass).  Addresses are clamped and validity is applied afterwards: loads inside a
+// loop with a bounds branch wait for each other.
 __device__ __forceinline__ void stage_p_onehot(const int16_t* __restrict__ P, int nx, int ny_arr, int x0, int ya0, int16_t nodata, uint16_t* sO) {
     constexpr int NIT = (TH * TH + 255) / 256, HALF = (NIT + 1) / 2;
     // two batches of loads (a converted value needs a register of its own where two raw int16 shared one: all 17 in flight at once spilled eleven registers;
@@ -392,34 +368,8 @@ __device__ __forceinline__ void stage_p_onehot(const int16_t* __restrict__ P, in
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__device__ __forceinline__ bool p_part(int16_t p, int16_t nodata) { return p != nodata && ((p >= 0 && p <= 8) || p == P_SINK); }
+// (a cell takes part in the sweep - d8_participates, src/commonLib.cpp:240-386 - iff its code is 0 .. 8 or the outlets mode's pure sink: OH_PART)
 __device__ __forceinline__ bool in_tile(int lx, int ly, int rv) { return lx >= 0 && lx < TS && ly >= 0 && ly < rv; }
-
-// topology of the in-tile cell (lx, ly) from the staged tile (initNeighborD8up, src/commonLib.cpp:251-282,
-// and the contamination test of src/aread8.cpp:241-242); rv = rows of the tile that belong to this strip
-__device__ __forceinline__ TileTopo tile_topo(const int16_t* sP, int lx, int ly, int rv, int16_t nodata) {
-    TileTopo t;
-    t.part = false; t.tgt = -1; t.con = false; t.poison = false; t.indeg = 0;
-    if (ly >= rv) return t;
-    const int16_t p = sP[(ly + 1) * TH + lx + 1];
-    t.part = p_part(p, nodata);
-    if (!t.part) return t;
-#pragma unroll
-    for (int k = 1; k <= 8; k++) {
-        const int nlx = lx + d1(k), nly = ly + d2(k);
-        const int16_t pn = sP[(nly + 1) * TH + nlx + 1];
-        if (pn == nodata) { t.con = true; continue; }
-        if (pn >= 0 && pn <= 8 && (pn - k == 4 || pn - k == -4)) {
-            if (pn == 0) t.poison = true;   // k == 4: counted in the in-degree but never decremented (src/aread8.cpp:262)
-            else if (in_tile(nlx, nly, rv)) t.indeg++;
-        }
-    }
-    if (p >= 1 && p <= 8) {
-        const int tlx = lx + d1(p), tly = ly + d2(p);
-        if (p_part(sP[(tly + 1) * TH + tlx + 1], nodata)) t.tgt = in_tile(tlx, tly, rv) ? int16_t(tly * TS + tlx) : int16_t(-2);
-    }
-    return t;
-}
 
 // ring cell j of a tile with rv valid rows: top row, bottom row, left column, right column
 __device__ __forceinline__ bool ring_cell(int j, int rv, int& hx, int& hy) {
@@ -493,7 +443,7 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
                 const int r = 4 * h + q, ly = ry0 + r;
                 const unsigned dirs = oh[1][q + 1] & OH_DIRS;
                 const int p = dirs ? __ffs(int(dirs)) - 1 : 0;   // 1 .. 8, or 0: no direction
-                const bool part = ly < rv && (oh[1][q + 1] & OH_PART) != 0u;   // p_part()
+                const bool part = ly < rv && (oh[1][q + 1] & OH_PART) != 0u;
                 // neighbours 1 .. 8 = E NE N NW W SW S SE (src/commonLib.h:83-84); k <= 4 drains into the cell with code k + 4, k >= 5 with k - 4
                 const unsigned oE = oh[2][q + 1], oNE = oh[2][q], oN = oh[1][q], oNW = oh[0][q], oW = oh[0][q + 1], oSW = oh[0][q + 2], oS = oh[1][q + 2],
                                oSE = oh[2][q + 2];
