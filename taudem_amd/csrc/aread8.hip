@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict
 // the serial chain is only as long as the number of TILE crossings of the longest path:
 //
 //   A  ad8_tile_local_kernel   per tile, in LDS: Kahn sweep of the flows that stay inside the tile
-//                              (lanes walk downstream with ONE returning 64-bit LDS atomic per hop that
-//                              carries count + arrival + the contamination / not-evaluated flags).
+//                              (the tile staged as one-hot direction codes; lanes walk downstream with ONE
+//                              returning 32-bit LDS atomic per hop that carries count + arrival + the
+//                              contamination / not-evaluated flags, one loop per lane over all its sources).
 //                              Result S_loc(c) -> global; every cell that leaves the tile towards a
 //                              participating cell becomes a NODE of the crossing forest; for every
 //                              crossing that enters the tile the lane follows the in-tile path to the
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(256) void ad8_halo_kernel(const int16_t* __restrict
 //                              in-tile path, convert to float32, apply contamination, write ad8.
 //   D  big cells (count > 2^24, where float32 adds round and the k order of src/aread8.cpp:239-256
 //                              matters) are re-evaluated with the exact k-ordered pull of ad8_evaluate in
-//                              dependency order (ad8_big_* kernels): a few main-stem cells.
+//                              dependency order (ad8_big_* kernels): the main stems - a few thousand cells
+//                              at 16384^2, ~10^5 per strip at 65536 columns; chains inside a 64-entry chunk
+//                              by an in-binade scan (ad8_big_fold_kernel).
 //
 // "not evaluated" (the reference leaves -1): cells fed by the p == 0 north-west quirk, cells on / below
 // a cycle, and everything downstream of them - carried as a flag next to the contamination flag.
@@ -390,10 +393,9 @@ __global__ __launch_bounds__(256, 6) void ad8_tile_local_kernel(const int16_t* _
     unsigned long long tcs[6];
 #define AD8_MARK(i) do { if (DBG) tcs[i] = clock64(); } while (0)
     AD8_MARK(0);
-    // 26 KB of LDS per tile (6 workgroups per CU): the in-tile targets overwrite the interior of the staged P tile
-    // once every lane has derived its topology from it; the ring cells keep their directions for the entry search
-    // (the staged tile holds ONE-HOT direction codes, 66-pitch with the ring; the target table that replaces it is 64-pitch - a hop addresses it and sAcc
-    // with the same cell index, two shifts - so the ring cells' codes are set aside first: sRing, in ring_cell() order)
+    // 26.7 KB of LDS per tile (six workgroups per CU use 160 of its 163.8 KB).  The staged tile holds ONE-HOT direction codes, 66-pitch with the ring; once every
+    // lane has derived its topology from it, the table of in-tile targets takes its place at 64-pitch - a hop addresses the table and sAcc with the same cell
+    // index, two shifts - so the ring cells' codes, which the entry search needs afterwards, are set aside first: sRing, in ring_cell() order.
     __shared__ uint16_t sO[TH * TH];
     __shared__ unsigned sAcc[TS * TS];
     __shared__ unsigned sIn[256];   // crossings that end at each perimeter cell
