@@ -921,32 +921,27 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
     const bool spill = nbig - b0 > ring;   // a tree longer than the ring (ring <= BIG_LDS, a multiple of 64; TDX_AD8_BIG_RING: test hook): folded values also go to bigval
     unsigned base = 0u;                    // ring slot of list position chunk0
     float hint = 0.f;   // the value of the last cell folded in this tree: values ascend with the list, so its binade is the guess for the next chunk's scan
-    // Operands two chunks ahead (with the scan a chunk is folded in a fraction of a memory latency: one chunk ahead, the wave waited for its operands in
-    // every chunk), the eight values and the eight dependencies of an entry as two 16-byte loads each.
-    struct Operands { uint32_t f, c; float bv; float4 a0, a1; uint4 d0, d1; };
+    // operands of the first chunk; the next chunk's are fetched while the current one is folded
+    uint32_t f = 0, c = 0, dp[8];
+    float ak[8], bv = BIG_MARK;
     auto fetch = [&](unsigned long long q) {
-        Operands o;
-        o.f = 0; o.c = 0; o.bv = BIG_MARK;
-        o.a0 = o.a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        o.d0 = o.d1 = make_uint4(BIG_NODEP, BIG_NODEP, BIG_NODEP, BIG_NODEP);
+        f = 0; c = 0;
         if (q < nbig) {
-            o.f = flags[q]; o.c = sorted[q]; o.bv = bigval[q];   // (bigval as the gather left it: the final value of a cell that is not pending)
-            const float4* va = reinterpret_cast<const float4*>(vals + q * 8);
-            const uint4* da = reinterpret_cast<const uint4*>(deps + q * 8);
-            o.a0 = va[0]; o.a1 = va[1]; o.d0 = da[0]; o.d1 = da[1];
+            f = flags[q]; c = sorted[q]; bv = bigval[q];   // (bigval as the gather left it: the final value of a cell that is not pending)
+#pragma unroll
+            for (int k = 0; k < 8; k++) { ak[k] = vals[q * 8 + k]; dp[k] = deps[q * 8 + k]; }
         }
-        return o;
     };
-    Operands nx1 = fetch(b0 + (unsigned long long)lane), nx2 = fetch(b0 + 64ull + (unsigned long long)lane);
+    fetch(b0 + (unsigned long long)lane);
     for (unsigned long long chunk0 = b0; chunk0 < nbig; chunk0 += 64) {
         const unsigned long long q = chunk0 + (unsigned long long)lane;
-        const Operands cur = nx1;
-        nx1 = nx2;
-        nx2 = fetch(q + 128);
-        const uint32_t fl = cur.f, cell = cur.c;
-        const float own = cur.bv;
-        float a8[8] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w};
-        uint32_t d8[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
+        const uint32_t fl = f, cell = c;
+        const float own = bv;
+        float a8[8];
+        uint32_t d8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a8[k] = ak[k]; d8[k] = dp[k]; }
+        fetch(q + 64);
         const bool pending = (fl & BIGF_PENDING) != 0u;
         bool blocked = (fl & BIGF_BLOCKED) != 0u;
         unsigned inchunk = 0;
