@@ -340,7 +340,9 @@ __device__ __forceinline__ uint32_t node_id(const Ad8Geom& g, int gx, int gy) {
 // what lies outside the array, nothing for anything else (16 + p: a cell outside the outlets' closure - it neither takes part nor contributes nor contaminates).
 constexpr unsigned OH_NODATA = 0x8000u, OH_SINK = 0x4000u, OH_DIRS = 0x1FEu, OH_PART = 0x1FFu | OH_SINK;
 __device__ __forceinline__ unsigned p_onehot(int v, int nodata) {
-    const unsigned sel = v == nodata ? 15u : (v == int(P_SINK) ? 14u : min(unsigned(v), 31u));
+    // (only the two explicit branches reach bits 15 / 14: a raw code 9 .. 15 in p is a cell that neither takes part nor contaminates - like everywhere else
+    // in the pipeline, d8_participates and the reference, which ignores codes outside 0 .. 8 - and not a sink or a nodata cell)
+    const unsigned sel = v == nodata ? 15u : (v == int(P_SINK) ? 14u : (unsigned(v) <= 8u ? unsigned(v) : 31u));
     return (1u << sel) & (0x1FFu | OH_SINK | OH_NODATA);
 }
 // Stage P (tile + ring; ya0 = array row of the tile's first row; outside the array = nodata) into LDS, every cell converted ONCE (each cell is in the 3 x 3 window of
@@ -1507,6 +1509,9 @@ static int aread8_impl(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t 
     // BASELINE.json configs[3], is exactly 2^32 cells, 4 294 700 699 of them with a direction - has its participating cells counted
     // (one streaming pass over p).  Beyond that the tile dependency sweep runs, whose float32 adds have no such limit.
     // TDX_AD8_COUNT_LIMIT: test hook for that switch.
+    // (cell indices of the tile contraction are uint32: the strip's ARRAY must hold at most 2^32 - 1 cells whatever the participating count says - the entry
+    // points refuse larger strips; this keeps the two conditions side by side)
+    if (n > 0xffffffffull) return tdx_fail(ctx, TDX_ERR_ARG, "aread8: strip array larger than 2^32 - 1 cells");
     if (tiled) {
         int64_t cells = int64_t(st.nx) * int64_t(st.y1 - st.y0);
         int rc0 = strip_allreduce(ctx, st, &cells, 1, TDX_OP_SUM);

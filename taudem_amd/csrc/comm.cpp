@@ -399,16 +399,22 @@ extern "C" void tdx_group_abort(tdx_group* g) {
     if (!g) return;
     if (g->aborted.exchange(true)) return;   // one shot: every failing rank thread calls this, the first one does the work
     if (g->bar) g->bar->abort();
+    // Every communicator is marked dead FIRST (no rank thread starts a new RCCL call), then ONE bounded wait of 2 s covers all of them: N stuck ranks
+    // delay the abort by 2 s, not 2 N s.
+    for (tdx_rccl_comm* r : g->rc) if (r) r->dead.store(true);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
     for (tdx_rccl_comm* r : g->rc) {
         if (!r) continue;
         // Take the communicator away under its lock: a rank thread is either before its calls (and will find `dead`) or past them.  A rank thread
         // that is STUCK inside an RCCL call (ncclGroupEnd setting up a connection to a peer that has already failed) holds the lock for good -
-        // and the abort is the only thing that releases it: after a bounded wait the communicator is aborted under that thread's feet (what
+        // and the abort is the only thing that releases it: after the bounded wait the communicator is aborted under that thread's feet (what
         // ncclCommAbort is for); its call returns an error, every later call finds `dead`, and nobody touches the handle again.
-        r->dead.store(true);
+        // ORDERING the unlocked accesses below rely on: this function runs at most once per group (the `aborted` guard above), and
+        // tdx_group_destroy - the only other reader of r->comm / writer of r->abandoned outside a rank thread's locked section - is called
+        // after the rank threads have been joined (taudem_amd.distributed.StripGroup.__exit__, tool_strips.hpp).
         std::unique_lock<std::mutex> lk(r->use, std::defer_lock);
         bool got = false;
-        for (int i = 0; i < 200 && !(got = lk.try_lock()); i++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        while (!(got = lk.try_lock()) && std::chrono::steady_clock::now() < deadline) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         ncclComm_t c = r->comm;
         if (got) { r->comm = nullptr; lk.unlock(); }
         else r->abandoned = true;

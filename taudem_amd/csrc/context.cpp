@@ -36,7 +36,10 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 void tdx_context::seg_begin() {
     if (!seg_mode || seg_open) return;
-    if (seg_mode == 2 && comm_size > 1) {
+    // Mode 2 hands ONE device token round: that is only safe when a collective BLOCKS until every rank has entered it (the peer transport's barriers).  A
+    // stream-ordered transport (RCCL) merely enqueues: a rank could re-take the token behind a collective its peer - still waiting for the token - can
+    // never post, and the next seg_end would wait on that stream for ever.  There mode 2 times like mode 1 (the ranks have a GPU each anyway).
+    if (seg_mode == 2 && comm_size > 1 && !comm_ordered) {
         std::unique_lock<std::mutex> lk(g_tok_m);
         g_tok_cv.wait(lk, [] { return !g_tok_taken; });
         g_tok_taken = true;

@@ -63,6 +63,7 @@ struct tdx_context {
     // ---- multi-strip diagnostics (strips.hpp): what this rank is doing, for time-out messages and TDX_COMM_TRACE=1 ----
     const char* stage = "";                   // tool stage of the running call ("pitremove", "d8flowdir" ...)
     int comm_rank = 0, comm_size = 1;
+    bool comm_ordered = false;   // the call's transport enqueues its collectives on the stream (TDX_COMM_STREAM_ORDERED)
     int64_t comm_exchanges = 0, comm_allreduces = 0;   // of the running call
     int64_t comm_exchanges_total = 0, comm_allreduces_total = 0;   // since the context was created (tdx_context_comm_counters)
 

@@ -29,6 +29,7 @@ static inline void strip_mark(tdx_context* ctx, const Strip& st, const char* sta
     ctx->stage = stage;
     ctx->comm_rank = st.comm ? st.comm->rank : 0;
     ctx->comm_size = st.comm ? st.comm->size : 1;
+    ctx->comm_ordered = st.comm && (st.comm->flags & TDX_COMM_STREAM_ORDERED) != 0;
 }
 static inline Strip strip_from_comm(const tdx_comm* comm, int nx, int ny_local) {
     Strip s; s.nx = nx; s.ny_arr = ny_local + 2; s.y0 = 1; s.y1 = ny_local + 1; s.comm = comm;

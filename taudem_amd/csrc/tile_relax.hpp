@@ -1230,6 +1230,8 @@ struct RoundRunner {
         if (rounds > (round_cap > 0 ? round_cap : 64ll * ntiles + 65536ll))
             return tdx_fail(ctx, TDX_ERR_HIP, "tile schedule: no fixed point after " + std::to_string(rounds) + " rounds (" + std::to_string(ntiles) + " tiles)");
         if (batch > ring_len - 2) batch = ring_len - 2;
+        if (batch > TDX_MAIL_RUN_SLOT) batch = TDX_MAIL_RUN_SLOT;   // a batch reports into ONE host slot of TDX_MAIL_RUN_SLOT words, whatever a caller (TDX_SWEEP_EAGER_ROUNDS) asks for
+        if (batch < 1) batch = 1;
         if (r_enq + batch + 1 > ring_len) {   // counts[r + batch] (written by the batch's last round) must be inside the ring
             hipLaunchKernelGGL(ring_wrap_kernel, dim3(1), dim3(256), 0, s, sc.counts, r_enq);
             r_enq = 0;

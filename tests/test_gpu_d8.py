@@ -244,6 +244,31 @@ def test_aread8_tiles_quirks(ctx, oracle):
         assert bits_equal(a, a_o), describe_diff(a, a_o, f"quirks contcheck={cc}")
 
 
+def test_aread8_direction_codes_outside_0_to_8(ctx, oracle, monkeypatch):
+    """A p grid somebody else wrote may hold codes that are neither 0 .. 8 nor the nodata value (9 .. 15, 20, 100, -5): such a cell does not take part
+    (initNeighborD8up, src/commonLib.cpp:257-266) and is no nodata cell either; what it does to a neighbour follows the reference's own test
+    `p[n] - k == +-4` (src/aread8.cpp:246) - every path of the product (tile contraction, dependency sweep, walk) against the restatement."""
+    rng = np.random.default_rng(17)
+    p = _p_field(oracle, (300, 330), 21).copy()
+    idx = rng.integers(3, 297, size=(120, 2))
+    codes = [9, 10, 11, 12, 13, 14, 15, 20, 100, -5]
+    for i, (y, x) in enumerate(idx):
+        p[y, x] = codes[i % len(codes)]
+    w = rng.random(p.shape, dtype=np.float32)
+    for env in ({}, {"TDX_AD8_SWEEP": "1"}, {"TDX_AD8_WALK": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for cc in (True, False):
+            a_o = oracle.aread8(p, -32768, contcheck=cc)
+            a = ctx.aread8(p, -32768, contcheck=cc)
+            assert bits_equal(a, a_o), describe_diff(a, a_o, f"codes outside 0..8, {env} contcheck={cc}")
+        for k in env:
+            monkeypatch.delenv(k)
+    a_o = oracle.aread8(p, -32768, weights=w, contcheck=True)
+    a = ctx.aread8(p, -32768, weights=w, contcheck=True)
+    assert bits_equal(a, a_o), describe_diff(a, a_o, "codes outside 0..8, weighted")
+
+
 def test_aread8_kahn_schedules_agree(ctx, oracle, monkeypatch):
     """The in-tile Kahn walk of ad8_tile_local_kernel as ONE loop per lane (default) and as a walk loop nested in the loop over the lane's sources
     (TDX_AD8_KAHN_NESTED=1): the same counts - the schedule is free (src/aread8.cpp:220-304) -, incl. the p == 0 quirk, holes and a cycle."""

@@ -380,3 +380,137 @@ def test_d8_config4_strip_vs_restatement(ctx, oracle, monkeypatch):
     bad, first, queued = oracle.aread8_check(p_h, ad8_h, -32768, contcheck=True)
     assert bad == 0, f"{bad} cells of ad8 do not follow from aread8()'s expression; first at row {first // nx} column {first % nx}"
     assert queued == int(((p_h >= 0) & (p_h <= 8)).sum()) and float(ad8_h.max()) > 1e7
+
+
+# ---- BASELINE.json configs[3] and configs[4] THEMSELVES: 65536 x 65536 in eight strips of 65536 x 8192, every cell on the host -------------------------
+# The regimes that exist only at full height (630 542 cells above 2^24 folded tree by tree with blocked contributors across strips, ad8 up to 2.75e9,
+# flat levels up to 32 002 of the int16 range's 32 766, a fourth flat iteration, coarse PitRemove levels relaxed across eight strips) are checked on EVERY
+# cell: the eight strips' owned rows are assembled on the host (the MI355X boxes have > 2 TB of host memory) and the WHOLE rasters go through the same
+# linear-time certificates as the lone strips above - nothing strip-local is assumed by the checkers, so a defect of the strip protocol (a halo row that
+# arrived late, a vote taken too early) shows up as a cell that does not follow from its neighbours in the other strip.
+def _eight_strips_to_host(nx, ny, size, rank_job, names_dtypes):
+    """Runs rank_job(r, c, comm, y0, nyl) -> ({name: strip tensor with halo rows}, extra) on an in-process group of `size` strips; returns the whole rasters on
+    the host (numpy, owned rows of every strip in place) and the per-rank extras."""
+    import torch
+
+    from taudem_amd.distributed import StripGroup, partition_rows
+
+    host = {k: np.empty((ny, nx), dtype=dt) for k, dt in names_dtypes.items()}
+    parts = partition_rows(ny, size)
+    with StripGroup(size, nx) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            nyl = y1 - y0
+            tensors, extra = rank_job(r, c, comm, y0, nyl)
+            torch.cuda.synchronize()
+            for k, t in tensors.items():
+                torch.from_numpy(host[k][y0:y1]).copy_(t[1:nyl + 1])
+            return extra
+        extras = grp.run(rank_main)
+        assert grp.transport == "peer"
+    torch.cuda.empty_cache()
+    return host, extras
+
+
+def test_config4_full_height_every_cell(ctx, oracle, monkeypatch):
+    """BASELINE.json configs[3] itself - PitRemove -> D8FlowDir -> AreaD8 on the 65536 x 65536 synthetic DEM, row-partitioned into EIGHT strips of 65536 x 8192
+    (src/linearpart.h:133-134; eight rank threads and contexts on the library's rank group, every halo exchange, vote and cross-strip dependency of the 8-GPU
+    protocol) - with every one of the 4 294 967 296 cells of fel, p, sd8 and ad8 checked on the host against the restatement: fel through flood()'s certificate
+    (orc_pitremove_check: src/flood.cpp:243-271,292-331 per cell + the flood from the seed cells), p and sd8 against the restatement's own rasters
+    (src/d8.cpp:359-409,459-680; flat loops as breadth-first searches: linear time, pinned to the real tools on CPU), ad8 through aread8()'s loop body on every
+    cell (orc_aread8_check: src/aread8.cpp:231-256, k-ordered float32 adds - all cells above 2^24 included)."""
+    if _host_gb() < 400:
+        pytest.skip("needs ~300 GB of host memory (the whole 65536 x 65536 rasters and the restatement's work arrays)")
+    import os
+    import time
+
+    import torch
+
+    import taudem_amd as T
+    from taudem_amd.distributed import StripPipeline
+
+    torch.cuda.empty_cache()
+    nx = ny = 65536
+    size, seed = 8, 1234
+    wl = T.synth_base_wavelength(nx)
+    t0 = time.time()
+
+    def rank_job(r, c, comm, y0, nyl):
+        pipe = StripPipeline(c, comm, nx, nyl)
+        dem = pipe.empty(torch.float32)
+        c.synth_dem((nyl, nx), seed=seed, x0=0, y0=y0, base_wavelength=wl, out=dem[1:nyl + 1])
+        fel, _ = pipe.pitremove(dem, -9999.0)
+        p, sd8, s2 = pipe.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+        ad8, _ = pipe.aread8(p, -32768, contcheck=False)   # (no edge contamination: every cell with a direction gets its count, the main stems reach 2.75e9)
+        return {"dem": dem, "fel": fel, "p": p, "sd8": sd8, "ad8": ad8}, s2
+
+    h, extras = _eight_strips_to_host(nx, ny, size, rank_job, {"dem": np.float32, "fel": np.float32, "p": np.int16, "sd8": np.float32, "ad8": np.float32})
+    st = extras[0]
+    t1 = time.time()
+    # ---- fel: every cell ----
+    _certify_fel(oracle, h["dem"], h["fel"], "65536 x 65536 in eight strips")
+    del h["dem"]
+    t2 = time.time()
+    # ---- ad8: every cell from its contributors (before p is compared: the two checks are independent) ----
+    bad, first, queued = oracle.aread8_check(h["p"], h["ad8"], -32768, contcheck=False)
+    assert bad == 0, f"{bad} cells of ad8 do not follow from aread8()'s expression; first at row {first // nx} column {first % nx}"
+    big = int(np.count_nonzero(h["ad8"] > np.float32(2 ** 24)))
+    amax = float(h["ad8"].max())
+    assert queued == int(np.count_nonzero((h["p"] >= 0) & (h["p"] <= 8)))
+    assert big > 500000 and amax > 2.0 ** 31, (big, amax)      # the regime this test exists for
+    del h["ad8"]
+    t3 = time.time()
+    # ---- p, sd8: every cell against the restatement's rasters ----
+    monkeypatch.setenv("ORC_FLATS", "bfs")
+    oracle.set_threads(os.cpu_count() or 1)
+    try:
+        p_o, sd8_o, st_o = oracle.d8flowdir(h["fel"], -3.0e38, 30.0, 30.0)
+    finally:
+        oracle.set_threads(1)
+    assert (st_o["flats_initial"], st_o["flat_iterations"], st_o["flats_left"]) == (st["flats_initial"], st["flat_iterations"], st["flats_left"])
+    neq = int(np.count_nonzero(h["p"] != p_o))
+    assert neq == 0, f"p: {neq} cells differ from the restatement"
+    assert np.array_equal(h["sd8"].view(np.uint32), sd8_o.view(np.uint32)), "sd8 differs from the restatement"
+    assert all(e["levels_fall_max"] == st["levels_fall_max"] for e in extras)
+    assert 30000 < st["levels_fall_max"] < 32766 and st["flat_iterations"] >= 4, (st["levels_fall_max"], st["flat_iterations"])
+    print(f"\nconfigs[3] at full height: {queued} directed cells, {big} cells above 2^24, ad8 max {amax:.4g}, deepest level {st['levels_fall_max']}, "
+          f"{st['flat_iterations']} flat iterations; GPU + download {t1 - t0:.0f} s, fel {t2 - t1:.0f} s, ad8 {t3 - t2:.0f} s, p / sd8 {time.time() - t3:.0f} s")
+
+
+def test_config5_full_height_every_cell(ctx, oracle, monkeypatch):
+    """BASELINE.json configs[4] itself - DinfDecayAccum with weights, decay multipliers and 64 outlets on the 65536 x 65536 DEM in EIGHT strips of 65536 x 8192,
+    under the sweep verifier - with every cell of dsca checked on the host: evaluated cells follow from their contributors' final values through dmarea()'s loop
+    body bit for bit (src/dinfdecayaccum.cpp:204-291), and a cell holds a value iff an outlet is reachable downstream of it (the restatement's own search of the
+    closure across the whole raster, src/commonLib.cpp:285-385).  The angles the strips computed (DinfFlowDir across eight strips) are the checker's input."""
+    if _host_gb() < 400:
+        pytest.skip("needs ~150 GB of host memory")
+    import time
+
+    import torch
+
+    import bench
+    import taudem_amd as T
+
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
+    nx = ny = 65536
+    size, seed = 8, 1234
+    t0 = time.time()
+
+    def rank_job(r, c, comm, y0, nyl):
+        job = bench.DecayStrip(torch, c, comm, nx, ny, y0, nyl, seed, T)
+        st = job.step()
+        torch.cuda.synchronize()
+        return {"ang": job.ang, "dm": job.dm, "w": job.w, "dsca": job.out}, ([(x, y0 + row - 1) for x, row in zip(*job.outlets)], job.evaluated_cells(torch), st["rounds"])
+
+    h, extras = _eight_strips_to_host(nx, ny, size, rank_job, {"ang": np.float32, "dm": np.float32, "w": np.float32, "dsca": np.float32})
+    t1 = time.time()
+    outl = sorted(o for e in extras for o in e[0])
+    assert len(outl) == 64
+    ox, oy = np.array([o[0] for o in outl], dtype=np.int32), np.array([o[1] for o in outl], dtype=np.int32)
+    evaluated = int(np.count_nonzero(h["dsca"] != np.float32(-3.402823466e38)))
+    assert evaluated == sum(e[1] for e in extras)
+    bad, first, queued = oracle.dinfdecayaccum_check(h["ang"], h["dm"], h["dsca"], dx=1.0, dy=1.0, weights=h["w"], contcheck=True, outlets=(ox, oy))
+    assert bad == 0, f"{bad} cells do not follow from dmarea()'s expression / closure; first at row {first // nx} column {first % nx}"
+    assert 0 < evaluated <= queued, (evaluated, queued)
+    print(f"\nconfigs[4] at full height: {queued} cells in the 64 outlets' closure, {evaluated} evaluated (the rest contaminated); GPU + download {t1 - t0:.0f} s, host check {time.time() - t1:.0f} s")
