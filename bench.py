@@ -308,7 +308,21 @@ def config4_strip_leg(torch, ctx, seed, T):
                     "projected 8-GPU critical path); profiles/r05*_8strips_65536_d8.json"}
 
 
-def config4_8strips_leg(torch, T, args):
+def comm_latency_leg(ctx, nx=65536, reps=1000):
+    """Latency of the strip protocol's two collectives over RCCL with ONE rank talking to itself (all a one-GPU box can run: taudem_amd/csrc/comm.cpp,
+    tdx_rccl_latency): a grouped ncclSend/ncclRecv of one boundary row (nx float32) and the termination vote (ncclAllReduce of one device int64 + the
+    device-to-host read of the result + the wait for it).  No link is involved, so these are LOWER bounds of the latencies between GPUs; they replace the
+    assumed 10 / 30 us as the projection's defaults, next to a pessimistic 50 / 100 us."""
+    import ctypes as C
+    out = (C.c_double * 2)()
+    rc = ctx._lib.tdx_rccl_latency(ctx._h, reps, nx * 4, out)
+    if rc != 0:
+        raise RuntimeError("tdx_rccl_latency failed")
+    return {"rccl_one_rank_self": {"exchange_us": out[0], "vote_us": out[1], "bytes_per_direction": nx * 4, "repetitions": reps,
+                                   "note": "one rank sending to itself: the software path of a collective without a link - a lower bound of the 8-GPU latencies"}}
+
+
+def config4_8strips_leg(torch, T, args, rccl_latency_us=None, lone_stage_ms=None):
     """BASELINE.json configs[3] itself - the 65536 x 65536 raster in EIGHT strips of 65536 x 8192 - on the ONE GPU the driver gives this run: eight rank
     threads on the library's rank group (peer transport), every halo exchange, vote and cross-strip dependency of the 8-GPU protocol included.  One timed
     step with the ranks sharing the device (a functional figure, not a throughput), then one traced step with the ranks taking turns on it, from which
@@ -317,7 +331,11 @@ def config4_8strips_leg(torch, T, args):
     import copy
     a = copy.copy(args)
     a.workload, a.warmup, a.steps, a.segments, a.segments_out = "d8", 1, 1, 2, ""
+    a.rccl_latency_us = rccl_latency_us
     line = strips_in_process(torch, T, a, 8, 65536, 65536)
+    if lone_stage_ms and "projected_ngpu_ms" in line:   # work of the eight strips against eight lone strips (no neighbours): what the exchanges' re-relaxations add
+        line["projected_ngpu_ms"]["redundant_work"] = {k: v["sum_over_ranks_ms"] / (8.0 * lone_stage_ms[k]) for k, v in line["projected_ngpu_ms"]["per_stage"].items()
+                                                       if lone_stage_ms.get(k)}
     keep = ("ms_per_step", "stage_ms_per_step_rank0", "comm", "checks", "max_level_per_iteration", "projected_ngpu_ms")
     out = {"workload": line["config"]["workload"], "note": "eight ranks share ONE GPU: ms_per_step is functional only; projected_ngpu_ms is a projection, not a measurement"}
     out.update({k: line[k] for k in keep if k in line})
@@ -437,6 +455,13 @@ def strips_in_process(torch, T, args, world, nx, ny):
                     st = step()
                 torch.cuda.synchronize(); bar.wait()
                 res["elapsed"] = time.perf_counter() - t0
+                if args.segments:   # the group's own transport: one exchange / one vote as the protocol issues them, all ranks at once
+                    import ctypes as C
+                    lat = (C.c_double * 2)()
+                    bar.wait()
+                    if lib.tdx_comm_latency(c._h, comm.ptr(), 200, nx * 4, lat) == 0:
+                        res["latency_us"] = (lat[0], lat[1])
+                    bar.wait()
                 if args.segments:   # one more step, traced (mode 2: the rank threads take turns on the device - not a step to time)
                     c.set_option("segment_trace", args.segments)
                     bar.wait()
@@ -492,11 +517,21 @@ def strips_in_process(torch, T, args, world, nx, ny):
     if args.segments:
         from taudem_amd.distributed import project_critical_path
         logs = [r["segments"] for r in res]
-        proj = project_critical_path(logs)
+        # collective latencies of the projection: the RCCL figures measured on this box with one rank (a lower bound: no link), if the caller has them
+        # (args.rccl_latency_us), else the assumed 10 / 30 us; the sensitivity rows show what the projection does with slower collectives
+        meas = getattr(args, "rccl_latency_us", None)
+        ex_us, vote_us = (meas if meas else (10.0, 30.0))
+        proj = project_critical_path(logs, ex_us, vote_us)
         line["projected_ngpu_ms"] = {"per_step": proj["total_ms"],
                                      "per_stage": {k: {kk: vv for kk, vv in v.items() if kk != "phases"} for k, v in proj["per_stage"].items()},
                                      "phases": {k: v["phases"] for k, v in proj["per_stage"].items()},
-                                     "assumed": proj["assumed"]}
+                                     "assumed": dict(proj["assumed"], source="measured: RCCL, one rank to itself (lower bound)" if meas else "assumed"),
+                                     "sensitivity": [{"exchange_us": e, "vote_us": v, "per_step": project_critical_path(logs, e, v)["total_ms"]}
+                                                     for e, v in ((10.0, 30.0), (ex_us, vote_us), (50.0, 100.0))]}
+        if all("latency_us" in r for r in res):
+            line.setdefault("comm", {})["latency_us"] = {"transport": transport + " (in-process rank group, " + str(world) + " rank threads on " + str(len(set(devices))) + " GPU(s))",
+                                                        "exchange_us": max(r["latency_us"][0] for r in res), "vote_us": max(r["latency_us"][1] for r in res),
+                                                        "note": "one boundary-row exchange / one termination vote as the protocol issues them, slowest rank, 200 repetitions"}
         if args.segments_out:
             with open(args.segments_out, "w") as f:
                 json.dump({"world": world, "nx": nx, "ny": ny, "workload": args.workload, "steps": 1, "mode": args.segments, "logs": logs}, f)
@@ -743,10 +778,19 @@ def main():
                     out[key] = {"error": f"{e.__class__.__name__}: {e}"}
                 torch.cuda.empty_cache()
             # last: the eight strips need ~190 GB of their own - this context's scratch arena (sized by config3) goes first
+            rccl_us = None
+            try:
+                out["comm_latency_us"] = comm_latency_leg(ctx)
+                rccl_us = (out["comm_latency_us"]["rccl_one_rank_self"]["exchange_us"], out["comm_latency_us"]["rccl_one_rank_self"]["vote_us"])
+            except Exception as e:   # noqa: BLE001
+                out["comm_latency_us"] = {"error": f"{e.__class__.__name__}: {e}"}
             ctx.close()
             torch.cuda.empty_cache()
             try:
-                out["config4_8strips_one_gpu"] = config4_8strips_leg(torch, T, args)
+                lone = out.get("config4_strip", {}).get("stage_ms")
+                out["config4_8strips_one_gpu"] = config4_8strips_leg(torch, T, args, rccl_us, lone)
+                if "comm" in out["config4_8strips_one_gpu"] and "latency_us" in out["config4_8strips_one_gpu"]["comm"]:
+                    out["comm_latency_us"]["peer_8_rank_threads_one_gpu"] = out["config4_8strips_one_gpu"]["comm"]["latency_us"]
             except Exception as e:   # noqa: BLE001
                 out["config4_8strips_one_gpu"] = {"error": f"{e.__class__.__name__}: {e}"}
         line = json.dumps(out)

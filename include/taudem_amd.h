@@ -300,6 +300,11 @@ void tdx_rccl_comm_counters(const tdx_rccl_comm* c, int64_t* exchanges, int64_t*
 void tdx_rccl_comm_destroy(tdx_rccl_comm* c);
 /* loop-back self test of the transport on one rank (send/recv to self + all-reduce): 0 = the RCCL calls work on this box */
 int tdx_rccl_selftest(tdx_context* ctx);
+/* latencies of the two primitives as the strip protocol uses them, microseconds per repetition (collective: every rank of `comm` calls it):
+ * out_us[0] one boundary-row exchange of `bytes` per direction, out_us[1] one termination vote (all-reduce of one device int64 + read-back + wait) */
+int tdx_comm_latency(tdx_context* ctx, const tdx_comm* comm, int32_t reps, uint64_t bytes, double* out_us);
+/* the same for RCCL with ONE rank sending to itself (what a one-GPU box can run): a lower bound of the latencies between GPUs */
+int tdx_rccl_latency(tdx_context* ctx, int32_t reps, uint64_t bytes, double* out_us);
 
 typedef struct tdx_group tdx_group;
 /* devices[size]: HIP device of every rank (repeats allowed: several ranks then share a GPU and the peer transport is used) */

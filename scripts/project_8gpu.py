@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--exchange-us", type=float, default=10.0)
     ap.add_argument("--vote-us", type=float, default=30.0)
     ap.add_argument("--use", choices=("wall", "device"), default="wall")
+    ap.add_argument("--lone-ms", default="", help="stage=ms,... of ONE strip without neighbours (bench.py: config4_strip.stage_ms): prints the eight strips' work "
+                                                 "against eight lone strips (\"redundant work\": what the re-relaxations after the exchanges add)")
     a = ap.parse_args()
     d = json.load(open(a.trace))
     logs = [[tuple(s) for s in lg] for lg in d["logs"]]
@@ -41,6 +43,18 @@ def main():
         for pk, pv in v["phases"].items():
             print(f"|   {k} / {pk} | | | | | | {pv / steps:.2f} | |")
     print(f"| total | | | | | | {proj['total_ms'] / steps:.2f} | |")
+    # how much of the projection is the ASSUMED collective latency: the same trace at three pairs of (exchange, vote) microseconds
+    print("| sensitivity: exchange us / vote us | projected ms |")
+    print("|---|---|")
+    for e, v in ((10.0, 30.0), (a.exchange_us, a.vote_us), (50.0, 100.0)):
+        print(f"| {e:g} / {v:g} | {project_critical_path(logs, e, v, a.use)['total_ms'] / steps:.2f} |")
+    if a.lone_ms:
+        lone = {k: float(v) for k, v in (kv.split("=") for kv in a.lone_ms.split(","))}
+        print("| stage | sum over ranks ms | world x lone strip ms | redundant work |")
+        print("|---|---|---|---|")
+        for k, v in proj["per_stage"].items():
+            if k in lone:
+                print(f"| {k} | {v['sum_over_ranks_ms'] / steps:.1f} | {d['world'] * lone[k]:.1f} | {v['sum_over_ranks_ms'] / steps / (d['world'] * lone[k]):.2f} x |")
     print(json.dumps({"projected_ngpu_ms_per_step": proj["total_ms"] / steps, "assumed": proj["assumed"]}))
 
 

@@ -188,6 +188,8 @@ _SIGNATURES = {
     "tdx_rccl_comm_counters": (None, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "tdx_rccl_comm_destroy": (None, [_P]),
     "tdx_rccl_selftest": (C.c_int, [_P]),
+    "tdx_comm_latency": (C.c_int, [_P, _P, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
+    "tdx_rccl_latency": (C.c_int, [_P, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
     "tdx_context_comm_counters": (None, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tdx_context_segments": (_I64, [_P, C.POINTER(TdxSegment), _I64]),
     "tdx_group_create": (C.c_int, [C.c_int32, _P, _I64, C.POINTER(_P)]),

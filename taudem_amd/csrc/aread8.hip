@@ -294,6 +294,15 @@ constexpr float BIG_MARK = -2.0f;                // provisional ad8 of a cell aw
 // Geometry of one strip: tiles cover the OWNED rows [y0, y1) of an array of ny_arr rows; the rows y0-1
 // and y1 (when inside the array) are halo rows owned by the neighbouring ranks.  Every cell that can
 // carry a crossing has a node id: perimeter cells of the tiles first, then the 2 x nx halo cells.
+// start of a tile-contraction call: stage counters = 0, node_indeg / node_next = "none" (all ones), out- / in-boxes (4 nx words) and delivered marks (2 nx bytes) = 0
+static __global__ __launch_bounds__(256) void ad8_init_kernel(unsigned long long* __restrict__ d_cnt, uint32_t* __restrict__ node_indeg, uint32_t* __restrict__ node_next, size_t nnodes,
+                                                              unsigned long long* __restrict__ boxes, uint8_t* __restrict__ delivered, size_t nx) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < 8) d_cnt[i] = 0ull;
+    if (i < nnodes) { node_indeg[i] = 0xFFFFFFFFu; node_next[i] = 0xFFFFFFFFu; }
+    if (i < 4 * nx) boxes[i] = 0ull;
+    if (i < 2 * nx) delivered[i] = 0;
+}
 struct Ad8Geom {
     int nx, ny_arr, y0, y1, tiles_x, tiles_y;
     uint32_t nnodes_local;   // tiles * 256
@@ -1279,11 +1288,9 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
     strip_mark(ctx, st, "aread8");
     int rc = strip_exchange<int16_t>(ctx, st, d_p, p_nodata);   // directions of the neighbours' boundary rows
     if (rc != TDX_OK) return rc;
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(node_indeg, 0xFF, nnodes * 4, s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(node_next, 0xFF, nnodes * 4, s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(boxes, 0, size_t(st.nx) * 4 * 8, s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(delivered, 0, size_t(st.nx) * 2, s));
+    // (one launch instead of five runtime fills: the stage counters, the node arrays, the per-column boxes and their "delivered" marks)
+    hipLaunchKernelGGL(ad8_init_kernel, dim3(tdx_blocks_for(std::max(nnodes, size_t(st.nx) * 4), 256)), dim3(256), 0, s, d_cnt, node_indeg, node_next, nnodes, boxes,
+                       delivered, size_t(st.nx));
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         static const bool ad8_debug = getenv("TDX_AD8_DEBUG") != nullptr;

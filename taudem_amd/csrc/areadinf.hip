@@ -764,7 +764,7 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                                     uint32_t* lnext, unsigned pull_max) { launch(small, rg, grid, ls, list, count, fcur, fnext, lnext, pull_max); };
             run.print_counts = dbg_rounds;
             if (dbg_rounds) fprintf(stderr, "\ndinf sweep rounds(%d tiles of %d):", run.ntiles, small ? bulk_ts : 64);
-            if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
+            if (dbg) TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 80));
             int last_printed = -1;
             int rcl = run.start();
             if (rcl != TDX_OK) return rcl;
@@ -775,12 +775,13 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 run.collect();
                 if (dbg) {   // per batch of rounds: average phase times (us) and hops per activation
-                    TDX_HIP_CHECK(ctx, hipMemcpy(ctx->h_mail + TDX_MAIL_DBG_SWEEP, dbg, 64, hipMemcpyDeviceToHost));
-                    TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 64));
+                    TDX_HIP_CHECK(ctx, hipMemcpy(ctx->h_mail + TDX_MAIL_DBG_SWEEP, dbg, 80, hipMemcpyDeviceToHost));
+                    TDX_HIP_CHECK(ctx, hipMemset(dbg, 0, 80));
                     const double na = double(ctx->h_mail[TDX_MAIL_DBG_SWEEP + 7] ? ctx->h_mail[TDX_MAIL_DBG_SWEEP + 7] : 1);
-                    fprintf(stderr, "\n  [rounds %d..%lld] activations %.0f: stage %.1f scan+bulk %.1f walks %.1f writeback %.1f us; hops/act %.1f, busiest lane %.1f, phases %.2f\n",
+                    fprintf(stderr, "\n  [rounds %d..%lld] activations %.0f: stage %.1f scan+bulk %.1f walks %.1f writeback %.1f us; hops/act %.1f, busiest lane %.1f, phases %.2f; of the records staged %.1f %% were pending, %.1f %% were evaluated\n",
                             last_printed + 1, (long long)run.rounds - 1, na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 0] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 1] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 2] / na / 100.0,
-                            ctx->h_mail[TDX_MAIL_DBG_SWEEP + 3] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 4] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 5] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 6] / na);
+                            ctx->h_mail[TDX_MAIL_DBG_SWEEP + 3] / na / 100.0, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 4] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 5] / na, ctx->h_mail[TDX_MAIL_DBG_SWEEP + 6] / na,
+                            100.0 * double(ctx->h_mail[TDX_MAIL_DBG_SWEEP + 8]) / (na * double(small ? bulk_ts * bulk_ts : 4096)), 100.0 * double(ctx->h_mail[TDX_MAIL_DBG_SWEEP + 9]) / (na * double(small ? bulk_ts * bulk_ts : 4096)));
                     last_printed = int(run.rounds) - 1;
                 }
                 if (!run.done && stop_at > 0 && run.last_count <= stop_at) { *active_left = true; *parity_out = run.parity; break; }

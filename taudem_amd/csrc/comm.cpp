@@ -268,6 +268,92 @@ extern "C" int tdx_rccl_selftest(tdx_context* ctx) {
     return TDX_OK;
 }
 
+// Latencies of the transport's two primitives as the strip protocol uses them (strips.hpp), `reps` repetitions each, microseconds per repetition:
+//   out_us[0]  one boundary-row exchange (bytes per direction) + what the protocol does around it: the pre-exchange synchronisation of a
+//              host-synchronous transport, none for a stream-ordered one - and ONE stream synchronisation at the very end (exchanges are followed by
+//              device work, not by a host wait)
+//   out_us[1]  one termination vote: all-reduce of one int64 that lives in device memory + the device-to-host read of the result + the wait for it
+//              (strip_allreduce_device), i.e. the host-visible round trip every outer round ends with
+// Collective: every rank of the communicator calls it with the same arguments.  comm == NULL: out_us = 0.
+extern "C" int tdx_comm_latency(tdx_context* ctx, const tdx_comm* comm, int32_t reps, uint64_t bytes, double* out_us) {
+    if (!ctx || !out_us || reps < 1) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm_latency: bad argument");
+    out_us[0] = out_us[1] = 0.0;
+    if (!comm) return TDX_OK;
+    if (bytes > comm->capacity) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_comm_latency: more bytes than the exchange buffers hold");
+    TDX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const bool ordered = (comm->flags & TDX_COMM_STREAM_ORDERED) != 0;
+    unsigned long long* d_v = reinterpret_cast<unsigned long long*>(ctx->d_mail) + TDX_MAIL_STRIP_CHANGED;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int pass = 0; pass < 2; pass++) {   // pass 0: warm-up (connections are set up by the first collective)
+        const int n = pass ? reps : std::min(reps, 8);
+        TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        double t0 = now();
+        for (int i = 0; i < n; i++) {
+            if (!ordered) TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            if (comm->exchange(comm->user, bytes) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm_latency: exchange failed: " + g_tdx_thread_error);
+        }
+        TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        out_us[0] = (now() - t0) / n;
+        t0 = now();
+        for (int i = 0; i < n; i++) {
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(d_v, 0, 8, s));
+            int64_t v = 0;
+            if (comm->allreduce_dev) {
+                if (comm->allreduce_dev(comm->user, reinterpret_cast<int64_t*>(d_v), 1, TDX_OP_SUM) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm_latency: allreduce_dev failed: " + g_tdx_thread_error);
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, 8, hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            } else {
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail + TDX_MAIL_STRIP_REDUCE, d_v, 8, hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                if (comm->allreduce(comm->user, &v, 1, TDX_OP_SUM) != 0) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_comm_latency: allreduce failed: " + g_tdx_thread_error);
+            }
+        }
+        out_us[1] = (now() - t0) / n;
+    }
+    return TDX_OK;
+}
+
+// The same two figures for RCCL with ONE rank talking to itself (the only RCCL configuration a one-GPU box can run: a send / recv pair of `bytes`
+// to rank 0 in one group, and the device all-reduce + read-back): the software path of a collective - enqueue, proxy, kernel launch, completion -
+// without a link in it, i.e. a LOWER bound of the latencies between GPUs.  out_us[0] exchange, out_us[1] vote.
+extern "C" int tdx_rccl_latency(tdx_context* ctx, int32_t reps, uint64_t bytes, double* out_us) {
+    if (!ctx || !out_us || reps < 1 || bytes < 1) return tdx_fail(ctx, TDX_ERR_ARG, "tdx_rccl_latency: bad argument");
+    unsigned char id[TDX_RCCL_ID_BYTES];
+    int rc = tdx_rccl_unique_id(id);
+    if (rc != TDX_OK) return rc;
+    tdx_rccl_comm* r = nullptr;
+    rc = tdx_rccl_comm_create(ctx, id, 0, 1, int64_t((bytes + 15) / 16), &r);
+    if (rc != TDX_OK) return rc;
+    RcclApi& a = rccl();
+    hipStream_t s = ctx->stream;
+    int fail = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int pass = 0; pass < 2 && !fail; pass++) {
+        const int n = pass ? reps : std::min(reps, 8);
+        if (hipStreamSynchronize(s) != hipSuccess) fail = 1;
+        double t0 = now();
+        for (int i = 0; i < n && !fail; i++) {
+            if (a.GroupStart() != ncclSuccess) { fail = 2; break; }
+            const bool sent = a.Send(r->c.send_up, bytes, ncclChar, 0, r->comm, s) == ncclSuccess && a.Recv(r->c.recv_down, bytes, ncclChar, 0, r->comm, s) == ncclSuccess;
+            if (a.GroupEnd() != ncclSuccess || !sent) fail = 2;
+        }
+        if (!fail && hipStreamSynchronize(s) != hipSuccess) fail = 3;
+        out_us[0] = (now() - t0) / n;
+        t0 = now();
+        for (int i = 0; i < n && !fail; i++) {
+            if (hipMemsetAsync(r->d_red, 0, 8, s) != hipSuccess) fail = 4;
+            if (!fail && r->c.allreduce_dev(r, r->d_red, 1, TDX_OP_SUM) != 0) fail = 4;
+            if (!fail && hipMemcpyAsync(r->h_red, r->d_red, 8, hipMemcpyDeviceToHost, s) != hipSuccess) fail = 4;
+            if (!fail && hipStreamSynchronize(s) != hipSuccess) fail = 4;
+        }
+        out_us[1] = (now() - t0) / n;
+    }
+    tdx_rccl_comm_destroy(r);
+    if (fail) return tdx_fail(ctx, TDX_ERR_HIP, "tdx_rccl_latency failed at step " + std::to_string(fail) + (g_tdx_thread_error.empty() ? "" : ": " + g_tdx_thread_error));
+    return TDX_OK;
+}
+
 // ---- one process, N rank threads ---------------------------------------------------------------------------------------
 struct tdx_group {
     int size = 0;

@@ -566,6 +566,7 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
 
     ctx->begin_call(stats);
     strip_mark(ctx, st, "d8flowdir");
+    ctx->phase = "slope pass";
     rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
@@ -626,7 +627,9 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
         bool old_list_valid = false;        // ... and whether qnext really holds them
         LV *lvl_next = nullptr, *rq_next = nullptr;   // the next iteration's markers, written by the streaming setFlow2 (rasters of their own)
         bool markers_ready = false;
-        for (;;) {
+        for (int iteration = 1;; iteration++) {
+            const FlatPhases& ph = flat_phases(iteration);
+            ctx->phase = ph.classify;
             // every call re-creates elev2 / dn (src/d8.cpp:483-486): the streaming classification rewrites all markers
             FlatLevels fl;
             D8Traits tr{d_p};
@@ -653,11 +656,13 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
             }
             markers_ready = false;
             // (the first queue of a dense strip exists as bit masks only: no list)
-            rc = flats_bfs<D8Traits, LV>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify);
+            rc = flats_bfs<D8Traits, LV>(ctx, tr, zcur, st, (nq_old == 0 && !have_list) ? nullptr : qlist, nq, fbuf, &fl, stats, sparse ? nullptr : &classify, iteration);
             if (rc != TDX_OK) return rc;
+            ctx->phase = ph.directions;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
-                TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+                // (the queue-length counter of the next iteration is word 4 of the stage counters: cleared by flatk::prepare_kernel of THIS iteration, untouched since)
+                unsigned long long* d_next = d_cnt + 4;
                 if (nq > n / 32) {   // dense queue: one streaming pass
                     const int nbx = (st.nx + SF2_COLS - 1) / SF2_COLS;
                     const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
@@ -668,15 +673,15 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
                         if (!lvl_next || !rq_next) return TDX_ERR_NOMEM;
                     }
                     hipLaunchKernelGGL((d8_setflow2_stream_kernel<LV>), grid, dim3(256), 0, s, zcur, inx, st.ny_arr, st.y0, st.y1, d_fact, lvl, rq, fl, d_p, qnext,
-                                       d_cnt, nbx, tdx_xcd_map() ? 1 : 0, lvl_next, rq_next);
+                                       d_next, nbx, tdx_xcd_map() ? 1 : 0, lvl_next, rq_next);
                     markers_ready = lvl_next != nullptr;
                 } else if (nq) {
                     if (fl.has_pits)
                         hipLaunchKernelGGL((d8_mark_pits_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_p);
                     hipLaunchKernelGGL((d8_setflow2_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_fact, qlist, nq, lvl, rq, fl, d_p);
-                    hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_cnt);
+                    hipLaunchKernelGGL(d8_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_p, qlist, nq, qnext, d_next);
                 }
-                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_next, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
             }
@@ -688,6 +693,7 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
             if (rc != TDX_OK) return rc;
             if (stats) { stats->flat_iterations++; stats->flats_left = total; }
             if (!(total > 0 && total < last)) break;     // src/d8.cpp:307
+            ctx->phase = ph.next;
             // another iteration: elevDEM := (float)elev2 for ALL cells (src/d8.cpp:669-675)
             if (!zwork) {
                 zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4));

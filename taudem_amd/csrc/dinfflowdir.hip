@@ -521,6 +521,7 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
 
     ctx->begin_call(stats);
     strip_mark(ctx, st, "dinfflowdir");
+    ctx->phase = "slope pass";
     int rc = strip_exchange<float>(ctx, st, d_fel, fel_nodata);   // elevation halo rows
     if (rc != TDX_OK) return rc;
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
@@ -570,23 +571,27 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
         int64_t last = total;
         bool first = true;
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
-        for (;;) {
+        for (int iteration = 1;; iteration++) {
+            const FlatPhases& ph = flat_phases(iteration);
+            ctx->phase = ph.classify;
             if (!first) { rc = flats_reset_markers_after(ctx, st, qnext, nq_old, qlist, nq, lvl, rq); if (rc != TDX_OK) return rc; }
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
-            rc = flats_bfs<DinfTraits, LV>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats);
+            rc = flats_bfs<DinfTraits, LV>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, nullptr, iteration);
             if (rc != TDX_OK) return rc;
+            ctx->phase = ph.directions;
             {
                 TdxSpan sp(ctx, TDX_K_FLATDIR);
-                TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+                // (the queue-length counter of the next iteration is word 4 of the stage counters: cleared by flatk::prepare_kernel of THIS iteration, untouched since)
+                unsigned long long* d_next = d_cnt + 4;
                 if (nq) {
                     if (fl.has_pits)
                         hipLaunchKernelGGL((dinf_mark_pits_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, qlist, nq, lvl, d_ang);
                     hipLaunchKernelGGL((dinf_set2flat_kernel<LV>), dim3(tdx_blocks_for(nq, 256)), dim3(256), 0, s, zcur, inx, d_geom, qlist, nq, lvl, rq, fl, d_ang);
-                    hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_cnt);
+                    hipLaunchKernelGGL(dinf_recollect_kernel, dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, d_ang, qlist, nq, qnext, d_next);
                 }
-                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_next, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 if (stats) stats->launches[TDX_K_FLATDIR] += 2 + (fl.has_pits ? 1 : 0);
             }
@@ -598,6 +603,7 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
             if (rc != TDX_OK) return rc;
             if (stats) { stats->flat_iterations++; stats->flats_left = total; }
             if (!(total > 0 && total < last)) break;     // src/dinf.cpp:230
+            ctx->phase = ph.next;
             if (!zwork) { zwork = static_cast<float*>(ctx->scratch(TDX_S_I, n * 4)); if (!zwork) return TDX_ERR_NOMEM; }
             // src/dinf.cpp:822-828 (only where the next iteration reads it when few flats are left)
             rc = nleft <= n / 32 ? flats_overwrite_elevation_sparse(ctx, inx, qnext, nleft, lvl, rq, fl, zwork) : flats_overwrite_elevation(ctx, n, lvl, rq, fl, zwork);

@@ -34,6 +34,16 @@
 #include "tile_relax.hpp"
 
 struct FlatLevels { int T; int Tr; int has_pits; };
+// phases of a flow-direction call in the segment trace (context.hpp: static strings, the same on every rank): the slope pass, then per call of
+// resolveflats() (src/d8.cpp:307-316) the classification, the two level fields, the directions (setFlow2 / SET2) and the next iteration's elevations
+struct FlatPhases { const char *classify, *levels, *stats, *directions, *next; };
+static inline const FlatPhases& flat_phases(int iteration) {   // iteration = 1, 2, 3 ... (4 and later share one name)
+    static const FlatPhases P[4] = {{"flats 1: classify", "flats 1: level fields", "flats 1: statistics", "flats 1: directions", "flats 1: next elev"},
+                                    {"flats 2: classify", "flats 2: level fields", "flats 2: statistics", "flats 2: directions", "flats 2: next elev"},
+                                    {"flats 3: classify", "flats 3: level fields", "flats 3: statistics", "flats 3: directions", "flats 3: next elev"},
+                                    {"flats 4+: classify", "flats 4+: level fields", "flats 4+: statistics", "flats 4+: directions", "flats 4+: next elev"}};
+    return P[iteration < 1 ? 0 : (iteration > 4 ? 3 : iteration - 1)];
+}
 // Level markers are stored as int16, like the reference's elev2 / dn / s partitions (SHORT_TYPE, src/d8.cpp:483,486,595): half the
 // bytes of every tile image, classification pass and list gather.  Levels saturate at LVL_SAT, which flats_bfs reports as an error
 // (the reference's int16 counters overflow there too).
@@ -124,6 +134,7 @@ struct LevelPlainT {
     using CellRaw = uint8_t;
     __device__ __forceinline__ S load_raw(size_t idx) const { return G[idx]; }
     static __device__ __forceinline__ int decode(S g) { return g > 0 ? int(g) : inf(); }
+    static __device__ __forceinline__ bool raw_can_move(S g) { return g >= 0; }   // a negative marker = outside the queue: its mask byte may be stale (flats_bfs)
     __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = S(sizeof(S) == 2 && v > LVL_SAT ? LVL_SAT : v); }
     __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
     static __device__ __forceinline__ void cell_decode(uint8_t m, int& lock, unsigned& mask) { lock = m ? 0 : inf(); mask = m; }
@@ -155,6 +166,7 @@ struct LevelOpT {
     using CellRaw = uint8_t;
     __device__ __forceinline__ S load_raw(size_t idx) const { return G[idx]; }
     static __device__ __forceinline__ int decode(S g) { return g > 0 ? int(g) : inf(); }
+    static __device__ __forceinline__ bool raw_can_move(S g) { return g >= 0; }   // (the closure's marks are 0 / 1: always true there)
     __device__ __forceinline__ void store(size_t idx, int v) const { G[idx] = S(v); }
     __device__ __forceinline__ uint8_t cell_raw(size_t idx) const { return M[idx]; }
     static __device__ __forceinline__ void cell_decode(uint8_t m, int& cst, unsigned& mask) { cst = 0; mask = m; }
@@ -313,6 +325,16 @@ static __global__ __launch_bounds__(256) void flat_stats_stream8_kernel(const in
     }
 }
 
+// What a flat iteration needs cleared before its classification, in ONE launch (they were five runtime fills): the stage counters, the activation flags, the
+// per-tile "needs its masks" marks (tm_mode 0: none, 1: every tile, 2: the first half - the TDX_FLATS_MASKED hooks) and the count rings of both round schedules.
+static __global__ __launch_bounds__(256) void prepare_kernel(unsigned long long* __restrict__ d_cnt, uint32_t* __restrict__ flags0, uint8_t* __restrict__ tmask, int ntiles,
+                                                             int tm_mode, unsigned long long* __restrict__ countsA, unsigned long long* __restrict__ countsB) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 8) d_cnt[t] = 0ull;
+    if (t < ntiles) { flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2)); }
+    if (t < 2 * tilek::COUNT_RING) { countsA[t] = 0ull; if (countsB) countsB[t] = 0ull; }
+}
+
 template <class LV>
 static __global__ __launch_bounds__(256) void reset_q_kernel(const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
                                                       LV* __restrict__ rq) {
@@ -441,8 +463,10 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked)>;
 template <class Traits, class LV>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
-                     FlatBuffersT<LV> b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr) {
+                     FlatBuffersT<LV> b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr, int iteration = 1) {
     using LOp = flatk::LevelOpT<1, LV>;
+    const FlatPhases& ph = flat_phases(iteration);
+    ctx->phase = ph.classify;
     hipStream_t s = ctx->stream;
     const int nx = st.nx;
     const size_t n = size_t(nx) * size_t(st.ny_arr);
@@ -461,45 +485,57 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     const bool no_plain = e_masked && e_masked[0] == '1';
     const bool half_plain = e_masked && e_masked[0] == '2';
     TdxSpan sp(ctx, TDX_K_BFS);
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(flags0, 0, size_t(ntiles) * 4, s));
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(tmask, no_plain ? 1 : 0, size_t(ntiles), s));
-    if (half_plain) TDX_HIP_CHECK(ctx, hipMemsetAsync(tmask, 1, size_t(ntiles + 1) / 2, s));
+    static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;
+    static const bool strips_sequential = getenv("TDX_FLATS_STRIPS_SEQUENTIAL") != nullptr;   // (A/B hook: one field after the other in a multi-strip run)
+    const bool pair = !(st.multi() && strips_sequential) && !ctx->kernel_timing && !no_pair;
+    // second schedule of the pair (own flags / list / counts)
+    uint32_t* flagsB = pair ? static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS))) : nullptr;
+    unsigned long long* countsB = pair ? static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16)) : nullptr;
+    if (pair && (!flagsB || !countsB)) return TDX_ERR_NOMEM;
+    hipLaunchKernelGGL(flatk::prepare_kernel, dim3(tdx_blocks_for(size_t(std::max(ntiles, 2 * tilek::COUNT_RING)), 256)), dim3(256), 0, s, d_cnt, flags0, tmask, ntiles,
+                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB);
     if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask);
     else {
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
-        TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
+        // The list classification writes the masks of the QUEUE's cells only.  The register tile kernel reads a mask byte only where the level marker says
+        // "in the queue" (LevelOpT::raw_can_move), so what other cells hold - a mask of an earlier iteration, or nothing yet - is never looked at; only the
+        // LDS-resident tile kernel and the worklist schedule (test hooks), which decode masks without the marker, need the two rasters cleared (read per call: the hooks are).
+        const bool clear_masks = getenv("TDX_RELAX_LDS") != nullptr || getenv("TDX_RELAX_ASYNC") != nullptr || getenv("TDX_FLATS_CLEAR_MASKS") != nullptr;
+        if (clear_masks) {
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(fmask, 0, n, s));
+            TDX_HIP_CHECK(ctx, hipMemsetAsync(rmask, 0, n, s));
+        }
         if (nq)
             hipLaunchKernelGGL((flatk::classify_kernel<Traits, LV>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
                                geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask);
     }
     int rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;
+    ctx->phase = ph.levels;
     rc = strip_exchange<LV>(ctx, st, b.rq, LV(-1));
     if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
-    static const bool no_pair = getenv("TDX_FLATS_SEQUENTIAL") != nullptr;
-    static const bool strips_sequential = getenv("TDX_FLATS_STRIPS_SEQUENTIAL") != nullptr;   // (A/B hook: one field after the other in a multi-strip run)
-    if (!(st.multi() && strips_sequential) && !ctx->kernel_timing && !no_pair) {
+    if (pair) {
         // the two level fields are independent: relax them side by side on two streams (own flags / list / counts each)
-        uint32_t* flagsB = static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS)));
-        unsigned long long* countsB = static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16));
-        if (!flagsB || !countsB) return TDX_ERR_NOMEM;
         uint32_t* listB = flagsB + ntiles;
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        TDX_HIP_CHECK(ctx, hipMemcpyAsync(flagsB, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
         // two round schedules on two HIP streams; TDX_FLATS_FUSED=1 (read per call): one launch per round for both fields on one stream - 0.5 ms slower at 16384^2
         // (a round ends when the slower field's does), but independent of how the runtime schedules two streams
         const bool two_streams = getenv("TDX_FLATS_FUSED") == nullptr || getenv("TDX_RELAX_LDS") != nullptr;
+        // round 0 of both schedules from the classification's flags in one launch (two streams); the fused form starts its runners itself
+        const uint32_t* start_flags = two_streams ? flags0 : nullptr;
+        if (!two_streams) {
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+            TDX_HIP_CHECK(ctx, hipMemcpyAsync(flagsB, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
+        }
         // Multi-strip: both fields to their strip-local fixed points side by side, then BOTH boundary rows are exchanged and one vote decides - the outer
         // rounds are those of the deeper field instead of the sum of both, and the shallower field's relaxation hides behind the deeper one's
         // (profiles/r05b_*: incrise's 6.7 + 1.5 ms of the critical path at BASELINE.json configs[3] ran after incfall's 27 ms).
         for (;;) {
             rc = two_streams ? tile_relax_run_pair(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
-                                                   LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches)
+                                                   LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches, start_flags)
                              : tile_relax_run_fused(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
                                                     LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
             if (rc != TDX_OK) return rc;
+            start_flags = nullptr;   // (later outer rounds start from what the exchanges flagged)
             if (!st.multi()) break;
             int64_t ch_fall = 0, ch_rise = 0;
             rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1), flags, geom.tiles_x, &ch_fall);
@@ -521,7 +557,8 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         rc = flats_relax_field<LOp>(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
         if (rc != TDX_OK) return rc;
     }
-    TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    ctx->phase = ph.stats;
+    // (the stage counters were cleared by prepare_kernel and nothing of this function has touched them since)
     if (nq && qlist) hipLaunchKernelGGL((flatk::flat_stats_kernel<LV>), dim3(tdx_blocks_for(nq, 2048)), dim3(256), 0, s, qlist, nq, b.lvl, b.rq, d_cnt);
     else if (nq) {   // no list (dense first queue of D8FlowDir): one pass over the owned rows
         const size_t first = size_t(st.y0) * size_t(nx), count = size_t(st.y1 - st.y0) * size_t(nx);

@@ -291,13 +291,11 @@ static inline Strip pit_level_strip(const Strip& st, int nxc, int nyc) {
 template <int NBR>
 static int pit_relax_level(tdx_context* ctx, const Strip& ls, const float* Z, float* W, tilek::Sched sc, int64_t* rounds, int64_t* launches, int64_t* outer,
                            bool all_tiles = true) {
-    hipStream_t s = ctx->stream;
     const tilek::TileGeom g = tilek::make_geom(ls.nx, ls.ny_arr, ls.y0, ls.y1);
-    const int ntiles = g.tiles_x * g.tiles_y;
-    if (all_tiles)   // round 0: every tile is active (otherwise: the tiles flagged in sc.flags)
-        hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, sc.flags, tilek::FLAG_FULL, size_t(ntiles));
     for (;;) {
-        int rc = tile_relax_run(ctx, PitOp<NBR>{Z, W}, g, sc, rounds, launches);
+        // round 0: every tile is active (one set-up launch: tilek::all_start_kernel), otherwise / later: the tiles flagged in sc.flags
+        int rc = tile_relax_run(ctx, PitOp<NBR>{Z, W}, g, sc, rounds, launches, all_tiles);
+        all_tiles = false;
         if (rc != TDX_OK) return rc;
         if (outer) (*outer)++;
         if (!ls.multi()) break;
@@ -415,9 +413,8 @@ static int pitremove_impl(tdx_context* ctx, const Strip& st, float* d_dem, const
         // one coarse correction after the first fine rounds (see pit_restrict_kernel); TDX_PIT_VCYCLE_AFTER=n: after n rounds (0: never)
         const int vc_env = getenv("TDX_PIT_VCYCLE_AFTER") ? std::max(0, atoi(getenv("TDX_PIT_VCYCLE_AFTER"))) : 8;   // (read per call: test hook)
         if (used_coarse && vc_env > 0) {
-            hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, size_t(ntiles));
             bool left = false;
-            rc = tile_relax_run_bounded(ctx, PitOp<8>{d_dem, d_fel}, geom, sched, vc_env, &left, &rounds, &launches);
+            rc = tile_relax_run_bounded(ctx, PitOp<8>{d_dem, d_fel}, geom, sched, vc_env, &left, &rounds, &launches, true);   // (round 0: every tile)
             if (rc != TDX_OK) return rc;
             all_tiles = false;   // what is still active stays flagged
             // A correction costs a pass over the fine surface, a coarse relaxation and a restart of the fine schedule (~1 ms at 16384^2): it pays when the fine

