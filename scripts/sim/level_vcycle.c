@@ -23,20 +23,30 @@ static const int d1[9] = {0, 1, 1, 0, -1, -1, -1, 0, 1}, d2[9] = {0, 0, -1, -1, 
 static inline int opp(int k) { return ((k - 1 + 4) & 7) + 1; }
 static inline int val(int32_t g) { return g > 0 ? g : INF; }
 
+static int g_chain = 0;          // 1: a tile that is activated and is FULL / PLAIN (every cell movable with all 8 neighbours eligible) is processed in the round that activates it, transitively
 typedef struct {
     int nx, ny, inc, tx, ty;
     int32_t* v;
     uint8_t* m;
     uint8_t* act;    // per tile: 0 idle, 1 halo, 2 full
     uint8_t* nxt;
-    long rounds, activations, changed_tiles;
+    uint8_t* plain;  // per tile (chain mode)
+    long rounds, activations, changed_tiles, chained;
 } Field;
 
 static void field_init(Field* f, int nx, int ny, int inc, int32_t* v, uint8_t* m) {
     f->nx = nx; f->ny = ny; f->inc = inc; f->v = v; f->m = m;
     f->tx = (nx + TS - 1) / TS; f->ty = (ny + TS - 1) / TS;
     f->act = calloc((size_t)f->tx * f->ty, 1); f->nxt = calloc((size_t)f->tx * f->ty, 1);
-    f->rounds = f->activations = f->changed_tiles = 0;
+    f->rounds = f->activations = f->changed_tiles = f->chained = 0;
+    f->plain = calloc((size_t)f->tx * f->ty, 1);
+    for (int ty = 0; ty < f->ty; ty++)
+        for (int tx = 0; tx < f->tx; tx++) {
+            int ok = (tx + 1) * TS <= nx && (ty + 1) * TS <= ny;
+            for (int j = 0; j < TS && ok; j++)
+                for (int i = 0; i < TS && ok; i++) ok = m[(size_t)(ty * TS + j) * nx + tx * TS + i] == 0xFF;
+            f->plain[(size_t)ty * f->tx + tx] = (uint8_t)ok;
+        }
 }
 static void activate_around(Field* f, int x, int y, uint8_t flag) {
     for (int dy = -1; dy <= 1; dy++)
@@ -96,6 +106,66 @@ static int relax_tile(const Field* f, int tx, int ty, int full, int32_t* out) {
     return changed;
 }
 
+
+// ---- macro blocks: aligned K x K blocks of full / plain tiles solved as ONE unit per round (what a closed-form rim update + lazy interior fill would do) ----
+static int g_macro = 0;            // largest K (power of two), 0 = off
+static int32_t* g_unit = NULL;     // per tile: -1 = ordinary tile, else index into g_blocks
+typedef struct { int tx0, ty0, k; } Block;
+static Block* g_blocks = NULL; static int g_nblocks = 0;
+static void build_blocks(const Field* f) {
+    const size_t nt = (size_t)f->tx * f->ty;
+    g_unit = malloc(nt * sizeof(int32_t));
+    for (size_t t = 0; t < nt; t++) g_unit[t] = -1;
+    g_blocks = malloc(nt * sizeof(Block)); g_nblocks = 0;
+    long covered = 0;
+    for (int k = g_macro; k >= 2; k >>= 1)
+        for (int by = 0; by + k <= f->ty; by += k)
+            for (int bx = 0; bx + k <= f->tx; bx += k) {
+                int ok = 1;
+                for (int j = 0; j < k && ok; j++)
+                    for (int i = 0; i < k && ok; i++) { size_t t = (size_t)(by + j) * f->tx + bx + i; ok = f->plain[t] && g_unit[t] < 0; }
+                if (!ok) continue;
+                for (int j = 0; j < k; j++) for (int i = 0; i < k; i++) g_unit[(size_t)(by + j) * f->tx + bx + i] = g_nblocks;
+                g_blocks[g_nblocks++] = (Block){bx, by, k}; covered += (long)k * k;
+            }
+    long np = 0; for (size_t t = 0; t < nt; t++) np += f->plain[t];
+    fprintf(stderr, "macro blocks (K <= %d): %d blocks cover %ld of %ld full / plain tiles\n", g_macro, g_nblocks, covered, np);
+}
+// a rectangular region of cells to its local fixed point against the ring around it (queue-based); out: w x h values; returns 1 if changed
+static int relax_region(const Field* f, int x0, int y0, int w, int h, int32_t* out) {
+    const int P = w + 2, nx = f->nx, ny = f->ny, inc = f->inc;
+    int32_t* Wv = malloc((size_t)P * (h + 2) * sizeof(int32_t));
+    for (int j = 0; j < h + 2; j++)
+        for (int i = 0; i < P; i++) {
+            int x = x0 - 1 + i, y = y0 - 1 + j;
+            Wv[(size_t)j * P + i] = (x >= 0 && y >= 0 && x < nx && y < ny) ? val(f->v[(size_t)y * nx + x]) : INF;
+        }
+    int* q = malloc((size_t)w * h * sizeof(int) * 4); uint8_t* in = calloc((size_t)w * h, 1);
+    size_t qh = 0, qt = 0; const size_t QN = (size_t)w * h * 4; int changed = 0;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            if (!(i == 0 || j == 0 || i == w - 1 || j == h - 1)) continue;
+            const uint8_t mk = f->m[(size_t)(y0 + j) * nx + x0 + i];
+            if (!mk) continue;
+            size_t c = (size_t)(j + 1) * P + i + 1; int best = INF;
+            for (int k = 1; k <= 8; k++) if (mk & (1u << (k - 1))) { int wv = Wv[c + d2[k] * P + d1[k]]; if (wv < best) best = wv; }
+            if (best < INF && best + inc < Wv[c]) { Wv[c] = best + inc; changed = 1; if (!in[(size_t)j * w + i]) { in[(size_t)j * w + i] = 1; q[qt++ % QN] = j * w + i; } }
+        }
+    while (qh != qt) {
+        int t = q[qh++ % QN]; in[t] = 0;
+        int j = t / w, i = t % w; size_t c = (size_t)(j + 1) * P + i + 1; int vc = Wv[c];
+        for (int k = 1; k <= 8; k++) {
+            int ii = i + d1[k], jj = j + d2[k];
+            if (ii < 0 || jj < 0 || ii >= w || jj >= h) continue;
+            if (!(f->m[(size_t)(y0 + jj) * nx + x0 + ii] & (1u << (opp(k) - 1)))) continue;
+            size_t n = (size_t)(jj + 1) * P + ii + 1;
+            if (vc + inc < Wv[n]) { Wv[n] = vc + inc; changed = 1; if (!in[(size_t)jj * w + ii]) { in[(size_t)jj * w + ii] = 1; q[qt++ % QN] = jj * w + ii; } }
+        }
+    }
+    if (changed) for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) out[(size_t)j * w + i] = Wv[(size_t)(j + 1) * P + i + 1];
+    free(Wv); free(q); free(in);
+    return changed;
+}
 // rounds until nothing is active or max_rounds (<= 0: no bound); returns the rounds run; prints per-round counts when verbose
 static long run_rounds(Field* f, long max_rounds, int verbose, const char* tag) {
     const size_t nt = (size_t)f->tx * f->ty;
@@ -109,7 +179,21 @@ static long run_rounds(Field* f, long max_rounds, int verbose, const char* tag) 
         if (max_rounds > 0 && r >= max_rounds) break;
         if (na * TS * TS > bufcap) { bufcap = na * TS * TS; buf = realloc(buf, bufcap * sizeof(int32_t)); }
         uint8_t* chg = calloc(na, 1);
-        for (size_t a = 0; a < na; a++) chg[a] = (uint8_t)relax_tile(f, tiles[a] % f->tx, tiles[a] / f->tx, f->act[tiles[a]] >= 2, buf + a * TS * TS);
+        // macro blocks with an active tile: solved whole, on the same snapshot as the ordinary tiles (committed below)
+        int nb_act = 0; int* bact = NULL; int32_t** bout = NULL; uint8_t* bchg = NULL;
+        if (g_macro && f->inc == 1 && g_unit) {
+            uint8_t* seen = calloc((size_t)g_nblocks + 1, 1);
+            bact = malloc(sizeof(int) * (g_nblocks + 1));
+            for (size_t a = 0; a < na; a++) { int u = g_unit[tiles[a]]; if (u >= 0 && !seen[u]) { seen[u] = 1; bact[nb_act++] = u; } }
+            free(seen);
+            bout = malloc(sizeof(int32_t*) * (nb_act + 1)); bchg = calloc((size_t)nb_act + 1, 1);
+            for (int b = 0; b < nb_act; b++) {
+                const Block B = g_blocks[bact[b]]; const int w = B.k * TS, h = B.k * TS;
+                bout[b] = malloc((size_t)w * h * sizeof(int32_t));
+                bchg[b] = (uint8_t)relax_region(f, B.tx0 * TS, B.ty0 * TS, w, h, bout[b]);
+            }
+        }
+        for (size_t a = 0; a < na; a++) chg[a] = (g_macro && g_unit && f->inc == 1 && g_unit[tiles[a]] >= 0) ? 0 : (uint8_t)relax_tile(f, tiles[a] % f->tx, tiles[a] / f->tx, f->act[tiles[a]] >= 2, buf + a * TS * TS);
         memset(f->nxt, 0, nt);
         long nchg = 0;
         for (size_t a = 0; a < na; a++) {
@@ -134,6 +218,56 @@ static long run_rounds(Field* f, long max_rounds, int verbose, const char* tag) 
                         }
                     }
                 }
+        }
+        for (int b = 0; b < nb_act; b++) {   // commit the macro blocks; a changed RIM cell activates the tiles outside the block it can improve
+            const Block B = g_blocks[bact[b]]; const int w = B.k * TS, h = B.k * TS, x0 = B.tx0 * TS, y0 = B.ty0 * TS;
+            if (bchg[b]) {
+                nchg++;
+                for (int j = 0; j < h; j++)
+                    for (int i = 0; i < w; i++) {
+                        const size_t idx = (size_t)(y0 + j) * f->nx + x0 + i;
+                        const int32_t nv = bout[b][(size_t)j * w + i];
+                        if (nv == val(f->v[idx])) continue;
+                        f->v[idx] = nv;
+                        if (i == 0 || j == 0 || i == w - 1 || j == h - 1)
+                            for (int k = 1; k <= 8; k++) {
+                                int x = x0 + i + d1[k], y = y0 + j + d2[k];
+                                if (x < 0 || y < 0 || x >= f->nx || y >= f->ny) continue;
+                                if (x >= x0 && x < x0 + w && y >= y0 && y < y0 + h) continue;
+                                const size_t n = (size_t)y * f->nx + x;
+                                if ((f->m[n] & (1u << (opp(k) - 1))) && nv + f->inc < val(f->v[n])) f->nxt[(size_t)(y / TS) * f->tx + x / TS] = 1;
+                            }
+                    }
+            }
+            free(bout[b]);
+        }
+        free(bact); free(bout); free(bchg);
+        if (g_chain) {   // plain tiles among the newly activated ones: processed now, in place, transitively
+            int again = 1;
+            int32_t* tb = malloc(sizeof(int32_t) * TS * TS);
+            while (again) {
+                again = 0;
+                for (size_t t = 0; t < nt; t++) {
+                    if (!f->nxt[t] || !f->plain[t]) continue;
+                    f->nxt[t] = 0; again = 1; f->chained++;
+                    const int tx = (int)(t % f->tx), ty = (int)(t / f->tx), x0 = tx * TS, y0 = ty * TS;
+                    if (!relax_tile(f, tx, ty, 0, tb)) continue;
+                    for (int j = 0; j < TS; j++)
+                        for (int i = 0; i < TS; i++) {
+                            const size_t idx = (size_t)(y0 + j) * f->nx + x0 + i;
+                            if (tb[j * TS + i] == val(f->v[idx])) continue;
+                            f->v[idx] = tb[j * TS + i];
+                            if (i == 0 || j == 0 || i == TS - 1 || j == TS - 1)
+                                for (int k = 1; k <= 8; k++) {
+                                    int x = x0 + i + d1[k], y = y0 + j + d2[k];
+                                    if (x < 0 || y < 0 || x >= f->nx || y >= f->ny || (x / TS == tx && y / TS == ty)) continue;
+                                    const size_t n = (size_t)y * f->nx + x;
+                                    if ((f->m[n] & (1u << (opp(k) - 1))) && tb[j * TS + i] + f->inc < val(f->v[n])) f->nxt[(size_t)(y / TS) * f->tx + x / TS] = 1;
+                                }
+                        }
+                }
+            }
+            free(tb);
         }
         free(chg);
         if (verbose) fprintf(stderr, "%s round %ld: active %zu changed %ld\n", tag, f->rounds, na, nchg);
@@ -262,14 +396,18 @@ int main(int argc, char** argv) {
     int32_t* v0 = slurp(argv[2], n * 4);
     uint8_t* m = slurp(argv[3], n);
     double t0 = now();
+    g_chain = getenv("SIM_CHAIN") != NULL;
+    g_macro = getenv("SIM_MACRO") ? atoi(getenv("SIM_MACRO")) : 0;
     // ---- reference: no corrections
     int32_t* vr = malloc(n * 4); memcpy(vr, v0, n * 4);
     Field ref; field_init(&ref, N, N, 1, vr, m);
     for (size_t c = 0; c < n; c++) if (m[c] || v0[c] > 0) { size_t y = c / N, x = c % N; ref.act[(y / TS) * ref.tx + x / TS] = 2; }
+    if (g_macro) build_blocks(&ref);
     run_rounds(&ref, 0, verbose > 2, "plain");
     int mxl = 0; long unreached = 0;
     for (size_t c = 0; c < n; c++) { if (vr[c] > mxl) mxl = vr[c]; unreached += vr[c] == 0; }
-    printf("plain: %ld rounds, %ld activations (%ld changed), deepest level %d, unreached %ld  [%.1f s]\n", ref.rounds, ref.activations, ref.changed_tiles, mxl, unreached, now() - t0);
+    { long np = 0; for (size_t t = 0; t < (size_t)ref.tx * ref.ty; t++) np += ref.plain[t];
+      printf("plain%s: %ld rounds, %ld activations (%ld changed, %ld chained in-round on %ld full / plain tiles), deepest level %d, unreached %ld  [%.1f s]\n", g_chain ? " + chain" : "", ref.rounds, ref.activations, ref.changed_tiles, ref.chained, np, mxl, unreached, now() - t0); }
     if (max_cycles <= 0) return 0;
     // ---- with corrections
     int32_t* v = malloc(n * 4); memcpy(v, v0, n * 4);

@@ -113,7 +113,7 @@ struct TdxSpan {
 // scratch slot ids (one namespace for all stages; stages never run concurrently on a context)
 enum {
     TDX_S_A = 0, TDX_S_B, TDX_S_C, TDX_S_D, TDX_S_E, TDX_S_F, TDX_S_G, TDX_S_H, TDX_S_I, TDX_S_J, TDX_S_K,
-    TDX_S_Q, TDX_S_L, TDX_S_M, TDX_S_N, TDX_S_O, TDX_S_P, TDX_S_R, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_FACT, TDX_S_COUNT
+    TDX_S_Q, TDX_S_L, TDX_S_M, TDX_S_N, TDX_S_O, TDX_S_P, TDX_S_R, TDX_S_IO0, TDX_S_IO1, TDX_S_IO2, TDX_S_IO3, TDX_S_IO4, TDX_S_FACT, TDX_S_MACRO, TDX_S_COUNT
 };
 
 static inline int tdx_fail(tdx_context* ctx, int code, const std::string& msg) {

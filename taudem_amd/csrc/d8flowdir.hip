@@ -230,7 +230,8 @@ template <class LV>
 __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
                                                                  int y_own0, int y_own1, int tiles_x, LV* __restrict__ lvl,
                                                                  LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap) {
+                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap,
+                                                                 uint8_t* __restrict__ notfull) {
     using tilek::lane_left;
     using tilek::lane_right;
     const int bx = tdxk::xcd_block_x(nbx, xmap);
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
     }
     int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
     int masked_row = -1;                  // ... a flat cell whose incfall mask shuts out an in-queue neighbour (flatk::LevelPlainT)
+    unsigned fall_all = 0xFFu, rise_all = 0xFFu;   // AND of this lane's masks: 0xFF = every cell of its column segment may move and look at all eight neighbours (flats.hpp: OPEN WATER)
 #pragma unroll
     for (int r = 0; r < SLOPE_ROWS; r++) {
         const int y = ybase + r;
@@ -317,7 +319,16 @@ __global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __
             rq[idx] = q;
             fmask[idx] = uint8_t(fm);
             rmask[idx] = uint8_t(rm);
+            fall_all &= fm;
+            rise_all &= rm;
         }
+    }
+    if (notfull != nullptr && mine) {   // the tile rows this lane's segment lies in are not full for a field unless every cell of the segment is (rows beyond the owned ones never are)
+        const int ylast = ybase + SLOPE_ROWS - 1;
+        const int tr0 = ybase / tilek::TS, tr1 = (ylast < ny ? ylast : ny - 1) / tilek::TS;
+        const bool short_seg = ylast >= y_own1;
+        if (fall_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS)] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS)] = 1; }
+        if (rise_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS) + 1] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS) + 1] = 1; }
     }
     if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
     if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
@@ -634,11 +645,11 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
             FlatLevels fl;
             D8Traits tr{d_p};
             const float* zc = zcur;
-            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked) {
+            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked, uint8_t* notfull) {
                 const int nbx = (st.nx + CLS_COLS - 1) / CLS_COLS;
                 const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
                 hipLaunchKernelGGL((d8_classify_stream_kernel<LV>), grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
-                                   rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0);
+                                   rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0, notfull);
             };
             if (sparse && markers_ready) {
                 // the streaming setFlow2 of the previous iteration left this iteration's markers in the second pair of rasters

@@ -150,9 +150,123 @@ struct LevelPlainT {
     static __device__ __forceinline__ int act_threshold_raw(S g) { return g >= 0 ? decode(g) - 1 : act_never(); }
 };
 
+// ---- OPEN WATER: aligned blocks of FULL tiles in closed form ---------------------------------------------------------------------------------------------
+// A tile is FULL for a level field when every one of its 4096 cells may move and may look at all eight neighbours (mask 0xFF: the cell and its neighbours
+// are in the queue, level with each other, no flow path in between - the inside of a lake).  There the operator is the plain chessboard distance: inside a
+// square block R of full tiles the fixed point against the ring of cells around R is
+//       v(c) = min over ring cells b of  v(b) + max(|dx|, |dy|)                                  (every king's path from b to c inside R is allowed)
+// and the rest of the raster sees R only through R's RIM (its outermost cells).  So a block is ONE node of the round schedule (tile_relax.hpp:
+// TileGeom::remap / blk_k): an activation recomputes the rim from the ring in closed form - per ring edge a prefix / suffix minimum of h, h - j and h + j
+// answer every rim cell in O(1) - and raises the flags of the tiles around what moved; the inside is filled ONCE, after the relaxation has ended, from the
+// final rim (rim values along an edge differ by at most one from cell to cell, so a cell at distance d from an edge takes d + the minimum over the 2d + 1
+// rim cells across: sparse tables).  A front crosses a block of K x K tiles in one round instead of K: the lake that carries the tail of incfall at
+// BASELINE.json configs[1] (8 001 levels) is 3 998 full tiles wide open, and the CPU model of the schedule (scripts/sim/level_vcycle.c, SIM_MACRO=8)
+// needs 73 rounds instead of 168.  The values are those of the tile relaxation: the same fixed point of the same operator.
+constexpr int MACRO_KMAX = 8;                         // largest block edge in tiles (ring edges of 64 K + 2 cells in LDS)
+constexpr int MACRO_LMAX = MACRO_KMAX * 64 + 2;
+constexpr int MACRO_INF = 0x3fffffff;
+constexpr int MACRO_LDS_WORDS = 5 * MACRO_LMAX + 4 * (MACRO_LMAX - 2) + 8;   // (+ moved[8])   // ring edge: h, pre, suf, pm, sp; rim accumulators t, b, l, r; a few words
+
+// Per aligned 8 x 8 region of tiles and field: the largest aligned blocks (8, 4, 2 tiles on edge) of tiles that are full for the field (notfull[2 t + field] == 0
+// and wholly inside the owned rows / the raster).  remap[t] = first tile of t's block (t itself outside blocks); blk_k[t] = K for a block's first tile, else 0.
+// One thread per region and field (blockIdx.y); a region's marks are eight 16-byte rows.
+static __global__ __launch_bounds__(64) void find_blocks_kernel(const uint8_t* __restrict__ notfull, int tiles_x, int tiles_y, int nx, int y_lo, int y_hi, int kmax,
+                                                                uint32_t* __restrict__ remapF, uint8_t* __restrict__ blkF, uint32_t* __restrict__ remapR, uint8_t* __restrict__ blkR) {
+    const int field = int(blockIdx.y);
+    uint32_t* const remap = field ? remapR : remapF;
+    uint8_t* const blk_k = field ? blkR : blkF;
+    const int rx = (tiles_x + 7) / 8;
+    const int reg = blockIdx.x * 64 + threadIdx.x;
+    if (reg >= rx * ((tiles_y + 7) / 8)) return;
+    const int bx0 = (reg % rx) * 8, by0 = (reg / rx) * 8;
+    unsigned long long fm = 0;   // bit j * 8 + i: tile (bx0 + i, by0 + j) is full
+    const bool vec = (tiles_x & 7) == 0;   // rows of 8 tiles = 16 aligned bytes
+    for (int j = 0; j < 8; j++) {
+        const int ty = by0 + j;
+        if (ty >= tiles_y || ty * tilek::TS < y_lo || (ty + 1) * tilek::TS > y_hi) continue;
+        unsigned rowbits = 0;
+        if (vec) {
+            const uint4 w = *reinterpret_cast<const uint4*>(notfull + 2 * (size_t(ty) * tiles_x + bx0));
+            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (((ww[i >> 1] >> (16 * (i & 1) + 8 * field)) & 0xFFu) == 0u) rowbits |= 1u << i;
+        } else {
+            for (int i = 0; i < 8 && bx0 + i < tiles_x; i++) if (notfull[2 * (size_t(ty) * tiles_x + bx0 + i) + field] == 0) rowbits |= 1u << i;
+        }
+        for (int i = 0; i < 8; i++) if (bx0 + i >= tiles_x || (bx0 + i + 1) * tilek::TS > nx) rowbits &= ~(1u << i);
+        fm |= (unsigned long long)rowbits << (8 * j);
+    }
+    // block edge per tile of the region: 8 if the whole region is full, else 4 per full aligned quadrant, else 2 per full aligned pair of pairs
+    auto full_block = [&](int i0, int j0, int kk) {
+        unsigned long long m = 0;
+        for (int b = 0; b < kk; b++) m |= ((kk == 8 ? 0xFFull : (kk == 4 ? 0xFull : 0x3ull)) << i0) << ((j0 + b) * 8);
+        return (fm & m) == m;
+    };
+    for (int j = 0; j < 8; j++) {
+        const int ty = by0 + j;
+        if (ty >= tiles_y) break;
+        for (int i = 0; i < 8; i++) {
+            const int tx = bx0 + i;
+            if (tx >= tiles_x) break;
+            const size_t t = size_t(ty) * tiles_x + tx;
+            int k = 0;
+            for (int kk = kmax; kk >= 2 && !k; kk >>= 1) if (full_block(i & ~(kk - 1), j & ~(kk - 1), kk)) k = kk;
+            if (k) {
+                const int i0 = i & ~(k - 1), j0 = j & ~(k - 1);
+                remap[t] = uint32_t(size_t(by0 + j0) * tiles_x + bx0 + i0);
+                blk_k[t] = uint8_t((i == i0 && j == j0) ? k : 0);
+            } else { remap[t] = uint32_t(t); blk_k[t] = 0; }
+        }
+    }
+}
+
+// only a block's first tile is a node of the schedule: the flags the classification raised on its other tiles are dropped
+static __global__ __launch_bounds__(256) void block_flags_kernel(uint32_t* __restrict__ flags, const uint32_t* __restrict__ remap, int ntiles) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ntiles && remap[t] != uint32_t(t)) flags[t] = 0u;
+}
+// inclusive minimum scans of one ring edge h[0 .. L) by ONE wave each: wave 0 prefix of h, 1 suffix of h, 2 prefix of h - j, 3 suffix of h + j
+__device__ __forceinline__ void macro_edge_scans(const int* __restrict__ h, int L, int* __restrict__ pre, int* __restrict__ suf, int* __restrict__ pm, int* __restrict__ sp) {
+    const int wv = int(threadIdx.x >> 6), lane = int(threadIdx.x & 63);
+    const bool fwd = (wv & 1) == 0;
+    int* const out = wv == 0 ? pre : (wv == 1 ? suf : (wv == 2 ? pm : sp));
+    int carry = MACRO_INF;
+    for (int base = 0; base < L; base += 64) {
+        const int j = fwd ? base + lane : L - 1 - base - lane;          // forward scans walk up, suffix scans walk down
+        int v = MACRO_INF;
+        if (j >= 0 && j < L) { v = h[j]; if (wv == 2) v -= j; else if (wv == 3) v += j; }
+        // inclusive minimum scan over the wave's 64 lanes in seven DPP steps (rows of 16: row_shr 1, 2, 4, 8; then lane 15 of a row into the next row, lane 31 into
+        // the upper half; a lane without a source keeps +inf) - as ds_bpermute shuffles the six steps were 40 % of a block update
+        {
+#define TDX_MACRO_SCAN_STEP(CTRL, ROWS) { const int t = __builtin_amdgcn_update_dpp(MACRO_INF, v, CTRL, ROWS, 0xf, false); v = t < v ? t : v; }
+            TDX_MACRO_SCAN_STEP(0x111, 0xf) TDX_MACRO_SCAN_STEP(0x112, 0xf) TDX_MACRO_SCAN_STEP(0x114, 0xf) TDX_MACRO_SCAN_STEP(0x118, 0xf)   // row_shr:1, 2, 4, 8
+            TDX_MACRO_SCAN_STEP(0x142, 0xa)                                                                                                   // row_bcast:15 into rows 1 and 3
+            TDX_MACRO_SCAN_STEP(0x143, 0xc)                                                                                                   // row_bcast:31 into rows 2 and 3
+#undef TDX_MACRO_SCAN_STEP
+        }
+        v = carry < v ? carry : v;
+        if (j >= 0 && j < L) out[j] = v;
+        carry = __shfl(v, 63, 64);
+    }
+}
+// best level a ring edge (arrays over ring index 0 .. L) offers a cell at ring index a, d >= 1 cells away from the edge's line: min over j of h[j] + max(|a - j|, d)
+__device__ __forceinline__ int macro_offer(const int* __restrict__ h, const int* __restrict__ pre, const int* __restrict__ suf, const int* __restrict__ pm,
+                                           const int* __restrict__ sp, int L, int a, int d) {
+    const int lo = a - d, hi = a + d;
+    int near;   // minimum of h over [lo, hi] (clipped): the window touches an end of the edge unless d == 1
+    if (lo <= 0) near = pre[hi < L - 1 ? hi : L - 1];
+    else if (hi >= L - 1) near = suf[lo];
+    else { near = h[lo]; for (int j = lo + 1; j <= hi; j++) near = h[j] < near ? h[j] : near; }   // (d == 1: three cells)
+    int best = near + d;
+    if (lo - 1 >= 0) { const int f = pm[lo - 1] + a; best = f < best ? f : best; }
+    if (hi + 1 <= L - 1) { const int f = sp[hi + 1] - a; best = f < best ? f : best; }
+    return best;
+}
+
 template <int INC, class S>   // INC 1: breadth-first level field; 0: plain reachability ("some selected neighbour is marked")
 struct LevelOpT {
     using T = int;
+    static constexpr int kMacroLdsWords = INC == 1 ? MACRO_LDS_WORDS : 0;   // (what tilek::has_macro looks for: the level fields only, not the closure)
     static constexpr int kUniform = 0;
     S* G;
     const uint8_t* M;
@@ -183,6 +297,155 @@ struct LevelOpT {
     static __device__ __forceinline__ int act_threshold(uint8_t m, int v) { return m ? v - INC : act_never(); }
     // ... and the value alone says as much: a negative marker = outside the queue, a seed's value is below every new value
     static __device__ __forceinline__ int act_threshold_raw(S g) { return g >= 0 ? decode(g) - INC : act_never(); }
+
+    // One activation of a macro block (see OPEN WATER above; tilek::relax_kernel calls it for a block's first tile, all 256 threads): the rim of the k x k tile
+    // block from the ring around it, in closed form; rim cells that moved are stored and the tiles outside the block that touch them are activated.
+    __device__ __forceinline__ int macro_update(const tilek::TileGeom& g, int tile, int k, int* __restrict__ lds, tilek::TileLds& TL, uint32_t* __restrict__ flags_next) const {
+        const int tid = int(threadIdx.x);
+        const int W = k * tilek::TS, L = W + 2;
+        const int tx0 = tile % g.tiles_x, ty0 = tile / g.tiles_x;
+        const int X0 = tx0 * tilek::TS, Y0 = ty0 * tilek::TS;
+        const size_t pitch = size_t(g.nx);
+        int* const h = lds; int* const pre = h + MACRO_LMAX; int* const suf = pre + MACRO_LMAX; int* const pm = suf + MACRO_LMAX; int* const sp = pm + MACRO_LMAX;
+        int* const acc = sp + MACRO_LMAX;                  // [4][MACRO_LMAX - 2]: rim edges top, bottom, left, right
+        int* const moved = acc + 4 * (MACRO_LMAX - 2);     // [4]: per rim edge, bit s = a cell of its s-th 64-cell segment moved
+        constexpr int AW = MACRO_LMAX - 2;
+        // rim cell i of edge e (0 top, 1 bottom, 2 left, 3 right)
+        auto rim_idx = [&](int e, int i) -> size_t {
+            const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i), y = e == 0 ? 0 : (e == 1 ? W - 1 : i);
+            return size_t(Y0 + y) * pitch + size_t(X0 + x);
+        };
+        // ---- every global load of the activation is issued up front (addresses clamped, validity applied afterwards: a load behind a bounds test or
+        // inside a loop with an LDS store is waited for before the next one is issued - the first version spent 12 memory latencies here)
+        S raw_rim[4][2], raw_ring[4][3];
+        unsigned ring_ok = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid + u * 256;
+                raw_rim[e][u] = G[rim_idx(e, i < W ? i : W - 1)];
+            }
+#pragma unroll
+        for (int E = 0; E < 4; E++)      // ring edges: 0 the row above, 1 the row below, 2 the column to the left, 3 the column to the right (corners included)
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int j = tid + u * 256;
+                const int x = E == 2 ? X0 - 1 : (E == 3 ? X0 + W : X0 - 1 + j), y = E == 0 ? Y0 - 1 : (E == 1 ? Y0 + W : Y0 - 1 + j);
+                if (j < L && x >= 0 && x < g.nx && y >= 0 && y < g.ny) ring_ok |= 1u << (E * 3 + u);
+                const int xc = x < 0 ? 0 : (x >= g.nx ? g.nx - 1 : x), yc = y < 0 ? 0 : (y >= g.ny ? g.ny - 1 : y);
+                raw_ring[E][u] = G[size_t(yc) * pitch + size_t(xc)];
+            }
+        int old[4][2];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid + u * 256;
+                old[e][u] = i < W ? decode(raw_rim[e][u]) : MACRO_INF;
+                if (i < W) acc[e * AW + i] = old[e][u];
+            }
+        if (tid < 8) moved[tid] = 0;   // [0 .. 4): per ring edge, bit p + 1 = the tile outside at position p (-1 .. k) can be improved; [4 .. 8): the ring edge holds a level at all
+#pragma unroll
+        for (int E = 0; E < 4; E++) {
+            bool fin = false;
+#pragma unroll
+            for (int u = 0; u < 3; u++) fin = fin || (((ring_ok >> (E * 3 + u)) & 1u) && raw_ring[E][u] > 0);
+            if (__ballot(fin) != 0ull && (tid & 63) == 0) moved[4 + E] = 1;
+        }
+#pragma unroll
+        for (int E = 0; E < 4; E++) {
+            __syncthreads();            // (the previous edge's tables are no longer read; the first time: the flags above are in place)
+            if (moved[4 + E] == 0) continue;   // nothing on this side of the block has a level yet: no offers (uniform)
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int j = tid + u * 256;
+                if (j < L) h[j] = ((ring_ok >> (E * 3 + u)) & 1u) ? decode(raw_ring[E][u]) : MACRO_INF;
+            }
+            __syncthreads();
+            macro_edge_scans(h, L, pre, suf, pm, sp);
+            __syncthreads();
+            for (int i = tid; i < W; i += 256) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    // position of rim cell i of edge e against ring edge E: index a along the ring edge, distance d from its line
+                    int a, d;
+                    if (E < 2) {          // a horizontal ring row: along = x + 1
+                        a = e == 2 ? 1 : (e == 3 ? W : i + 1);
+                        const int y = e == 0 ? 0 : (e == 1 ? W - 1 : i);
+                        d = E == 0 ? y + 1 : W - y;
+                    } else {              // a vertical ring column: along = y + 1
+                        a = e == 0 ? 1 : (e == 1 ? W : i + 1);
+                        const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
+                        d = E == 2 ? x + 1 : W - x;
+                    }
+                    const int off = macro_offer(h, pre, suf, pm, sp, L, a, d);
+                    if (off < acc[e * AW + i]) acc[e * AW + i] = off;
+                }
+            }
+        }
+        __syncthreads();
+        // (a corner cell is on two rim edges: both accumulators hold offers for it, the smaller one is its level)
+        if (tid < 4) {
+            const int ea = tid < 2 ? 0 : 1, ia = (tid & 1) ? W - 1 : 0;     // corner tid: top-left, top-right, bottom-left, bottom-right
+            const int eb = (tid & 1) ? 3 : 2, ib = tid < 2 ? 0 : W - 1;
+            const int m = acc[ea * AW + ia] < acc[eb * AW + ib] ? acc[ea * AW + ia] : acc[eb * AW + ib];
+            acc[ea * AW + ia] = m; acc[eb * AW + ib] = m;
+        }
+        __syncthreads();
+        // rim cells that moved are stored; chg (the ring tables' space) keeps the new level of a rim cell that moved, +inf for one that did not
+        int* const chg = h;   // [4][AW]
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid + u * 256;
+                if (i < W) {
+                    const int v = acc[e * AW + i];
+                    const bool mv = v < old[e][u] && v < MACRO_INF;
+                    if (mv) G[rim_idx(e, i)] = S(sizeof(S) == 2 && v > LVL_SAT ? LVL_SAT : v);
+                    chg[e * AW + i] = mv ? v : MACRO_INF;
+                }
+            }
+        __syncthreads();
+        // Which tiles outside the block have something to gain (the engine's activation filter, tile_relax.hpp): ring cell j of edge E touches the rim cells
+        // j - 2 .. j of rim edge E; it is in the queue (raw >= 0) and one of them moved to a level more than one below its own.  Necessary for an improvement,
+        // so a flag that is withheld could not have led to a change; without the test neighbouring blocks woke each other up after every update.
+#pragma unroll
+        for (int E = 0; E < 4; E++)
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int j = tid + u * 256;
+                bool gain = false;
+                if (j < L && ((ring_ok >> (E * 3 + u)) & 1u) && raw_ring[E][u] >= 0) {
+                    int best = MACRO_INF;
+                    for (int i = j - 2; i <= j; i++) if (i >= 0 && i < W && chg[E * AW + i] < best) best = chg[E * AW + i];
+                    gain = best + INC < decode(raw_ring[E][u]);
+                }
+                // (the ring cells j = 1 + 64 p .. 64 p + 64 lie in the tile at position p along the edge, j = 0 at position -1, j = L - 1 at position k: a wave's 64 cells
+                // of one u span at most two positions)
+                const int p = j == 0 ? -1 : (j - 1) / tilek::TS;
+                const int p0 = __builtin_amdgcn_readfirstlane(p);
+                const unsigned long long b_lo = __ballot(gain && p == p0), b_hi = __ballot(gain && p != p0);   // (one LDS atomic per wave and position, not one per cell)
+                if ((tid & 63) == 0) {
+                    if (b_lo != 0ull) atomicOr(&moved[E], 1 << (p0 + 1));
+                    if (b_hi != 0ull) atomicOr(&moved[E], 1 << (p0 + 2));
+                }
+            }
+        __syncthreads();
+        // the tiles outside the block along each edge (positions -1 .. k: the corners' diagonal neighbours too) that can be improved
+        if (tid < 4 * (k + 2)) {
+            const int e = tid / (k + 2), j = tid % (k + 2) - 1;
+            const int near = (moved[e] >> (j + 1)) & 1;
+            const int ntx = e == 2 ? tx0 - 1 : (e == 3 ? tx0 + k : tx0 + j), nty = e == 0 ? ty0 - 1 : (e == 1 ? ty0 + k : ty0 + j);
+            if (near && ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) {
+                const uint32_t target = g.remap[size_t(nty) * g.tiles_x + ntx];
+                if (atomicMax(&flags_next[target], tilek::FLAG_HALO) == 0u) TL.pend[atomicAdd(&TL.npend, 1u)] = target;
+            }
+        }
+        __syncthreads();
+        return 0;
+    }
 };
 using LevelOp = LevelOpT<1, lvl_t>;
 using ReachOp = LevelOpT<0, int32_t>;
@@ -325,13 +588,77 @@ static __global__ __launch_bounds__(256) void flat_stats_stream8_kernel(const in
     }
 }
 
+// The inside of every macro block from its FINAL rim (see OPEN WATER above), one workgroup per ROW OF TILES of a block (fill_list[0 .. *fill_count): the first
+// tile of each row, written by fill_list_kernel): level = min over the four rim edges of (distance to the edge + minimum of the rim over the 2 d + 1 cells
+// across), by sparse tables built once per row of tiles.  int16 fields only (tables of uint16: a level fits, 0xFFFF = not reached).  Both fields in one launch
+// (blockIdx.y).
+struct FillArgs { int16_t* G; const uint32_t* remap; const uint8_t* blk_k; uint32_t* list; unsigned long long* count; };
+static __global__ __launch_bounds__(256) void fill_list_kernel(FillArgs a0, FillArgs a1, int ntiles, int tiles_x) {
+    const FillArgs a = blockIdx.y ? a1 : a0;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bool on = false;
+    if (t < ntiles) { const uint32_t rep = a.remap[t]; on = a.blk_k[rep] != 0 && (uint32_t(t) % uint32_t(tiles_x)) == (rep % uint32_t(tiles_x)); }
+    const unsigned long long pos = tdxk::block_reserve(on ? 1u : 0u, a.count);
+    if (on) a.list[pos] = uint32_t(t);
+}
+constexpr int FILL_LEVELS = 10;   // windows of up to 2^9 = 512 cells = the longest rim edge
+static __global__ __launch_bounds__(256) void macro_fill_kernel(FillArgs a0, FillArgs a1, int nx, int tiles_x) {
+    __shared__ uint16_t tab[4][FILL_LEVELS][MACRO_KMAX * 64];
+    const FillArgs a = blockIdx.y ? a1 : a0;
+    int16_t* __restrict__ G = a.G;
+    const unsigned long long n = *a.count;
+    const int tid = int(threadIdx.x), lx = tid & 63, wv = tid >> 6;
+    for (unsigned long long it = blockIdx.x; it < n; it += gridDim.x) {
+        const int t = int(a.list[it]), rep = int(a.remap[t]), k = int(a.blk_k[rep]);
+        const int W = k * tilek::TS;
+        const int X0 = (rep % tiles_x) * tilek::TS, Y0 = (rep / tiles_x) * tilek::TS;
+        const int yt = (t / tiles_x) * tilek::TS - Y0;   // this row of tiles inside the block
+        __syncthreads();   // (the previous row's tables are no longer read)
+        for (int i = tid; i < W; i += 256) {
+            const int16_t p = G[size_t(Y0) * nx + X0 + i], q = G[size_t(Y0 + W - 1) * nx + X0 + i], c = G[size_t(Y0 + i) * nx + X0], d = G[size_t(Y0 + i) * nx + X0 + W - 1];
+            tab[0][0][i] = p > 0 ? uint16_t(p) : 0xFFFFu; tab[1][0][i] = q > 0 ? uint16_t(q) : 0xFFFFu;
+            tab[2][0][i] = c > 0 ? uint16_t(c) : 0xFFFFu; tab[3][0][i] = d > 0 ? uint16_t(d) : 0xFFFFu;
+        }
+        for (int lev = 1; (1 << lev) <= W; lev++) {
+            __syncthreads();
+            const int half = 1 << (lev - 1), cnt = W - (1 << lev) + 1;
+            for (int i = tid; i < 4 * cnt; i += 256) {
+                const int e = i / cnt, j = i - e * cnt;
+                const uint16_t p = tab[e][lev - 1][j], q = tab[e][lev - 1][j + half];
+                tab[e][lev][j] = p < q ? p : q;
+            }
+        }
+        __syncthreads();
+        auto rmq = [&](int e, int lo, int hi) -> unsigned {
+            lo = lo < 0 ? 0 : lo; hi = hi > W - 1 ? W - 1 : hi;
+            const int lev = 31 - __builtin_clz(unsigned(hi - lo + 1));
+            const unsigned p = tab[e][lev][lo], q = tab[e][lev][hi - (1 << lev) + 1];
+            return p < q ? p : q;
+        };
+        for (int xt = 0; xt < W; xt += tilek::TS) {   // the tiles of the row
+            const int x = xt + lx;
+#pragma unroll 4
+            for (int r = 0; r < 16; r++) {
+                const int y = yt + wv * 16 + r;
+                const int dt = y, db = W - 1 - y, dl = x, dr = W - 1 - x;
+                unsigned v = rmq(0, x - dt, x + dt) + unsigned(dt), w2 = rmq(1, x - db, x + db) + unsigned(db);
+                v = w2 < v ? w2 : v;
+                w2 = rmq(2, y - dl, y + dl) + unsigned(dl); v = w2 < v ? w2 : v;
+                w2 = rmq(3, y - dr, y + dr) + unsigned(dr); v = w2 < v ? w2 : v;
+                G[size_t(Y0 + y) * nx + X0 + x] = v >= 0xFFFFu ? int16_t(0) : int16_t(v > unsigned(LVL_SAT) ? LVL_SAT : int(v));
+            }
+        }
+    }
+}
+
 // What a flat iteration needs cleared before its classification, in ONE launch (they were five runtime fills): the stage counters, the activation flags, the
 // per-tile "needs its masks" marks (tm_mode 0: none, 1: every tile, 2: the first half - the TDX_FLATS_MASKED hooks) and the count rings of both round schedules.
 static __global__ __launch_bounds__(256) void prepare_kernel(unsigned long long* __restrict__ d_cnt, uint32_t* __restrict__ flags0, uint8_t* __restrict__ tmask, int ntiles,
-                                                             int tm_mode, unsigned long long* __restrict__ countsA, unsigned long long* __restrict__ countsB) {
+                                                             int tm_mode, unsigned long long* __restrict__ countsA, unsigned long long* __restrict__ countsB,
+                                                             uint16_t* __restrict__ notfull) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 8) d_cnt[t] = 0ull;
-    if (t < ntiles) { flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2)); }
+    if (t < ntiles) { flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2)); if (notfull) notfull[t] = 0; }
     if (t < 2 * tilek::COUNT_RING) { countsA[t] = 0ull; if (countsB) countsB[t] = 0ull; }
 }
 
@@ -460,7 +787,8 @@ static inline int flats_relax_field(tdx_context* ctx, const Strip& st, tilek::Ti
 // `stream_classify` (optional): replaces the marker reset + list-based classification by one streaming pass over the
 // whole strip that writes lvl / rq / both masks of EVERY owned cell and raises the tile flags; qlist may then be null (no list was
 // built for a dense queue): the level statistics come from a pass over the owned rows instead.
-using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked)>;
+// (notfull: two bytes per tile, set to 1 where the tile is NOT full for incfall [2 t] / incrise [2 t + 1] - see OPEN WATER; nullptr: not wanted)
+using StreamClassifyFn = std::function<void(const tilek::TileGeom&, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked, uint8_t* notfull)>;
 template <class Traits, class LV>
 static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& st, const uint32_t* qlist, unsigned long long nq,
                      FlatBuffersT<LV> b, FlatLevels* out, tdx_stats* stats, const StreamClassifyFn* stream_classify = nullptr, int iteration = 1) {
@@ -492,9 +820,26 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     uint32_t* flagsB = pair ? static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS))) : nullptr;
     unsigned long long* countsB = pair ? static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16)) : nullptr;
     if (pair && (!flagsB || !countsB)) return TDX_ERR_NOMEM;
+    // OPEN WATER (macro blocks of full tiles, see above): with the streaming classification (a dense first queue), int16 fields, both fields side by side on the
+    // register tile kernel.  TDX_FLATS_MACRO=0 switches it off, =2 / 4 / 8 sets the largest block edge (read per call: A/B and test hook).
+    int macro_k = 0;
+    if constexpr (sizeof(LV) == 2) {
+        const char* e_macro = getenv("TDX_FLATS_MACRO");
+        macro_k = e_macro ? atoi(e_macro) : flatk::MACRO_KMAX;
+        macro_k = macro_k >= 8 ? 8 : (macro_k >= 4 ? 4 : (macro_k >= 2 ? 2 : 0));
+        if (!stream_classify || getenv("TDX_FLATS_FUSED") != nullptr || getenv("TDX_RELAX_LDS") != nullptr || no_plain || half_plain) macro_k = 0;
+    }
+    uint8_t* notfull = nullptr; uint32_t *remapF = nullptr, *remapR = nullptr, *fill_list = nullptr; uint8_t *blkF = nullptr, *blkR = nullptr;
+    if (macro_k) {
+        // [notfull 2 nt][blkF nt][blkR nt][remapF 4 nt][remapR 4 nt][fill_list 2 x 4 nt]
+        uint8_t* m = static_cast<uint8_t*>(ctx->scratch(TDX_S_MACRO, size_t(ntiles) * 20 + 64));
+        if (!m) return TDX_ERR_NOMEM;
+        notfull = m; blkF = m + 2 * size_t(ntiles); blkR = blkF + ntiles;
+        remapF = reinterpret_cast<uint32_t*>(m + 4 * size_t(ntiles)); remapR = remapF + ntiles; fill_list = remapR + ntiles;
+    }
     hipLaunchKernelGGL(flatk::prepare_kernel, dim3(tdx_blocks_for(size_t(std::max(ntiles, 2 * tilek::COUNT_RING)), 256)), dim3(256), 0, s, d_cnt, flags0, tmask, ntiles,
-                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB);
-    if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask);
+                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB, reinterpret_cast<uint16_t*>(notfull));
+    if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask, notfull);
     else {
         // The list classification writes the masks of the QUEUE's cells only.  The register tile kernel reads a mask byte only where the level marker says
         // "in the queue" (LevelOpT::raw_can_move), so what other cells hold - a mask of an earlier iteration, or nothing yet - is never looked at; only the
@@ -514,6 +859,15 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     rc = strip_exchange<LV>(ctx, st, b.rq, LV(-1));
     if (rc != TDX_OK) return rc;
     int64_t launches = 1, rounds_fall = 0, rounds_rise = 0;
+    tilek::TileGeom geomF = geom, geomR = geom;
+    if (macro_k) {
+        // blocks of full tiles per field; in a multi-strip run the tile rows that hold the first / last owned row stay ordinary tiles (the halo exchange flags them directly)
+        const int y_lo = st.multi() ? st.y0 + 1 : st.y0, y_hi = st.multi() ? st.y1 - 1 : st.y1;
+        const unsigned nreg = unsigned(((geom.tiles_x + 7) / 8) * ((geom.tiles_y + 7) / 8));
+        hipLaunchKernelGGL(flatk::find_blocks_kernel, dim3((nreg + 63) / 64, 2), dim3(64), 0, s, notfull, geom.tiles_x, geom.tiles_y, nx, y_lo, y_hi, macro_k, remapF, blkF, remapR, blkR);
+        geomF.remap = remapF; geomF.blk_k = blkF;
+        geomR.remap = remapR; geomR.blk_k = blkR;
+    }
     if (pair) {
         // the two level fields are independent: relax them side by side on two streams (own flags / list / counts each)
         uint32_t* listB = flagsB + ntiles;
@@ -531,7 +885,7 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         // (profiles/r05b_*: incrise's 6.7 + 1.5 ms of the critical path at BASELINE.json configs[3] ran after incfall's 27 ms).
         for (;;) {
             rc = two_streams ? tile_relax_run_pair(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
-                                                   LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches, start_flags)
+                                                   LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geomF, &rounds_fall, &launches, start_flags, &geomR)
                              : tile_relax_run_fused(ctx, LOp{b.lvl, fmask, tmask}, tilek::Sched{flags, list, counts},
                                                     LOp{b.rq, rmask, no_plain ? tmask : nullptr}, tilek::Sched{flagsB, listB, countsB}, geom, &rounds_fall, &launches);
             if (rc != TDX_OK) return rc;
@@ -548,14 +902,25 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
             if (changed == 0) break;
         }
     } else {
-        // ---- incfall ----
+        // ---- incfall ---- (with macro blocks: only a block's first tile starts active)
+        const unsigned cg = tdx_blocks_for(size_t(ntiles), 256);
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field<LOp>(ctx, st, geom, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches, tmask);
+        if (macro_k) hipLaunchKernelGGL(flatk::block_flags_kernel, dim3(cg), dim3(256), 0, s, flags, remapF, ntiles);
+        rc = flats_relax_field<LOp>(ctx, st, geomF, b.lvl, fmask, tilek::Sched{flags, list, counts}, &rounds_fall, &launches, tmask);
         if (rc != TDX_OK) return rc;
         // ---- incrise ----
         TDX_HIP_CHECK(ctx, hipMemcpyAsync(flags, flags0, size_t(ntiles) * 4, hipMemcpyDeviceToDevice, s));
-        rc = flats_relax_field<LOp>(ctx, st, geom, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
+        if (macro_k) hipLaunchKernelGGL(flatk::block_flags_kernel, dim3(cg), dim3(256), 0, s, flags, remapR, ntiles);
+        rc = flats_relax_field<LOp>(ctx, st, geomR, b.rq, rmask, tilek::Sched{flags, list, counts}, &rounds_rise, &launches, no_plain ? tmask : nullptr);
         if (rc != TDX_OK) return rc;
+    }
+    if constexpr (sizeof(LV) == 2) {
+        if (macro_k) {   // the inside of the macro blocks from their final rims (both fields; d_cnt[5], [6]: the numbers of tiles to fill, cleared by prepare_kernel)
+            const unsigned cg = tdx_blocks_for(size_t(ntiles), 256);
+            const flatk::FillArgs aF{reinterpret_cast<int16_t*>(b.lvl), remapF, blkF, fill_list, d_cnt + 5}, aR{reinterpret_cast<int16_t*>(b.rq), remapR, blkR, fill_list + ntiles, d_cnt + 6};
+            hipLaunchKernelGGL(flatk::fill_list_kernel, dim3(cg, 2), dim3(256), 0, s, aF, aR, ntiles, geom.tiles_x);
+            hipLaunchKernelGGL(flatk::macro_fill_kernel, dim3(unsigned(std::min(ntiles, 2 * ctx->num_cus)), 2), dim3(256), 0, s, aF, aR, nx, geom.tiles_x);
+        }
     }
     ctx->phase = ph.stats;
     // (the stage counters were cleared by prepare_kernel and nothing of this function has touched them since)

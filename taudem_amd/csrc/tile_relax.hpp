@@ -60,6 +60,11 @@ struct TileGeom {
     const unsigned long long* cnt_dev;
     unsigned long long cnt_tag;
     int act_filter;         // 1: a moved rim cell raises a neighbour's flag only if it can improve a cell of it (relax_tile_reg; TDX_ACT_FILTER_OFF=1: every moved rim cell does)
+    // MACRO BLOCKS (optional; flats.hpp: open water of a level field).  An aligned K x K block of tiles that an operator can solve in closed form is ONE node
+    // of the schedule: every activation of one of its tiles is redirected to its first tile (remap[t], identity elsewhere), and that tile - blk_k[t] = K, zero
+    // elsewhere - is handed to Op::macro_update instead of the tile kernel.  nullptr: no blocks.
+    const uint32_t* remap;
+    const uint8_t* blk_k;
 };
 
 static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
@@ -74,6 +79,7 @@ static inline TileGeom make_geom(int nx, int ny, int y_own0, int y_own1) {
     g.cnt_host = nullptr; g.cnt_dev = nullptr; g.cnt_tag = 0ull;
     static const int af = getenv("TDX_ACT_FILTER_OFF") ? 0 : 1;
     g.act_filter = af;
+    g.remap = nullptr; g.blk_k = nullptr;
     return g;
 }
 
@@ -821,6 +827,7 @@ __device__ __forceinline__ int activation_target(int res, int tile, const TileGe
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
         if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) target = nty * g.tiles_x + ntx;
+        if (g.remap != nullptr && target >= 0) target = int(g.remap[target]);   // a tile of a macro block: the block's first tile stands for it
     }
     if (tid == 8 && (res & RES_CAPPED)) { target = tile; *flag = FLAG_FULL; }   // not yet at its fixed point: run again, everything dirty
     return target;
@@ -904,6 +911,7 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
                 __syncthreads();
                 const int ch = L.chain;
                 if (ch == -1) break;
+                if (g.blk_k != nullptr && g.blk_k[ch & 0x7fffffff] != 0) break;   // a macro block is never entered by hand-over: it is flagged for its own workgroups (below)
                 tile = ch & 0x7fffffff;   // (the next body()'s first barrier comes after every lane has read L.chain)
                 full = ch < 0;
             }
@@ -929,20 +937,83 @@ struct has_plain : std::false_type {};
 template <class Op>
 struct has_plain<Op, std::enable_if_t<Op::kHasPlain>> : std::true_type {};
 
+// Op::kMacroLdsWords + op.macro_update(g, tile, k, lds, L, flags_next) (optional): the operator solves a K x K block of tiles in closed form (TileGeom::blk_k)
+template <class Op, class = void>
+struct has_macro : std::false_type {};
+template <class Op>
+struct has_macro<Op, std::enable_if_t<(Op::kMacroLdsWords > 0)>> : std::true_type {};
+template <class Op, bool = has_macro<Op>::value>
+struct macro_lds_words : std::integral_constant<int, 0> {};
+template <class Op>
+struct macro_lds_words<Op, true> : std::integral_constant<int, Op::kMacroLdsWords> {};
+
+// The macro blocks of a round (TileGeom::blk_k; flats.hpp: OPEN WATER) have workgroups of their own in the round's launch - the ones from index grid_tiles on -
+// instead of a branch inside the tile loop: inlined there, the closed-form update cost the tile kernel two more spilled registers and 35 scalar spills
+// (+1.3 ms per 16384^2 step with NO block in sight), as a called function a stack (+2.4 ms).  These workgroups look through the round's list, 256 entries at
+// a time, for first tiles of blocks, update them (Op::macro_update raises the neighbours' flags into TL.pend) and append what they activated to the next
+// round's list like round_driver does; the tile workgroups pass such entries by.
+template <class Op>
+__device__ __forceinline__ void macro_role(const Op& op, const TileGeom& g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
+                                           uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next, int* __restrict__ lds, TileLds& L, unsigned bid, unsigned nblocks,
+                                           unsigned long long* __restrict__ dbg) {
+    const unsigned nact = unsigned(count[0]);
+    if (threadIdx.x == 0) L.npend = 0u;
+    // 64 list entries per look (at most PULL_MAX = 64 blocks to remember), STRIDED over the list: neighbouring entries - blocks activated by the same front - go
+    // to different workgroups (a workgroup that took 64 consecutive entries served a dozen blocks one after the other while the others idled: 500 us per round)
+    for (unsigned base = bid; base < nact; base += nblocks * 64u) {
+        __syncthreads();                                   // (L.pulled of the previous batch has been read)
+        if (threadIdx.x == 0) L.next = 0u;
+        __syncthreads();
+        if (threadIdx.x < 64u) {
+            const unsigned i = base + nblocks * threadIdx.x;
+            const uint32_t e = i < nact ? list[i] : 0u;
+            if (i < nact && g.blk_k[e] != 0) L.pulled[atomicAdd(&L.next, 1u)] = e;
+        }
+        __syncthreads();
+        const unsigned nb = L.next;
+        if (dbg && threadIdx.x == 0 && nb) atomicMax(dbg + 15, (unsigned long long)nb);   // TDX_DEBUG_ROUNDS=1: most blocks one workgroup served in one look
+        for (unsigned b = 0; b < nb; b++) {
+            const int tile = int(L.pulled[b]);
+            const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
+            (void)op.macro_update(g, tile, int(g.blk_k[tile]), lds, L, flags_next);   // (ends with a barrier)
+            if (dbg && threadIdx.x == 0) { atomicAdd(dbg + 13, __builtin_readcyclecounter() - tc0); atomicAdd(dbg + 14, 1ull); }   // cycles in block updates, updates
+            const unsigned npend = L.npend;
+            if (threadIdx.x == 0) L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;
+            __syncthreads();
+            const unsigned long long lb = L.base;
+            for (unsigned q = threadIdx.x; q < npend; q += blockDim.x) list_next[lb + q] = L.pend[q];
+            __syncthreads();
+            if (threadIdx.x == 0) L.npend = 0u;
+        }
+    }
+}
+
+// grid_tiles: 0 = every workgroup serves tiles; otherwise the workgroups from index grid_tiles on serve the round's macro blocks (macro_role)
 template <class Op, bool REG>
 __global__ __launch_bounds__(NTHR, relax_waves<Op>::value) void relax_kernel(Op op, TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                     uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next,
-                                                    uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg) {
+                                                    uint32_t* __restrict__ list_next, unsigned pull_max, unsigned long long* __restrict__ dbg, unsigned grid_tiles) {
     using T = typename Op::T;
     static_assert(sizeof(T) == 4, "tile engine works on 4-byte values");
-    __shared__ T sV[REG ? REG_LDS_WORDS : LH * LP];
+    constexpr int kLdsWords = REG ? (REG_LDS_WORDS > macro_lds_words<Op>::value ? REG_LDS_WORDS : macro_lds_words<Op>::value) : LH * LP;
+    __shared__ T sV[kLdsWords];
     __shared__ TileLds L;
+    if constexpr (REG && has_macro<Op>::value) {
+        if (grid_tiles != 0u && blockIdx.x >= grid_tiles) {
+            macro_role(op, g, list, count, flags_next, list_next, reinterpret_cast<int*>(sV), L, blockIdx.x - grid_tiles, gridDim.x - grid_tiles, dbg);
+            return;
+        }
+    }
+    const unsigned nblocks = grid_tiles != 0u ? grid_tiles : gridDim.x;
     round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
+        if constexpr (REG && has_macro<Op>::value) {   // the first tile of a macro block: left to the block workgroups of this launch
+            if (g.blk_k != nullptr && __builtin_amdgcn_readfirstlane(int(g.blk_k[tile])) != 0) { __syncthreads(); return 0; }
+        }
         if constexpr (REG && has_plain<Op>::value) {   // tiles whose masks only say "may move" take the uniform form of the operator (flats.hpp)
             if (!__builtin_amdgcn_readfirstlane(int(op.tile_masked(tile)))) return relax_tile_reg(op.plain(), g, tile, sV, L, dbg);
         }
         return REG ? relax_tile_reg(op, g, tile, sV, L, dbg) : relax_tile(op, g, tile, full, sV, L, dbg);
-    });
+    }, blockIdx.x, nblocks);
 }
 
 // Two independent relaxations of the same operator type (the two level fields of flat resolution) in ONE launch per round: the first
@@ -1118,15 +1189,17 @@ static __global__ __launch_bounds__(256) void first_list_kernel(const uint32_t* 
 // must be zero on entry (flatk::prepare_kernel).
 static __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restrict__ flags0, int ntiles, uint32_t* __restrict__ flagsA, uint32_t* __restrict__ flagsA1,
                                                                 uint32_t* __restrict__ listA, unsigned long long* __restrict__ countA, uint32_t* __restrict__ flagsB,
-                                                                uint32_t* __restrict__ flagsB1, uint32_t* __restrict__ listB, unsigned long long* __restrict__ countB) {
+                                                                uint32_t* __restrict__ flagsB1, uint32_t* __restrict__ listB, unsigned long long* __restrict__ countB,
+                                                                const uint32_t* __restrict__ remapA, const uint32_t* __restrict__ remapB) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t f = t < ntiles ? flags0[t] : 0u;
-    if (t < ntiles) { flagsA[t] = f; flagsB[t] = f; flagsA1[t] = 0u; flagsB1[t] = 0u; }
-    const bool on = f != 0u;
-    const unsigned long long pa = block_reserve(on ? 1u : 0u, countA);
-    if (on) listA[pa] = uint32_t(t);
-    const unsigned long long pb = block_reserve(on ? 1u : 0u, countB);
-    if (on) listB[pb] = uint32_t(t);
+    // (macro blocks, TileGeom::remap: only a block's first tile is a node of the schedule - every tile of a block is flagged by the classification, so it is)
+    const uint32_t fa = (remapA != nullptr && t < ntiles && remapA[t] != uint32_t(t)) ? 0u : f, fb = (remapB != nullptr && t < ntiles && remapB[t] != uint32_t(t)) ? 0u : f;
+    if (t < ntiles) { flagsA[t] = fa; flagsB[t] = fb; flagsA1[t] = 0u; flagsB1[t] = 0u; }
+    const unsigned long long pa = block_reserve(fa != 0u ? 1u : 0u, countA);
+    if (fa != 0u) listA[pa] = uint32_t(t);
+    const unsigned long long pb = block_reserve(fb != 0u ? 1u : 0u, countB);
+    if (fb != 0u) listB[pb] = uint32_t(t);
 }
 // Round 0 with EVERY tile active (the first relaxation of a PitRemove level): flags, list, count ring and the second flag half in one launch instead of
 // three fills and first_list_kernel.
@@ -1307,10 +1380,14 @@ struct RoundRunner {
                 custom_launch(g, grid, s, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1), list_of(p ^ 1), pull_max);
             else if (lds_variant)
                 hipLaunchKernelGGL((relax_kernel<Op, false>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
-                                   list_of(p ^ 1), pull_max, dbg);
-            else
-                hipLaunchKernelGGL((relax_kernel<Op, true>), dim3(grid), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
-                                   list_of(p ^ 1), pull_max, dbg);
+                                   list_of(p ^ 1), pull_max, dbg, 0u);
+            else {
+                // with macro blocks (TileGeom::blk_k): four more workgroups per CU in the same launch serve the blocks of the round (1 / 2 / 4 / 8 / 16 per CU: 22.07 / 21.97 / 21.86 / 21.81 / 21.87 ms per 16384^2 step, profiles/r06g_macro_wgs.txt)
+                static const int macro_wgs = getenv("TDX_MACRO_WGS") ? std::max(1, atoi(getenv("TDX_MACRO_WGS"))) : 4;   // (A/B hook: block workgroups per CU)
+                const unsigned gm = (has_macro<Op>::value && g.blk_k != nullptr) ? unsigned(macro_wgs * ctx->num_cus) : 0u;
+                hipLaunchKernelGGL((relax_kernel<Op, true>), dim3(grid + gm), dim3(NTHR), 0, s, op, g, list_of(p), sc.counts + r + b, flags_of(p), flags_of(p ^ 1),
+                                   list_of(p ^ 1), pull_max, dbg, gm ? grid : 0u);
+            }
             ctx->span_end(sp);
             if (timed && ctx->cur_stats) ctx->cur_stats->launches[TDX_K_TILEK]++;
         }
@@ -1467,12 +1544,13 @@ static int tile_relax_run_fused(tdx_context* ctx, Op opA, tilek::Sched scA, Op o
 // flags0 != nullptr: BOTH relaxations start from these activation flags (scA.flags / scB.flags need not be filled in) and both count rings are zero: round 0
 // of both schedules is set up by one launch (tilek::pair_start_kernel).
 template <class Op>
+// gB (optional): the second relaxation's geometry where it differs from the first's (its own macro blocks).
 static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op opB, tilek::Sched scB, tilek::TileGeom g, int64_t* rounds_out,
-                               int64_t* launches_out, const uint32_t* flags0 = nullptr) {
+                               int64_t* launches_out, const uint32_t* flags0 = nullptr, const tilek::TileGeom* gB = nullptr) {
     if (flags0) {
         const int ntiles = g.tiles_x * g.tiles_y;
         hipLaunchKernelGGL(tilek::pair_start_kernel, dim3(tdx_blocks_for(size_t(ntiles), 256)), dim3(256), 0, ctx->stream, flags0, ntiles, scA.flags, scA.list + 2 * size_t(ntiles),
-                           scA.list, scA.counts, scB.flags, scB.list + 2 * size_t(ntiles), scB.list, scB.counts);
+                           scA.list, scA.counts, scB.flags, scB.list + 2 * size_t(ntiles), scB.list, scB.counts, g.remap, gB ? gB->remap : g.remap);
     }
     if (!ctx->stream2) {
         TDX_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -1480,7 +1558,7 @@ static int tile_relax_run_pair(tdx_context* ctx, Op opA, tilek::Sched scA, Op op
     }
     TDX_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     TDX_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail + TDX_MAIL_RUN_A, nullptr), B(ctx, ctx->stream2, opB, g, scB, ctx->h_mail + TDX_MAIL_RUN_B, nullptr);
+    RoundRunner<Op> A(ctx, ctx->stream, opA, g, scA, ctx->h_mail + TDX_MAIL_RUN_A, nullptr), B(ctx, ctx->stream2, opB, gB ? *gB : g, scB, ctx->h_mail + TDX_MAIL_RUN_B, nullptr);
     B.ev_base = 2;
     A.prestarted = B.prestarted = flags0 != nullptr;
     A.batch_max = B.batch_max = RoundRunner<Op>::pipelined_batch_max();
@@ -1590,6 +1668,8 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
                 double(ctx->h_mail[8]) / na);
         fprintf(stderr, "    load split: issue tile loads %.0f, issue cell loads %.0f, wait+LDS stores %.0f, barrier %.0f\n", double(ctx->h_mail[9]) / na,
                 double(ctx->h_mail[10]) / na, double(ctx->h_mail[11]) / na, double(ctx->h_mail[12]) / na);
+        if (ctx->h_mail[14]) fprintf(stderr, "    macro blocks: %llu updates, %.0f cycles each, at most %llu per workgroup and look\n", (unsigned long long)ctx->h_mail[14],
+                                    double(ctx->h_mail[13]) / double(ctx->h_mail[14]), (unsigned long long)ctx->h_mail[15]);
     }
     if (rounds_out) *rounds_out += rounds;
     if (launches_out) *launches_out += launches;
