@@ -88,6 +88,8 @@ typedef struct tdx_stats {
  * Fails with TDX_ERR_NOGPU when no HIP device is available: there is no CPU fallback. */
 int tdx_context_create(int device, tdx_context** ctx);
 void tdx_context_destroy(tdx_context* ctx);
+/* frees the context's scratch arena (it grows again on demand): for hosts that keep one context across workloads of very different sizes */
+int tdx_context_release_scratch(tdx_context* ctx);
 const char* tdx_last_error(const tdx_context* ctx); /* ctx may be NULL: last error of the calling thread */
 int tdx_synchronize(tdx_context* ctx);
 void* tdx_stream(tdx_context* ctx);                  /* the hipStream_t all work is enqueued on */

@@ -110,6 +110,7 @@ _F = C.c_float
 _SIGNATURES = {
     "tdx_context_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "tdx_context_destroy": (None, [_P]),
+    "tdx_context_release_scratch": (C.c_int, [_P]),
     "tdx_last_error": (C.c_char_p, [_P]),
     "tdx_synchronize": (C.c_int, [_P]),
     "tdx_stream": (_P, [_P]),

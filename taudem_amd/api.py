@@ -56,6 +56,10 @@ class Context:
                 self._lib.tdx_context_destroy(self._h)
             self._h = None
 
+    def release_scratch(self):
+        """Frees the scratch arena (it grows again on demand)."""
+        check(self._lib.tdx_context_release_scratch(self._h), self._h)
+
     def set_option(self, name: str, value: int):
         """Context options of include/taudem_amd.h (e.g. "kernel_timing")."""
         check(self._lib.tdx_context_set_option(self._h, name.encode(), int(value)), self._h)

@@ -1108,149 +1108,6 @@ __global__ __launch_bounds__(64) void ad8_big_fold_kernel(int contcheck, int sca
 }
 
 
-// ---- big cells in LEVEL order (round 5, second half; an A/B hook - it lost: see aread8_tiled) ----------------------------------------------------------------------------------------------
-// The fold above walks the list in count order: consecutive main-stem cells land in one 64-entry chunk and are handed on one after the other
-// (~0.12 us per cell), a tree of 10^5 cells costs 12 ms - and the forest is bushy: the largest tree of a 65536 x 8192 strip holds ~10^5 cells
-// on chains of a few thousand (scripts: 15 - 40 cells per level).  So the list is ordered by the DISTANCE TO THE TREE'S ROOT instead (pointer
-// jumping with hop counts), farthest first: a pending contributor of a cell is exactly one level further out, cells of one level do not
-// depend on each other, and a 64-entry chunk never needs a serial step.  One wave folds level after level, the previous level's values in
-// LDS; three more waves stage the next block of records (flags, cell, level, the eight addends in k order - a pending contributor as a
-// NaN-tagged list position) from global memory into LDS meanwhile, so the folding wave never waits for HBM.
-constexpr uint32_t BIG_REF = 0x7FC00000u;   // quiet-NaN tag of a slot that refers to a pending contributor's list position (low 22 bits)
-constexpr int BIG_REC = 12;                 // words per record: flags, cell, level key, (pad), eight slots
-constexpr int BIG_SB = 640;                 // records per staged block (2 x 640 x 48 B of LDS)
-constexpr int BIG_CAP = 8192;               // values of a level kept in LDS (2 x 32 KB); a larger level continues through global memory
-__global__ __launch_bounds__(256) void ad8_big_next_dist_kernel(const int16_t* __restrict__ P, int nx, int y_own0, int y_own1, const uint32_t* __restrict__ list,
-                                                                unsigned long long nbig, const uint32_t* __restrict__ pos, const float* __restrict__ A,
-                                                                uint32_t* __restrict__ nxt, uint32_t* __restrict__ dist) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
-    const size_t c = size_t(list[q]);
-    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-    const int p = P[c];
-    uint32_t r = uint32_t(q), d = 0u;   // a root: the flow ends, leaves the strip, or goes on into a cell that is not big
-    if (p >= 1 && p <= 8) {
-        const int xn = x + d1(p), yn = y + d2(p);
-        if (xn >= 0 && xn < nx && yn >= y_own0 && yn < y_own1) {
-            const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-            if (A[n] == BIG_MARK) { r = pos[n]; d = 1u; }
-        }
-    }
-    nxt[q] = r; dist[q] = d;
-}
-__global__ __launch_bounds__(256) void ad8_big_jump_dist_kernel(const uint32_t* __restrict__ nin, const uint32_t* __restrict__ din, uint32_t* __restrict__ nout,
-                                                                uint32_t* __restrict__ dout, unsigned long long nbig) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nbig) return;
-    const uint32_t j = nin[q];
-    dout[q] = din[q] + din[j];   // (a root points at itself with distance 0)
-    nout[q] = nin[j];
-}
-__global__ __launch_bounds__(256) void ad8_big_level_keys_kernel(const uint32_t* __restrict__ dist, unsigned long long nbig, uint32_t* __restrict__ keys) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q < nbig) keys[q] = 0xFFFFFFFFu - dist[q];   // ascending key = farthest from the root first
-}
-// records of the (still pending) cells of the list, in list order
-__global__ __launch_bounds__(256) void ad8_big_records_kernel(const int16_t* __restrict__ P, int nx, int ny, int y_own0, int y_own1, int16_t nodata,
-                                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ level, const unsigned long long* __restrict__ n_dev,
-                                                              const uint32_t* __restrict__ pos, const float* __restrict__ A, uint32_t* __restrict__ rec) {
-    const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= *n_dev) return;
-    const size_t c = size_t(list[q]);
-    const int x = int(c % size_t(nx)), y = int(c / size_t(nx));
-    uint32_t f = BIGF_PENDING, slot[8];
-#pragma unroll
-    for (int k = 1; k <= 8; k++) {
-        uint32_t sv = 0u;   // 0.0f: adds nothing to a sum >= 1
-        const int xn = x + d1(k), yn = y + d2(k);
-        if (xn < 0 || xn >= nx || yn < 0 || yn >= ny) f |= BIGF_CON;
-        else {
-            const size_t n = size_t(yn) * size_t(nx) + size_t(xn);
-            const int16_t pn = P[n];
-            if (is_nodata_s(pn, nodata)) f |= BIGF_CON;
-            else if (pn - k == 4 || pn - k == -4) {
-                const float v = A[n];
-                if (v == BIG_MARK) {
-                    if (yn >= y_own0 && yn < y_own1) sv = BIG_REF | pos[n];   // one level further out: folded just before this cell
-                    else f |= BIGF_BLOCKED;                                   // a pending cell of a neighbouring strip blocks this round
-                } else if (is_nodata_f(v, TDX_AREA_NODATA)) f |= BIGF_CON;
-                else sv = __float_as_uint(v);
-            }
-        }
-        slot[k - 1] = sv;
-    }
-    uint32_t* r = rec + q * BIG_REC;
-    *reinterpret_cast<uint4*>(r) = make_uint4(f, uint32_t(c), level[q], 0u);
-    *reinterpret_cast<uint4*>(r + 4) = make_uint4(slot[0], slot[1], slot[2], slot[3]);
-    *reinterpret_cast<uint4*>(r + 8) = make_uint4(slot[4], slot[5], slot[6], slot[7]);
-}
-__global__ __launch_bounds__(256) void ad8_big_fold_levels_kernel(int contcheck, const unsigned long long* __restrict__ n_dev, const uint32_t* __restrict__ rec,
-                                                                  float* __restrict__ bigval, float* __restrict__ A) {
-    __shared__ uint4 s_rec[2][BIG_SB * (BIG_REC / 4)];
-    __shared__ float s_lv[2][BIG_CAP];
-    const unsigned long long n = *n_dev;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long nsb = (n + BIG_SB - 1) / BIG_SB;
-    auto stage = [&](unsigned long long sb, int buf, int t0, int nt) {
-        const unsigned long long first = sb * BIG_SB, cnt = (n - first < (unsigned long long)BIG_SB) ? n - first : (unsigned long long)BIG_SB;
-        const uint4* src = reinterpret_cast<const uint4*>(rec + first * BIG_REC);
-        for (unsigned long long i = t0; i < cnt * (BIG_REC / 4); i += nt) s_rec[buf][i] = src[i];
-    };
-    if (nsb) stage(0, 0, tid, 256);
-    __syncthreads();
-    // the folding wave's state: the level being folded starts at list position b (its values in s_lv[cur]), the one before at pb
-    unsigned long long b = 0, pb = 0;
-    uint32_t tag = 0xFFFFFFFFu;   // (no level yet: the first entry opens one)
-    int cur = 0;
-    bool first_level = true, spilled = false;
-    for (unsigned long long sb = 0; sb < nsb; sb++) {
-        if (wave > 0) {
-            if (sb + 1 < nsb) stage(sb + 1, int((sb + 1) & 1), tid - 64, 192);
-        } else {
-            const uint4* R = s_rec[sb & 1];
-            const unsigned long long r0 = sb * BIG_SB, r1 = (n - r0 < (unsigned long long)BIG_SB) ? n : r0 + BIG_SB;
-            unsigned long long p = r0;
-            while (p < r1) {
-                const unsigned long long q = p + (unsigned long long)lane;
-                const bool in = q < r1;
-                const uint4 h = R[(in ? q - r0 : p - r0) * (BIG_REC / 4)];   // flags, cell, level key
-                const uint32_t tag_p = uint32_t(__builtin_amdgcn_readfirstlane(int(h.z)));
-                if (first_level || tag_p != tag) {   // a new level: what was folded becomes "the level before"
-                    if (spilled) { drain_stores(); spilled = false; }
-                    if (!first_level) { cur ^= 1; pb = b; }
-                    b = p; tag = tag_p; first_level = false;
-                }
-                const unsigned long long same = __ballot(in && h.z == tag_p);
-                const int cnt = same == ~0ull ? 64 : __builtin_ctzll(~same);   // the leading lanes of this level
-                if (lane < cnt) {
-                    const uint4 s0 = R[(q - r0) * (BIG_REC / 4) + 1], s1 = R[(q - r0) * (BIG_REC / 4) + 2];
-                    const uint32_t sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                    float a = 1.0f;
-                    bool c2 = (h.x & BIGF_CON) != 0u, blk = (h.x & BIGF_BLOCKED) != 0u;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        float v = __uint_as_float(sl[k]);
-                        if ((sl[k] & BIG_REF) == BIG_REF) {   // a contributor of the level before
-                            const unsigned long long d = (unsigned long long)(sl[k] & 0x3FFFFFu);
-                            v = (d - pb < (unsigned long long)BIG_CAP) ? s_lv[cur ^ 1][d - pb] : ld_agent(&bigval[d]);
-                            if (v == BIG_MARK) { blk = true; v = 0.f; }
-                            else if (is_nodata_f(v, TDX_AREA_NODATA)) { c2 = true; v = 0.f; }
-                        }
-                        a = a + v;
-                    }
-                    if (c2 && contcheck == 1) a = TDX_AREA_NODATA;
-                    const float result = blk ? BIG_MARK : a;
-                    if (q - b < (unsigned long long)BIG_CAP) s_lv[cur][q - b] = result;
-                    else { st_agent(&bigval[q], result); spilled = true; }
-                    if (!blk) A[h.y] = result;   // read again only after this kernel (exchange / host)
-                }
-                spilled = __builtin_amdgcn_readfirstlane(int(__ballot(spilled) != 0ull)) != 0;
-                p += (unsigned long long)cnt;
-            }
-        }
-        __syncthreads();
-    }
-}
 }  // namespace
 
 
@@ -1357,11 +1214,8 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
                  *segbeg = listB + nb1;
         uint32_t* pos = cellw;   // list position of every big cell (the per-cell words are no longer needed once the keys are out)
         const bool no_trees = getenv("TDX_AD8_BIG_ONE_WAVE") != nullptr;                   // (A/B hook, read per call: one wave folds the whole list in count order)
-        // default: count order, one wave per tree.  TDX_AD8_BIG_LEVELS=1 (A/B hook): LEVEL order (distance to the tree's root, farthest first: no serial step
-        // inside a chunk; ad8_big_fold_levels_kernel) - bit-identical, measured 3 - 5 x SLOWER: a level step is a chain of dependent LDS round trips
-        // (~0.5 us) where the count-order fold hands a value on in registers (0.12 us per cell), and main stems are chains (docs/experiments_r05.md)
-        static const bool by_levels = getenv("TDX_AD8_BIG_LEVELS") != nullptr;
-        const bool levels = !no_trees && by_levels && nbig < (1ull << 22);   // (a record refers to a list position in 22 bits)
+        // count order, one wave per tree.  (Round 5 also built the fold in LEVEL order - distance to the tree's root, no serial step inside a chunk: bit-identical and
+        // 3 - 5 x slower, a level step is a chain of dependent LDS round trips where this fold hands a value on in registers; docs/experiments_r05.md section 1.  Retired in round 6.)
         static const bool no_incremental = getenv("TDX_AD8_BIG_FULL_ROUNDS") != nullptr;   // (A/B hook: every outer round on the whole list)
         // in-chunk dependencies of the count-order fold by pointer jumping when at least this many cells of a 64-entry chunk wait for another cell of the chunk
         // (TDX_AD8_BIG_SCAN=0: always one after the other - A/B hook; read per call)
@@ -1371,22 +1225,7 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         uint32_t *cur = sorted, *cur_root = rootA, *other = listB, *other_root = rootB;
         unsigned long long* n_cur = d_cnt;            // the apply pass's counter = the first list's length
         const unsigned gb = tdx_blocks_for(nb1, 256);
-        if (nbig && levels) {
-            // distance of every big cell to the root of its tree: pointer jumping with hop counts over the (unsorted) list, then the list by falling distance
-            hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(gb), dim3(256), 0, s, biglist, n_cur, pos);
-            uint32_t *ra = keys, *da = keys_sorted, *rb = rootA, *db = rootB;
-            hipLaunchKernelGGL(ad8_big_next_dist_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.y0, st.y1, biglist, nbig, pos, d_ad8, ra, da);
-            for (unsigned long long reach = 1; reach < nbig; reach *= 2) {   // after j steps a pointer spans 2^j cells of its chain
-                hipLaunchKernelGGL(ad8_big_jump_dist_kernel, dim3(gb), dim3(256), 0, s, ra, da, rb, db, nbig);
-                std::swap(ra, rb); std::swap(da, db);
-            }
-            hipLaunchKernelGGL(ad8_big_level_keys_kernel, dim3(gb), dim3(256), 0, s, da, nbig, grouped);
-            rc = tdx_sort_pairs_u32(ctx, TDX_S_I, grouped, listB, biglist, sorted, size_t(nbig));
-            if (rc != TDX_OK) return rc;
-            cur = sorted; cur_root = listB;                 // (cur_root: the level keys)
-            other = (ra == keys) ? rootA : keys;            // two arrays the jumping no longer needs
-            other_root = (ra == keys) ? rootB : keys_sorted;
-        } else if (nbig) {
+        if (nbig) {
             hipLaunchKernelGGL(ad8_big_keys_kernel, dim3(gb), dim3(256), 0, s, biglist, nbig, cellw, keys);
             rc = tdx_sort_pairs_u32(ctx, TDX_S_I, keys, keys_sorted, biglist, sorted, size_t(nbig));
             if (rc != TDX_OK) return rc;
@@ -1419,11 +1258,6 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
         for (;;) {
             if (nbig) {
                 hipLaunchKernelGGL(ad8_big_pos_kernel, dim3(gb), dim3(256), 0, s, cur, n_cur, pos);
-                if (levels) {
-                    uint32_t* recs = reinterpret_cast<uint32_t*>(big_vals);   // (12 of the 18 words per cell; big_val behind them)
-                    hipLaunchKernelGGL(ad8_big_records_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, cur, cur_root, n_cur, pos, d_ad8, recs);
-                    hipLaunchKernelGGL(ad8_big_fold_levels_kernel, dim3(1), dim3(256), 0, s, contcheck, n_cur, recs, big_val, d_ad8);
-                } else {
                 hipLaunchKernelGGL(ad8_big_gather_kernel, dim3(gb), dim3(256), 0, s, d_p, inx, st.ny_arr, st.y0, st.y1, p_nodata, cur, n_cur, pos, d_ad8, big_vals,
                                    big_deps, big_flags, big_val);
                 if (no_trees)
@@ -1433,7 +1267,6 @@ static int aread8_tiled(tdx_context* ctx, const Strip& st, int16_t* d_p, int16_t
                     hipLaunchKernelGGL(ad8_big_segments_kernel, dim3(1), dim3(1024), 0, s, cur_root, n_cur, segbeg, d_cnt + 6);
                     hipLaunchKernelGGL(ad8_big_fold_kernel, dim3(unsigned(std::min<unsigned long long>(nbig, 2ull * unsigned(ctx->num_cus)))), dim3(64), 0, s, contcheck, big_scan, big_ring, cur,
                                        n_cur, segbeg, d_cnt + 6, big_vals, big_deps, big_flags, big_val, d_ad8, d_cnt + 2);
-                }
                 }
                 if (st.multi() && !no_incremental) {
                     unsigned long long* n_next = d_cnt + 4 + flip;

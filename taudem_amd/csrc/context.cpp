@@ -234,6 +234,18 @@ void tdx_context_destroy(tdx_context* c) {
     delete c;
 }
 
+// Gives the scratch arena back to the device (the slots grow again with the next call that needs them): for a host that keeps a context alive across
+// workloads of very different sizes - a 32768^2 raster, then eight contexts of other ranks on the same GPU.
+int tdx_context_release_scratch(tdx_context* c) {
+    if (!c) return TDX_ERR_ARG;
+    TDX_HIP_CHECK(c, hipSetDevice(c->device));
+    if (c->stream) TDX_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) TDX_HIP_CHECK(c, hipStreamSynchronize(c->stream2));
+    for (auto& s : c->slots) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+    c->fact_dxc.clear(); c->fact_dyc.clear();   // (the distance table lived in a slot)
+    return TDX_OK;
+}
+
 const char* tdx_last_error(const tdx_context* c) { return c ? c->err.c_str() : g_tdx_thread_error.c_str(); }
 
 int tdx_synchronize(tdx_context* c) {

@@ -170,165 +170,8 @@ __global__ __launch_bounds__(256) void dinf_slope_kernel(const float* __restrict
     (void)block_reserve(nfl, nflat);   // one atomic per block
 }
 
-// ---- the slope pass as TWO kernels (round 5) -----------------------------------------------------------------------
-// dinf_slope_kernel spends ~770 VALU instructions per cell on eight fp64 facets of which one wins.  Pass A decides in fp32, without a
-// division, WHICH facets can win; pass B evaluates those - typically one - exactly as before.
-//
-// Pass A: per facet the fp32 image of VSLOPE's slope (reciprocal cell sizes from the host; the branch A < 0 is decided exactly - it is the
-// sign of E1 - E2 -, the branch A > AD by the fp32 cross product: VSLOPE's three closed forms are continuous across both borders, so a facet
-// on the wrong side of a border still gets its slope to fp32 accuracy).  Every step is one rounding of a product / sum of positive terms
-// or a difference of two float32 inputs: the result is within a few 2^-23 of the exact slope, RELATIVE - so a facet whose image is
-// more than 1e-5 (relative) below the largest image cannot hold the largest exact slope.  Kept: every facet within that band; of two
-// facets whose exact slope is THE SAME EXPRESSION - both on the branch A < 0 with the same cardinal neighbour, or both on A > AD (by a
-// clear margin) with the same diagonal neighbour - only the first (the reference's strict `>` keeps the first, src/dinf.cpp:356-362).
-// Images outside [1e-30, 1e30] (underflowing products) keep every facet.  mask 0 = no facet has a positive slope: a flat cell.
-struct RowGeomF { float dx, dy, idx, idy, idd; };
-__global__ __launch_bounds__(256) void dinf_candidates_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
-                                                              const RowGeomF* __restrict__ geom, uint8_t* __restrict__ CAND) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = y_own0 + blockIdx.y * (4 * DSLOPE_ROWS) + (threadIdx.x >> 6) * DSLOPE_ROWS;
-    const bool colok = x < nx;
-    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    auto ldrow = [&](int y, float (&row)[3]) {   // (rows outside the array are never used: edge cells are not evaluated)
-        const int yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
-        const float* r = Z + size_t(yc) * size_t(nx);
-        row[0] = r[xm]; row[1] = r[xc]; row[2] = r[xp];
-    };
-    float w[3][3];   // rows y - 1, y, y + 1 (a rolling window: the 18-row form held 54 registers and ran at three waves per SIMD)
-    ldrow(ybase - 1, w[0]);
-    ldrow(ybase, w[1]);
-#pragma unroll 2
-    for (int r = 0; r < DSLOPE_ROWS; r++) {
-        const int y = ybase + r;
-        ldrow(y + 1, w[2]);
-        if (colok && y < y_own1) {
-        const float z0 = w[1][1];
-        unsigned mask = 0;
-        const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
-        if (!edge) {   // (nodata / contaminated cells: pass B decides from its own window and ignores the mask)
-            const RowGeomF g = geom[y];
-            float sv[8];
-            unsigned k0 = 0, k1 = 0;   // facets decided to lie on the branch A < 0 / clearly on A > AD
-            float smax = 0.f;
-#pragma unroll
-            for (int K = 1; K <= 8; K++) {
-                const float e1 = w[1 + fI1(K)][1 + fJ1(K)], e2 = w[1 + fI2(K)][1 + fJ2(K)];
-                float sK = 0.f;
-                if (e1 < z0 || e2 < z0) {
-                    const bool one = fID1_is1(K);
-                    const float D1 = one ? g.dx : g.dy, D2 = one ? g.dy : g.dx, i1 = one ? g.idx : g.idy, i2 = one ? g.idy : g.idx;
-                    const float d1v = z0 - e1, d2v = e1 - e2;
-                    const float s1 = d1v * i1, s2 = d2v * i2;
-                    if (d2v < 0.f) { sK = s1; k0 |= 1u << (K - 1); }                       // A < 0: S = S1 (d2v == 0 falls through: S2 = 0)
-                    else if (d1v <= 0.f) { sK = (z0 - e2) * g.idd; k1 |= 1u << (K - 1); }   // S1 <= 0 < S2 (or both 0): A > AD, exactly
-                    else {
-                        const float l = s2 * D1, rr = s1 * D2;
-                        if (l > rr) { sK = (z0 - e2) * g.idd; if (l - rr > 1e-4f * (l + rr)) k1 |= 1u << (K - 1); }
-                        else { const float mx = fmaxf(s1, s2), mn = fminf(s1, s2), t = mn * __frcp_rn(mx); sK = mx * __fsqrt_rn(1.f + t * t); }
-                    }
-                }
-                sv[K - 1] = sK;
-                smax = fmaxf(smax, sK);   // (a NaN image is never the maximum and never within the band: its exact slope is NaN too and never wins)
-            }
-            if (smax > 0.f) {
-                const bool wild = !(smax >= 1e-30f && smax <= 1e30f);
-                const float lo = smax - 1e-5f * smax;
-#pragma unroll
-                for (int K = 1; K <= 8; K++)
-                    if (sv[K - 1] > 0.f && (wild || sv[K - 1] >= lo)) mask |= 1u << (K - 1);
-                if (wild) {   // every facet the one-kernel form would have evaluated
-                    mask = 0;
-#pragma unroll
-                    for (int K = 1; K <= 8; K++) {
-                        const float e1 = w[1 + fI1(K)][1 + fJ1(K)], e2 = w[1 + fI2(K)][1 + fJ2(K)];
-                        if (e1 < z0 || e2 < z0) mask |= 1u << (K - 1);
-                    }
-                } else {
-                    // same expression, same value: the later facet can never replace the earlier one
-                    if ((mask & k0 & 0x01u) && (k0 & 0x80u)) mask &= ~0x80u;   // facets 1, 8: east neighbour
-                    if ((mask & k0 & 0x02u) && (k0 & 0x04u)) mask &= ~0x04u;   // 2, 3: north
-                    if ((mask & k0 & 0x08u) && (k0 & 0x10u)) mask &= ~0x10u;   // 4, 5: west
-                    if ((mask & k0 & 0x20u) && (k0 & 0x40u)) mask &= ~0x40u;   // 6, 7: south
-                    if ((mask & k1 & 0x01u) && (k1 & 0x02u)) mask &= ~0x02u;   // 1, 2: north-east neighbour
-                    if ((mask & k1 & 0x04u) && (k1 & 0x08u)) mask &= ~0x08u;   // 3, 4: north-west
-                    if ((mask & k1 & 0x10u) && (k1 & 0x20u)) mask &= ~0x20u;   // 5, 6: south-west
-                    if ((mask & k1 & 0x40u) && (k1 & 0x80u)) mask &= ~0x80u;   // 7, 8: south-east
-                }
-            }
-        }
-        CAND[size_t(y) * size_t(nx) + size_t(x)] = uint8_t(mask);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { w[0][i] = w[1][i]; w[1][i] = w[2][i]; }
-    }
-}
-
-// Pass B: dinf_slope_kernel with the facet loop over the candidates only - ONE facet body with a run-time facet index (the compact form of
-// dinf_set2flat_kernel: its registers no longer compete with eight unrolled bodies).
-__global__ __launch_bounds__(256) void dinf_slope_select_kernel(const float* __restrict__ Z, int nx, int ny, int y_own0, int y_own1, float nodata,
-                                                                const RowGeom* __restrict__ geom, const uint8_t* __restrict__ CAND, float* __restrict__ ANG,
-                                                                float* __restrict__ SLP, unsigned long long* __restrict__ nflat) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ybase = y_own0 + blockIdx.y * (4 * DSLOPE_ROWS) + (threadIdx.x >> 6) * DSLOPE_ROWS;
-    const bool colok = x < nx;
-    const int xc = colok ? x : nx - 1, xm = xc > 0 ? xc - 1 : xc, xp = xc < nx - 1 ? xc + 1 : xc;
-    auto ldrow = [&](int y, float& a, float& b, float& c) {
-        if (y >= 0 && y < ny) {
-            const float* r = Z + size_t(y) * size_t(nx);
-            a = r[xm]; b = r[xc]; c = r[xp];
-        } else { a = b = c = nodata; }
-    };
-    float n0, n1, n2, c0, c1, c2, s0, s1, s2;
-    ldrow(ybase - 1, n0, n1, n2);
-    ldrow(ybase, c0, c1, c2);
-    unsigned nfl = 0;
-#pragma unroll 1
-    for (int r = 0; r < DSLOPE_ROWS; r++) {
-        const int y = ybase + r;
-        ldrow(y + 1, s0, s1, s2);
-        if (colok && y < y_own1) {
-            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-            unsigned m = CAND[idx];
-            float ang = TDX_ANG_NODATA, slp = -1.0f;
-            const float z0 = c1;
-            const bool edge = (x == 0 || y == 0 || x == nx - 1 || y == ny - 1);
-            if (!edge && !is_nodata_f(z0, nodata)) {
-                const bool con = is_nodata_f(n0, nodata) || is_nodata_f(n1, nodata) || is_nodata_f(n2, nodata) || is_nodata_f(c0, nodata) ||
-                                 is_nodata_f(c2, nodata) || is_nodata_f(s0, nodata) || is_nodata_f(s1, nodata) || is_nodata_f(s2, nodata);
-                if (!con) {
-                    const RowGeom g = geom[y];
-                    double SMAX = 0., S1W = 0., S2W = 0.;
-                    int KD = 0, KINDW = 0;
-                    const double a = (double)z0;
-                    for (; m; m &= m - 1u) {   // the candidates in facet order
-                        const int K = __ffs(int(m));
-                        const int j1 = facet_cardinal(K), j2 = facet_diagonal(K);
-                        const float e1 = sel4(j1, c2, n1, c0, s1), e2 = sel4(j2, n2, n0, s0, s2);
-                        double D1, D2, AD, sa, sb;
-                        facet_geom(g, K, D1, D2, AD);
-                        int kind;
-                        const double S = vslope_s(a, (double)e1, (double)e2, D1, D2, g.dd, AD, &kind, &sa, &sb);
-                        if (S > SMAX) { SMAX = S; KD = K; KINDW = kind; S1W = sa; S2W = sb; }
-                    }
-                    ang = -1.f;
-                    if (KD > 0) {
-                        double AD, D1, D2;
-                        facet_geom(g, KD, D1, D2, AD);
-                        const double AMAX = KINDW == 0 ? 0. : (KINDW == 1 ? AD : ((S2W == 0 && S1W == 0) ? 0. : atan2(S2W, S1W)));
-                        ang = (float)(fANGC_rt(KD) * (TDX_PI / 2) + fANGF_rt(KD) * AMAX);
-                    }
-                    slp = (float)SMAX;
-                    if (ang == -1.f) nfl++;
-                }
-            }
-            ANG[idx] = ang;
-            SLP[idx] = slp;
-        }
-        n0 = c0; n1 = c1; n2 = c2;
-        c0 = s0; c1 = s1; c2 = s2;
-    }
-    (void)block_reserve(nfl, nflat);   // one atomic per block
-}
+// (Round 5 also built the slope pass as TWO kernels - an fp32 candidate mask, then fp64 on the candidates: bit-identical, slower (8.4 + 15.3 against 22.3 ms at
+// 32768^2: the candidate pass is itself ~260 VALU instructions per cell); docs/experiments_r05.md section 2b.  Retired in round 6.)
 
 struct DinfTraits {
     const float* ANG;
@@ -506,16 +349,9 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
         g.ad21 = atan2(dxc[j], dyc[j]);
         geom[size_t(j)] = g;
     }
-    // ... and its float32 image for the candidate pass (reciprocals: that pass has no division)
-    std::vector<RowGeomF> geomf;
-    geomf.resize(size_t(iny));
-    for (int j = 0; j < iny; j++) geomf[size_t(j)] = RowGeomF{float(dxc[j]), float(dyc[j]), float(1.0 / dxc[j]), float(1.0 / dyc[j]), float(1.0 / geom[size_t(j)].dd)};
-    char* geom_mem = static_cast<char*>(ctx->scratch(TDX_S_J, geom.size() * (sizeof(RowGeom) + sizeof(RowGeomF))));
-    if (!geom_mem) return TDX_ERR_NOMEM;
-    RowGeom* d_geom = reinterpret_cast<RowGeom*>(geom_mem);
-    RowGeomF* d_geomf = reinterpret_cast<RowGeomF*>(geom_mem + geom.size() * sizeof(RowGeom));
+    RowGeom* d_geom = static_cast<RowGeom*>(ctx->scratch(TDX_S_J, geom.size() * sizeof(RowGeom)));
+    if (!d_geom) return TDX_ERR_NOMEM;
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_geom, geom.data(), geom.size() * sizeof(RowGeom), hipMemcpyHostToDevice, s));
-    TDX_HIP_CHECK(ctx, hipMemcpyAsync(d_geomf, geomf.data(), geomf.size() * sizeof(RowGeomF), hipMemcpyHostToDevice, s));
     TDX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(ctx->d_mail);
 
@@ -528,17 +364,7 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
     {
         TdxSpan sp(ctx, TDX_K_STENCIL);
         dim3 grid((inx + 63) / 64, (st.y1 - st.y0 + 4 * DSLOPE_ROWS - 1) / (4 * DSLOPE_ROWS));
-        // default: all eight facets in fp64 in ONE kernel.  TDX_DINF_SLOPE_TWO_PASS=1 (A/B hook): fp32 candidate mask + fp64 on the candidates - bit-identical,
-        // measured SLOWER at 32768^2 (8.4 + 15.3 ms against 22.3: the candidate pass is itself ~260 VALU instructions per cell, the run-time-K fp64 body
-        // needs 121 VGPRs; profiles/r05i_dinf_slope_two_vs_one.txt, docs/experiments_r05.md)
-        static const bool one_pass = getenv("TDX_DINF_SLOPE_TWO_PASS") == nullptr;
-        uint8_t* cand = one_pass ? nullptr : static_cast<uint8_t*>(ctx->scratch(TDX_S_A, n));   // (the slot of the level field: not in use yet)
-        if (one_pass || !cand)
-            hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geom, d_ang, d_slp, d_cnt);
-        else {
-            hipLaunchKernelGGL(dinf_candidates_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geomf, cand);
-            hipLaunchKernelGGL(dinf_slope_select_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geom, cand, d_ang, d_slp, d_cnt);
-        }
+        hipLaunchKernelGGL(dinf_slope_kernel, grid, dim3(256), 0, s, d_fel, inx, iny, st.y0, st.y1, fel_nodata, d_geom, d_ang, d_slp, d_cnt);   // all eight facets in fp64 in one kernel
         if (stats) stats->launches[TDX_K_STENCIL]++;
     }
     TDX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_mail, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -74,11 +74,13 @@ template <class Traits, class LV>
 __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* __restrict__ Z, int nx, int tiles_x,
                                                        const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
                                                        LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                       uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
+                                                       uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, uint32_t* __restrict__ fullcnt) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * CLASSIFY_ITEMS) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < CLASSIFY_ITEMS; i++) {
         const unsigned long long q = base + (unsigned long long)i * 256;
+        unsigned my_tile = 0xFFFFFFFFu;   // (OPEN WATER: cells per tile and field that may move and look at all eight neighbours - a tile with 4096 of them is full)
+        bool full_f = false, full_r = false;
         if (q < nq) {
             const size_t c = list[q];
             const float z0 = Z[c];
@@ -108,8 +110,27 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
             const unsigned tile = (y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS;
             tile_flags[tile] = tilek::FLAG_FULL;
             if (!low && fm != rm) tile_masked[tile] = 1;   // an in-queue neighbour that incfall must not read: no plain tile (see LevelPlainT)
+            my_tile = tile; full_f = !low && fm == 0xFFu; full_r = !higher && rm == 0xFFu;
+        }
+        if (fullcnt != nullptr) {   // one atomic per wave and field where the wave's 64 list entries lie in one tile (the list is in raster order: nearly always)
+            const unsigned t0 = unsigned(__builtin_amdgcn_readfirstlane(int(my_tile)));
+            const bool same = my_tile == t0;
+            const unsigned long long bf = __ballot(same && full_f), br = __ballot(same && full_r);
+            if ((threadIdx.x & 63) == 0 && t0 != 0xFFFFFFFFu) {
+                if (bf) atomicAdd(&fullcnt[2 * size_t(t0)], unsigned(__popcll(bf)));
+                if (br) atomicAdd(&fullcnt[2 * size_t(t0) + 1], unsigned(__popcll(br)));
+            }
+            if (!same && my_tile != 0xFFFFFFFFu) {
+                if (full_f) atomicAdd(&fullcnt[2 * size_t(my_tile)], 1u);
+                if (full_r) atomicAdd(&fullcnt[2 * size_t(my_tile) + 1], 1u);
+            }
         }
     }
+}
+// the marks find_blocks_kernel reads, from the list classification's counts: a tile is not full for a field unless all its 4096 cells are
+static __global__ __launch_bounds__(256) void notfull_from_counts_kernel(const uint32_t* __restrict__ fullcnt, int n2, uint8_t* __restrict__ notfull) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) notfull[i] = fullcnt[i] == unsigned(tilek::TS * tilek::TS) ? 0 : 1;
 }
 
 // level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move.  S = storage type of the field in
@@ -319,6 +340,13 @@ struct LevelOpT {
         // inside a loop with an LDS store is waited for before the next one is issued - the first version spent 12 memory latencies here)
         S raw_rim[4][2], raw_ring[4][3];
         unsigned ring_ok = 0;
+        // (the first 4 (k + 2) threads also fetch, now, which node of the schedule stands for "their" tile outside the block: needed only at the very end)
+        int out_target = -1;
+        if (tid < 4 * (k + 2)) {
+            const int e = tid / (k + 2), j = tid % (k + 2) - 1;
+            const int ntx = e == 2 ? tx0 - 1 : (e == 3 ? tx0 + k : tx0 + j), nty = e == 0 ? ty0 - 1 : (e == 1 ? ty0 + k : ty0 + j);
+            if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) out_target = int(g.remap[size_t(nty) * g.tiles_x + ntx]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -436,11 +464,8 @@ struct LevelOpT {
         // the tiles outside the block along each edge (positions -1 .. k: the corners' diagonal neighbours too) that can be improved
         if (tid < 4 * (k + 2)) {
             const int e = tid / (k + 2), j = tid % (k + 2) - 1;
-            const int near = (moved[e] >> (j + 1)) & 1;
-            const int ntx = e == 2 ? tx0 - 1 : (e == 3 ? tx0 + k : tx0 + j), nty = e == 0 ? ty0 - 1 : (e == 1 ? ty0 + k : ty0 + j);
-            if (near && ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) {
-                const uint32_t target = g.remap[size_t(nty) * g.tiles_x + ntx];
-                if (atomicMax(&flags_next[target], tilek::FLAG_HALO) == 0u) TL.pend[atomicAdd(&TL.npend, 1u)] = target;
+            if (((moved[e] >> (j + 1)) & 1) && out_target >= 0) {
+                if (atomicMax(&flags_next[out_target], tilek::FLAG_HALO) == 0u) TL.pend[atomicAdd(&TL.npend, 1u)] = uint32_t(out_target);
             }
         }
         __syncthreads();
@@ -655,10 +680,14 @@ static __global__ __launch_bounds__(256) void macro_fill_kernel(FillArgs a0, Fil
 // per-tile "needs its masks" marks (tm_mode 0: none, 1: every tile, 2: the first half - the TDX_FLATS_MASKED hooks) and the count rings of both round schedules.
 static __global__ __launch_bounds__(256) void prepare_kernel(unsigned long long* __restrict__ d_cnt, uint32_t* __restrict__ flags0, uint8_t* __restrict__ tmask, int ntiles,
                                                              int tm_mode, unsigned long long* __restrict__ countsA, unsigned long long* __restrict__ countsB,
-                                                             uint16_t* __restrict__ notfull) {
+                                                             uint8_t* __restrict__ notfull, uint32_t* __restrict__ fullcnt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 8) d_cnt[t] = 0ull;
-    if (t < ntiles) { flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2)); if (notfull) notfull[t] = 0; }
+    if (t < ntiles) {
+        flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2));
+        if (notfull) { notfull[2 * t] = 0; notfull[2 * t + 1] = 0; }
+        if (fullcnt) { fullcnt[2 * t] = 0u; fullcnt[2 * t + 1] = 0u; }
+    }
     if (t < 2 * tilek::COUNT_RING) { countsA[t] = 0ull; if (countsB) countsB[t] = 0ull; }
 }
 
@@ -827,18 +856,19 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         const char* e_macro = getenv("TDX_FLATS_MACRO");
         macro_k = e_macro ? atoi(e_macro) : flatk::MACRO_KMAX;
         macro_k = macro_k >= 8 ? 8 : (macro_k >= 4 ? 4 : (macro_k >= 2 ? 2 : 0));
-        if (!stream_classify || getenv("TDX_FLATS_FUSED") != nullptr || getenv("TDX_RELAX_LDS") != nullptr || no_plain || half_plain) macro_k = 0;
+        if (getenv("TDX_FLATS_FUSED") != nullptr || getenv("TDX_RELAX_LDS") != nullptr || no_plain || half_plain) macro_k = 0;
     }
-    uint8_t* notfull = nullptr; uint32_t *remapF = nullptr, *remapR = nullptr, *fill_list = nullptr; uint8_t *blkF = nullptr, *blkR = nullptr;
+    uint8_t* notfull = nullptr; uint32_t *remapF = nullptr, *remapR = nullptr, *fill_list = nullptr, *fullcnt = nullptr; uint8_t *blkF = nullptr, *blkR = nullptr;
     if (macro_k) {
-        // [notfull 2 nt][blkF nt][blkR nt][remapF 4 nt][remapR 4 nt][fill_list 2 x 4 nt]
-        uint8_t* m = static_cast<uint8_t*>(ctx->scratch(TDX_S_MACRO, size_t(ntiles) * 20 + 64));
+        // [notfull 2 nt][blkF nt][blkR nt][remapF 4 nt][remapR 4 nt][fill_list 2 x 4 nt][fullcnt 2 x 4 nt: the list classification's counts]
+        uint8_t* m = static_cast<uint8_t*>(ctx->scratch(TDX_S_MACRO, size_t(ntiles) * 28 + 64));
         if (!m) return TDX_ERR_NOMEM;
         notfull = m; blkF = m + 2 * size_t(ntiles); blkR = blkF + ntiles;
         remapF = reinterpret_cast<uint32_t*>(m + 4 * size_t(ntiles)); remapR = remapF + ntiles; fill_list = remapR + ntiles;
+        if (!stream_classify) fullcnt = fill_list + 2 * size_t(ntiles);
     }
     hipLaunchKernelGGL(flatk::prepare_kernel, dim3(tdx_blocks_for(size_t(std::max(ntiles, 2 * tilek::COUNT_RING)), 256)), dim3(256), 0, s, d_cnt, flags0, tmask, ntiles,
-                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB, reinterpret_cast<uint16_t*>(notfull));
+                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB, notfull, fullcnt);
     if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask, notfull);
     else {
         // The list classification writes the masks of the QUEUE's cells only.  The register tile kernel reads a mask byte only where the level marker says
@@ -851,7 +881,8 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         }
         if (nq)
             hipLaunchKernelGGL((flatk::classify_kernel<Traits, LV>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
-                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask);
+                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask, fullcnt);
+        if (fullcnt) hipLaunchKernelGGL(flatk::notfull_from_counts_kernel, dim3(tdx_blocks_for(size_t(2 * ntiles), 256)), dim3(256), 0, s, fullcnt, 2 * ntiles, notfull);
     }
     int rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;

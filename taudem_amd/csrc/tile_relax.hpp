@@ -967,15 +967,16 @@ __device__ __forceinline__ void macro_role(const Op& op, const TileGeom& g, cons
         if (threadIdx.x < 64u) {
             const unsigned i = base + nblocks * threadIdx.x;
             const uint32_t e = i < nact ? list[i] : 0u;
-            if (i < nact && g.blk_k[e] != 0) L.pulled[atomicAdd(&L.next, 1u)] = e;
+            const unsigned kk = i < nact ? unsigned(g.blk_k[e]) : 0u;
+            if (kk != 0u) L.pulled[atomicAdd(&L.next, 1u)] = e | (kk << 27);   // (tile indices stay below 2^27: 2^32 cells / 4096 per tile = 2^20)
         }
         __syncthreads();
         const unsigned nb = L.next;
         if (dbg && threadIdx.x == 0 && nb) atomicMax(dbg + 15, (unsigned long long)nb);   // TDX_DEBUG_ROUNDS=1: most blocks one workgroup served in one look
         for (unsigned b = 0; b < nb; b++) {
-            const int tile = int(L.pulled[b]);
+            const int tile = int(L.pulled[b] & 0x7ffffffu), kb = int(L.pulled[b] >> 27);
             const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
-            (void)op.macro_update(g, tile, int(g.blk_k[tile]), lds, L, flags_next);   // (ends with a barrier)
+            (void)op.macro_update(g, tile, kb, lds, L, flags_next);   // (ends with a barrier)
             if (dbg && threadIdx.x == 0) { atomicAdd(dbg + 13, __builtin_readcyclecounter() - tc0); atomicAdd(dbg + 14, 1ull); }   // cycles in block updates, updates
             const unsigned npend = L.npend;
             if (threadIdx.x == 0) L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;

@@ -429,6 +429,7 @@ def test_config4_full_height_every_cell(ctx, oracle, monkeypatch):
     import taudem_amd as T
     from taudem_amd.distributed import StripPipeline
 
+    ctx.release_scratch()      # (the session context's arena - sized by the 32768^2 tests - goes first: eight more contexts share this GPU)
     torch.cuda.empty_cache()
     nx = ny = 65536
     size, seed = 8, 1234
@@ -491,6 +492,7 @@ def test_config5_full_height_every_cell(ctx, oracle, monkeypatch):
     import bench
     import taudem_amd as T
 
+    ctx.release_scratch()
     torch.cuda.empty_cache()
     monkeypatch.setenv("TDX_SWEEP_VERIFY", "1")
     nx = ny = 65536
