@@ -74,13 +74,11 @@ template <class Traits, class LV>
 __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* __restrict__ Z, int nx, int tiles_x,
                                                        const uint32_t* __restrict__ list, unsigned long long nq, LV* __restrict__ lvl,
                                                        LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                       uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, uint32_t* __restrict__ fullcnt) {
+                                                       uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked) {
     const unsigned long long base = (unsigned long long)blockIdx.x * (256 * CLASSIFY_ITEMS) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < CLASSIFY_ITEMS; i++) {
         const unsigned long long q = base + (unsigned long long)i * 256;
-        unsigned my_tile = 0xFFFFFFFFu;   // (OPEN WATER: cells per tile and field that may move and look at all eight neighbours - a tile with 4096 of them is full)
-        bool full_f = false, full_r = false;
         if (q < nq) {
             const size_t c = list[q];
             const float z0 = Z[c];
@@ -110,27 +108,8 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
             const unsigned tile = (y / tilek::TS) * unsigned(tiles_x) + x / tilek::TS;
             tile_flags[tile] = tilek::FLAG_FULL;
             if (!low && fm != rm) tile_masked[tile] = 1;   // an in-queue neighbour that incfall must not read: no plain tile (see LevelPlainT)
-            my_tile = tile; full_f = !low && fm == 0xFFu; full_r = !higher && rm == 0xFFu;
-        }
-        if (fullcnt != nullptr) {   // one atomic per wave and field where the wave's 64 list entries lie in one tile (the list is in raster order: nearly always)
-            const unsigned t0 = unsigned(__builtin_amdgcn_readfirstlane(int(my_tile)));
-            const bool same = my_tile == t0;
-            const unsigned long long bf = __ballot(same && full_f), br = __ballot(same && full_r);
-            if ((threadIdx.x & 63) == 0 && t0 != 0xFFFFFFFFu) {
-                if (bf) atomicAdd(&fullcnt[2 * size_t(t0)], unsigned(__popcll(bf)));
-                if (br) atomicAdd(&fullcnt[2 * size_t(t0) + 1], unsigned(__popcll(br)));
-            }
-            if (!same && my_tile != 0xFFFFFFFFu) {
-                if (full_f) atomicAdd(&fullcnt[2 * size_t(my_tile)], 1u);
-                if (full_r) atomicAdd(&fullcnt[2 * size_t(my_tile) + 1], 1u);
-            }
         }
     }
-}
-// the marks find_blocks_kernel reads, from the list classification's counts: a tile is not full for a field unless all its 4096 cells are
-static __global__ __launch_bounds__(256) void notfull_from_counts_kernel(const uint32_t* __restrict__ fullcnt, int n2, uint8_t* __restrict__ notfull) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n2) notfull[i] = fullcnt[i] == unsigned(tilek::TS * tilek::TS) ? 0 : 1;
 }
 
 // level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move.  S = storage type of the field in
@@ -321,8 +300,10 @@ struct LevelOpT {
 
     // One activation of a macro block (see OPEN WATER above; tilek::relax_kernel calls it for a block's first tile, all 256 threads): the rim of the k x k tile
     // block from the ring around it, in closed form; rim cells that moved are stored and the tiles outside the block that touch them are activated.
-    __device__ __forceinline__ int macro_update(const tilek::TileGeom& g, int tile, int k, int* __restrict__ lds, tilek::TileLds& TL, uint32_t* __restrict__ flags_next) const {
+    __device__ __forceinline__ int macro_update(const tilek::TileGeom& g, int tile, int k, int* __restrict__ lds, tilek::TileLds& TL, uint32_t* __restrict__ flags_next,
+                                                unsigned long long* __restrict__ dbg = nullptr) const {
         const int tid = int(threadIdx.x);
+        const unsigned long long tq0 = dbg ? __builtin_readcyclecounter() : 0ull;
         const int W = k * tilek::TS, L = W + 2;
         const int tx0 = tile % g.tiles_x, ty0 = tile / g.tiles_x;
         const int X0 = tx0 * tilek::TS, Y0 = ty0 * tilek::TS;
@@ -364,14 +345,14 @@ struct LevelOpT {
                 const int xc = x < 0 ? 0 : (x >= g.nx ? g.nx - 1 : x), yc = y < 0 ? 0 : (y >= g.ny ? g.ny - 1 : y);
                 raw_ring[E][u] = G[size_t(yc) * pitch + size_t(xc)];
             }
-        int old[4][2];
+        int old[4][2], best[4][2];   // a thread's (up to) two cells of each rim edge: their levels as loaded, the best offer so far
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = tid + u * 256;
                 old[e][u] = i < W ? decode(raw_rim[e][u]) : MACRO_INF;
-                if (i < W) acc[e * AW + i] = old[e][u];
+                best[e][u] = old[e][u];
             }
         if (tid < 8) moved[tid] = 0;   // [0 .. 4): per ring edge, bit p + 1 = the tile outside at position p (-1 .. k) can be improved; [4 .. 8): the ring edge holds a level at all
 #pragma unroll
@@ -393,26 +374,54 @@ struct LevelOpT {
             __syncthreads();
             macro_edge_scans(h, L, pre, suf, pm, sp);
             __syncthreads();
-            for (int i = tid; i < W; i += 256) {
+            // Offers of ring edge E to the four rim edges.  With E and e known at compile time (both loops are unrolled) the general form
+            // min_j h[j] + max(|a - j|, d) = min(d + min of h over [a - d, a + d], a + pm[a - d - 1], sp[a + d + 1] - a)       (macro_offer)
+            // - a = position along the ring edge, d = distance from its line - collapses to one to five LDS reads without a branch:
+            //   the edge beside the rim (d = 1): three cells and the two far terms; the edge across (d = W): W + the edge's minimum, one number for all;
+            //   an edge at right angles (a = 1 or a = W, d = 1 .. W): a prefix or suffix minimum and one far term.
+            const int all_min = pre[L - 1];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    // position of rim cell i of edge e against ring edge E: index a along the ring edge, distance d from its line
-                    int a, d;
-                    if (E < 2) {          // a horizontal ring row: along = x + 1
-                        a = e == 2 ? 1 : (e == 3 ? W : i + 1);
-                        const int y = e == 0 ? 0 : (e == 1 ? W - 1 : i);
-                        d = E == 0 ? y + 1 : W - y;
-                    } else {              // a vertical ring column: along = y + 1
-                        a = e == 0 ? 1 : (e == 1 ? W : i + 1);
-                        const int x = e == 2 ? 0 : (e == 3 ? W - 1 : i);
-                        d = E == 2 ? x + 1 : W - x;
+            for (int u = 0; u < 2; u++) {
+                const int i = tid + u * 256;
+                if (i < W) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        int off;
+                        const bool horiz_E = E < 2, horiz_e = e < 2;
+                        if (horiz_E == horiz_e) {
+                            if (E == e) {            // beside: a = i + 1, d = 1
+                                const int a = i + 1;
+                                int m3 = h[a - 1] < h[a] ? h[a - 1] : h[a]; m3 = h[a + 1] < m3 ? h[a + 1] : m3;
+                                off = m3 + 1;
+                                if (a - 2 >= 0) { const int f = pm[a - 2] + a; off = f < off ? f : off; }
+                                if (a + 2 <= L - 1) { const int f = sp[a + 2] - a; off = f < off ? f : off; }
+                            } else off = all_min + W;   // across
+                        } else {
+                            // at right angles: the rim cell's coordinate ALONG edge e is i; its distance from ring edge E's line is i + 1 (E on the low side: 0, 2) or W - i
+                            const int d = (E & 1) == 0 ? i + 1 : W - i;
+                            if ((e & 1) == 0) {      // rim edge on the low side (top / left): the cell sits at a = 1 of ring edge E
+                                off = d + pre[1 + d < L - 1 ? 1 + d : L - 1];
+                                if (d + 2 <= L - 1) { const int f = sp[d + 2] - 1; off = f < off ? f : off; }
+                            } else {                 // on the high side (bottom / right): a = W
+                                off = d + suf[W - d > 0 ? W - d : 0];
+                                if (W - d - 1 >= 0) { const int f = pm[W - d - 1] + W; off = f < off ? f : off; }
+                            }
+                        }
+                        best[e][u] = off < best[e][u] ? off : best[e][u];
                     }
-                    const int off = macro_offer(h, pre, suf, pm, sp, L, a, d);
-                    if (off < acc[e * AW + i]) acc[e * AW + i] = off;
                 }
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid + u * 256;
+                if (i < W) acc[e * AW + i] = best[e][u];
+            }
+        __syncthreads();
+        const unsigned long long tq1 = dbg ? __builtin_readcyclecounter() : 0ull;
         // (a corner cell is on two rim edges: both accumulators hold offers for it, the smaller one is its level)
         if (tid < 4) {
             const int ea = tid < 2 ? 0 : 1, ia = (tid & 1) ? W - 1 : 0;     // corner tid: top-left, top-right, bottom-left, bottom-right
@@ -461,6 +470,7 @@ struct LevelOpT {
                 }
             }
         __syncthreads();
+        const unsigned long long tq2 = dbg ? __builtin_readcyclecounter() : 0ull;
         // the tiles outside the block along each edge (positions -1 .. k: the corners' diagonal neighbours too) that can be improved
         if (tid < 4 * (k + 2)) {
             const int e = tid / (k + 2), j = tid % (k + 2) - 1;
@@ -469,6 +479,10 @@ struct LevelOpT {
             }
         }
         __syncthreads();
+        if (dbg && tid == 0) {   // TDX_DEBUG_ROUNDS=1: cycles of the offers (loads + four ring edges), of the stores + gain test, of the activations
+            const unsigned long long tq3 = __builtin_readcyclecounter();
+            atomicAdd(dbg + 9, tq1 - tq0); atomicAdd(dbg + 10, tq2 - tq1); atomicAdd(dbg + 11, tq3 - tq2);
+        }
         return 0;
     }
 };
@@ -680,13 +694,12 @@ static __global__ __launch_bounds__(256) void macro_fill_kernel(FillArgs a0, Fil
 // per-tile "needs its masks" marks (tm_mode 0: none, 1: every tile, 2: the first half - the TDX_FLATS_MASKED hooks) and the count rings of both round schedules.
 static __global__ __launch_bounds__(256) void prepare_kernel(unsigned long long* __restrict__ d_cnt, uint32_t* __restrict__ flags0, uint8_t* __restrict__ tmask, int ntiles,
                                                              int tm_mode, unsigned long long* __restrict__ countsA, unsigned long long* __restrict__ countsB,
-                                                             uint8_t* __restrict__ notfull, uint32_t* __restrict__ fullcnt) {
+                                                             uint8_t* __restrict__ notfull) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 8) d_cnt[t] = 0ull;
     if (t < ntiles) {
         flags0[t] = 0u; tmask[t] = uint8_t(tm_mode == 1 || (tm_mode == 2 && t < (ntiles + 1) / 2));
         if (notfull) { notfull[2 * t] = 0; notfull[2 * t + 1] = 0; }
-        if (fullcnt) { fullcnt[2 * t] = 0u; fullcnt[2 * t + 1] = 0u; }
     }
     if (t < 2 * tilek::COUNT_RING) { countsA[t] = 0ull; if (countsB) countsB[t] = 0ull; }
 }
@@ -849,26 +862,26 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     uint32_t* flagsB = pair ? static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS))) : nullptr;
     unsigned long long* countsB = pair ? static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16)) : nullptr;
     if (pair && (!flagsB || !countsB)) return TDX_ERR_NOMEM;
-    // OPEN WATER (macro blocks of full tiles, see above): with the streaming classification (a dense first queue), int16 fields, both fields side by side on the
-    // register tile kernel.  TDX_FLATS_MACRO=0 switches it off, =2 / 4 / 8 sets the largest block edge (read per call: A/B and test hook).
+    // OPEN WATER (macro blocks of full tiles, see above): with the streaming classification (a dense first queue: D8FlowDir's first iteration), int16 fields, the
+    // register tile kernel.  (From the list classification - DinfFlowDir, later iterations - the per-tile "full" marks were built and measured in round 6: a wave's 64
+    // list entries span three or four tiles, the marks cost more than the rounds they save - DinfFlowDir 24.2 -> 32.6 ms at 16384^2; profiles/r06l_macro_dinf_ab.txt.)  TDX_FLATS_MACRO=0 switches it off, =2 / 4 / 8 sets the largest block edge (read per call: A/B and test hook).
     int macro_k = 0;
     if constexpr (sizeof(LV) == 2) {
         const char* e_macro = getenv("TDX_FLATS_MACRO");
         macro_k = e_macro ? atoi(e_macro) : flatk::MACRO_KMAX;
         macro_k = macro_k >= 8 ? 8 : (macro_k >= 4 ? 4 : (macro_k >= 2 ? 2 : 0));
-        if (getenv("TDX_FLATS_FUSED") != nullptr || getenv("TDX_RELAX_LDS") != nullptr || no_plain || half_plain) macro_k = 0;
+        if (!stream_classify || getenv("TDX_FLATS_FUSED") != nullptr || getenv("TDX_RELAX_LDS") != nullptr || no_plain || half_plain) macro_k = 0;
     }
-    uint8_t* notfull = nullptr; uint32_t *remapF = nullptr, *remapR = nullptr, *fill_list = nullptr, *fullcnt = nullptr; uint8_t *blkF = nullptr, *blkR = nullptr;
+    uint8_t* notfull = nullptr; uint32_t *remapF = nullptr, *remapR = nullptr, *fill_list = nullptr; uint8_t *blkF = nullptr, *blkR = nullptr;
     if (macro_k) {
-        // [notfull 2 nt][blkF nt][blkR nt][remapF 4 nt][remapR 4 nt][fill_list 2 x 4 nt][fullcnt 2 x 4 nt: the list classification's counts]
-        uint8_t* m = static_cast<uint8_t*>(ctx->scratch(TDX_S_MACRO, size_t(ntiles) * 28 + 64));
+        // [notfull 2 nt][blkF nt][blkR nt][remapF 4 nt][remapR 4 nt][fill_list 2 x 4 nt]
+        uint8_t* m = static_cast<uint8_t*>(ctx->scratch(TDX_S_MACRO, size_t(ntiles) * 20 + 64));
         if (!m) return TDX_ERR_NOMEM;
         notfull = m; blkF = m + 2 * size_t(ntiles); blkR = blkF + ntiles;
         remapF = reinterpret_cast<uint32_t*>(m + 4 * size_t(ntiles)); remapR = remapF + ntiles; fill_list = remapR + ntiles;
-        if (!stream_classify) fullcnt = fill_list + 2 * size_t(ntiles);
     }
     hipLaunchKernelGGL(flatk::prepare_kernel, dim3(tdx_blocks_for(size_t(std::max(ntiles, 2 * tilek::COUNT_RING)), 256)), dim3(256), 0, s, d_cnt, flags0, tmask, ntiles,
-                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB, notfull, fullcnt);
+                       no_plain ? 1 : (half_plain ? 2 : 0), counts, countsB, notfull);
     if (stream_classify) (*stream_classify)(geom, fmask, rmask, flags0, tmask, notfull);
     else {
         // The list classification writes the masks of the QUEUE's cells only.  The register tile kernel reads a mask byte only where the level marker says
@@ -881,8 +894,7 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
         }
         if (nq)
             hipLaunchKernelGGL((flatk::classify_kernel<Traits, LV>), dim3(tdx_blocks_for(nq, 256 * flatk::CLASSIFY_ITEMS)), dim3(256), 0, s, tr, Z, nx,
-                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask, fullcnt);
-        if (fullcnt) hipLaunchKernelGGL(flatk::notfull_from_counts_kernel, dim3(tdx_blocks_for(size_t(2 * ntiles), 256)), dim3(256), 0, s, fullcnt, 2 * ntiles, notfull);
+                               geom.tiles_x, qlist, nq, b.lvl, b.rq, fmask, rmask, flags0, tmask);
     }
     int rc = strip_exchange<LV>(ctx, st, b.lvl, LV(-1));   // the neighbours' seeds
     if (rc != TDX_OK) return rc;

@@ -976,7 +976,7 @@ __device__ __forceinline__ void macro_role(const Op& op, const TileGeom& g, cons
         for (unsigned b = 0; b < nb; b++) {
             const int tile = int(L.pulled[b] & 0x7ffffffu), kb = int(L.pulled[b] >> 27);
             const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
-            (void)op.macro_update(g, tile, kb, lds, L, flags_next);   // (ends with a barrier)
+            (void)op.macro_update(g, tile, kb, lds, L, flags_next, dbg);   // (ends with a barrier)
             if (dbg && threadIdx.x == 0) { atomicAdd(dbg + 13, __builtin_readcyclecounter() - tc0); atomicAdd(dbg + 14, 1ull); }   // cycles in block updates, updates
             const unsigned npend = L.npend;
             if (threadIdx.x == 0) L.base = npend ? atomicAdd(count + 1, (unsigned long long)npend) : 0ull;
@@ -1669,8 +1669,9 @@ static int tile_relax_run(tdx_context* ctx, Op op, tilek::TileGeom g, tilek::Sch
                 double(ctx->h_mail[8]) / na);
         fprintf(stderr, "    load split: issue tile loads %.0f, issue cell loads %.0f, wait+LDS stores %.0f, barrier %.0f\n", double(ctx->h_mail[9]) / na,
                 double(ctx->h_mail[10]) / na, double(ctx->h_mail[11]) / na, double(ctx->h_mail[12]) / na);
-        if (ctx->h_mail[14]) fprintf(stderr, "    macro blocks: %llu updates, %.0f cycles each, at most %llu per workgroup and look\n", (unsigned long long)ctx->h_mail[14],
-                                    double(ctx->h_mail[13]) / double(ctx->h_mail[14]), (unsigned long long)ctx->h_mail[15]);
+        if (ctx->h_mail[14]) fprintf(stderr, "    macro blocks: %llu updates, %.0f cycles each (offers %.0f, stores + gain test %.0f, activations %.0f), at most %llu per workgroup and look\n",
+                                    (unsigned long long)ctx->h_mail[14], double(ctx->h_mail[13]) / double(ctx->h_mail[14]), double(ctx->h_mail[9]) / double(ctx->h_mail[14]),
+                                    double(ctx->h_mail[10]) / double(ctx->h_mail[14]), double(ctx->h_mail[11]) / double(ctx->h_mail[14]), (unsigned long long)ctx->h_mail[15]);
     }
     if (rounds_out) *rounds_out += rounds;
     if (launches_out) *launches_out += launches;
