@@ -244,6 +244,52 @@ def test_aread8_tiles_quirks(ctx, oracle):
         assert bits_equal(a, a_o), describe_diff(a, a_o, f"quirks contcheck={cc}")
 
 
+@pytest.mark.parametrize("kmax", ["0", "2", "4", "8"])
+def test_open_water_blocks_change_the_schedule_never_a_value(ctx, oracle, monkeypatch, kmax):
+    """A raster with lakes wide enough for blocks of full tiles of every size (a plateau of 1200 x 1100 cells with islands, an outlet on one side, a pit
+    basin without one): D8FlowDir with the open-water blocks off / up to 2, 4, 8 tiles on edge, one strip and three, against the restatement
+    (src/d8.cpp:523-558,606-638: the level fields are what they are, whatever computes them) - and the blocks must have been used."""
+    from taudem_amd.distributed import StripGroup, StripPipeline, partition_rows
+    import torch
+
+    rng = np.random.default_rng(11)
+    ny, nx = 1500, 1400
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    z = (300.0 + 0.05 * xx + 0.02 * yy + rng.random((ny, nx)) * 0.01).astype(np.float32)
+    z[150:1350, 150:1250] = np.float32(100.0)                       # the lake floor: one big flat after filling
+    for cy, cx, r in ((400, 500, 40), (900, 800, 70), (700, 300, 9), (1100, 1000, 25)):   # islands
+        z[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = np.float32(400.0)
+    z[640:660, 0:160] = np.float32(90.0) - 0.01 * np.arange(160, dtype=np.float32)[::-1]   # an outlet channel to the west edge
+    fel = oracle.pitremove(z, -9999.0)
+    p_o, sd8_o, st_o = oracle.d8flowdir(fel, -3.0e38, 30.0, 30.0)
+    monkeypatch.setenv("TDX_FLATS_MACRO", kmax)
+    p, sd8, st = ctx.d8flowdir(fel, -3.0e38, 30.0, 30.0, stats=True)
+    assert bits_equal(p, p_o), describe_diff(p, p_o, f"p, blocks <= {kmax}")
+    assert bits_equal(sd8, sd8_o)
+    assert st["flats_initial"] == st_o["flats_initial"] > 1000000 and st["levels_fall_max"] > 500
+    if kmax == "0":
+        test_open_water_blocks_change_the_schedule_never_a_value.rounds0 = st["rounds"]
+    elif hasattr(test_open_water_blocks_change_the_schedule_never_a_value, "rounds0"):
+        assert st["rounds"] < test_open_water_blocks_change_the_schedule_never_a_value.rounds0, "the blocks were not used"
+    # three strips: blocks never touch the tile rows at a strip boundary; the halo exchange wakes them like any tile
+    size = 3
+    parts = partition_rows(ny, size)
+    fel_t = torch.from_numpy(fel)
+    with StripGroup(size, nx) as grp:
+        def rank_main(r, c, comm):
+            y0, y1 = parts[r]
+            pipe = StripPipeline(c, comm, nx, y1 - y0)
+            f = pipe.empty(torch.float32)
+            f[1:y1 - y0 + 1].copy_(fel_t[y0:y1])
+            pp, ss, _ = pipe.d8flowdir(f, -3.0e38, 30.0, 30.0)
+            torch.cuda.synchronize()
+            return pp[1:y1 - y0 + 1].cpu().numpy(), ss[1:y1 - y0 + 1].cpu().numpy()
+        res = grp.run(rank_main)
+    p3 = np.concatenate([r[0] for r in res])
+    assert bits_equal(p3, p_o), describe_diff(p3, p_o, f"p in three strips, blocks <= {kmax}")
+    assert bits_equal(np.concatenate([r[1] for r in res]), sd8_o)
+
+
 def test_aread8_direction_codes_outside_0_to_8(ctx, oracle, monkeypatch):
     """A p grid somebody else wrote may hold codes that are neither 0 .. 8 nor the nodata value (13, 14, 15, 20, 100, -5 ...): such a cell does not take part
     (initNeighborD8up, src/commonLib.cpp:257-266), is no nodata cell either and contaminates nobody - every path of the product (tile contraction, dependency

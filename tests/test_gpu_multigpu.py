@@ -32,6 +32,49 @@ def test_rccl_transport_selftest(ctx):
     assert rc == 0, T._lib.last_error(ctx._h)
 
 
+def test_collective_latencies_are_measurable(ctx):
+    """tdx_rccl_latency (one rank to itself) and tdx_comm_latency on a peer group of three rank threads: both primitives of the strip protocol answer with
+    plausible microsecond figures (bench.py puts them in the line and uses the RCCL pair as the projection's default latencies)."""
+    import threading
+
+    out = (C.c_double * 2)()
+    assert ctx._lib.tdx_rccl_latency(ctx._h, 50, 4096 * 4, out) == 0, T._lib.last_error(ctx._h)
+    assert 0.5 < out[0] < 5000 and 0.5 < out[1] < 5000, tuple(out)
+    lib = T.load()
+    size, nx = 3, 4096
+    devs = (C.c_int32 * size)(0, 0, 0)
+    g = C.c_void_p()
+    assert lib.tdx_group_create(size, devs, nx, C.byref(g)) == 0, T._lib.last_error(None)
+    res, errors = [None] * size, []
+
+    def rank_main(r):
+        try:
+            o = (C.c_double * 2)()
+            rc = lib.tdx_comm_latency(C.c_void_p(lib.tdx_group_context(g, r)), C.c_void_p(lib.tdx_group_comm(g, r)), 20, nx * 4, o)
+            assert rc == 0
+            res[r] = (o[0], o[1])
+        except BaseException as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+            lib.tdx_group_abort(g)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(size)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    lib.tdx_group_destroy(g)
+    assert not errors, errors
+    assert all(0.5 < a < 1e5 and 0.5 < b < 1e5 for a, b in res), res
+
+
+def test_release_scratch_and_go_on(ctx, oracle):
+    """tdx_context_release_scratch: the arena goes, the next call builds what it needs."""
+    dem = oracle.synth_dem((300, 280), 5)
+    a = ctx.pitremove(dem, -9999.0)
+    ctx.release_scratch()
+    b = ctx.pitremove(dem, -9999.0)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(b.view(np.uint32), oracle.pitremove(dem, -9999.0).view(np.uint32))
+
+
 def test_group_peer_transport_protocol():
     """tdx_group with 3 ranks on one GPU (peer transport): exchange + all-reduce from three threads, checked like the gloo protocol test."""
     import threading
