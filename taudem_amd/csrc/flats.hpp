@@ -168,7 +168,7 @@ constexpr int MACRO_INF = 0x3fffffff;
 constexpr int MACRO_LDS_WORDS = 5 * MACRO_LMAX + 4 * (MACRO_LMAX - 2) + 8;   // (+ moved[8])   // ring edge: h, pre, suf, pm, sp; rim accumulators t, b, l, r; a few words
 
 // Per aligned 8 x 8 region of tiles and field: the largest aligned blocks (8, 4, 2 tiles on edge) of tiles that are full for the field (notfull[2 t + field] == 0
-// and wholly inside the owned rows / the raster).  remap[t] = first tile of t's block (t itself outside blocks); blk_k[t] = K for a block's first tile, else 0.
+// and wholly inside the owned rows / the raster).  remap[t] = first tile of t's block + log2 K in bits 27-28 (tilek::entry_tile / entry_blk_k), t itself outside blocks; blk_k[t] = K for a block's first tile, else 0.
 // One thread per region and field (blockIdx.y); a region's marks are eight 16-byte rows.
 static __global__ __launch_bounds__(64) void find_blocks_kernel(const uint8_t* __restrict__ notfull, int tiles_x, int tiles_y, int nx, int y_lo, int y_hi, int kmax,
                                                                 uint32_t* __restrict__ remapF, uint8_t* __restrict__ blkF, uint32_t* __restrict__ remapR, uint8_t* __restrict__ blkR) {
@@ -213,7 +213,7 @@ static __global__ __launch_bounds__(64) void find_blocks_kernel(const uint8_t* _
             for (int kk = kmax; kk >= 2 && !k; kk >>= 1) if (full_block(i & ~(kk - 1), j & ~(kk - 1), kk)) k = kk;
             if (k) {
                 const int i0 = i & ~(k - 1), j0 = j & ~(k - 1);
-                remap[t] = uint32_t(size_t(by0 + j0) * tiles_x + bx0 + i0);
+                remap[t] = uint32_t(size_t(by0 + j0) * tiles_x + bx0 + i0) | (uint32_t(k == 8 ? 3 : (k == 4 ? 2 : 1)) << tilek::TILE_BLK_SHIFT);   // (+ log2 K: a list entry)
                 blk_k[t] = uint8_t((i == i0 && j == j0) ? k : 0);
             } else { remap[t] = uint32_t(t); blk_k[t] = 0; }
         }
@@ -223,7 +223,7 @@ static __global__ __launch_bounds__(64) void find_blocks_kernel(const uint8_t* _
 // only a block's first tile is a node of the schedule: the flags the classification raised on its other tiles are dropped
 static __global__ __launch_bounds__(256) void block_flags_kernel(uint32_t* __restrict__ flags, const uint32_t* __restrict__ remap, int ntiles) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < ntiles && remap[t] != uint32_t(t)) flags[t] = 0u;
+    if (t < ntiles && tilek::entry_tile(remap[t]) != t) flags[t] = 0u;
 }
 // inclusive minimum scans of one ring edge h[0 .. L) by ONE wave each: wave 0 prefix of h, 1 suffix of h, 2 prefix of h - j, 3 suffix of h + j
 __device__ __forceinline__ void macro_edge_scans(const int* __restrict__ h, int L, int* __restrict__ pre, int* __restrict__ suf, int* __restrict__ pm, int* __restrict__ sp) {
@@ -475,7 +475,7 @@ struct LevelOpT {
         if (tid < 4 * (k + 2)) {
             const int e = tid / (k + 2), j = tid % (k + 2) - 1;
             if (((moved[e] >> (j + 1)) & 1) && out_target >= 0) {
-                if (atomicMax(&flags_next[out_target], tilek::FLAG_HALO) == 0u) TL.pend[atomicAdd(&TL.npend, 1u)] = uint32_t(out_target);
+                if (atomicMax(&flags_next[tilek::entry_tile(uint32_t(out_target))], tilek::FLAG_HALO) == 0u) TL.pend[atomicAdd(&TL.npend, 1u)] = uint32_t(out_target);
             }
         }
         __syncthreads();
@@ -636,7 +636,7 @@ static __global__ __launch_bounds__(256) void fill_list_kernel(FillArgs a0, Fill
     const FillArgs a = blockIdx.y ? a1 : a0;
     const int t = blockIdx.x * 256 + threadIdx.x;
     bool on = false;
-    if (t < ntiles) { const uint32_t rep = a.remap[t]; on = a.blk_k[rep] != 0 && (uint32_t(t) % uint32_t(tiles_x)) == (rep % uint32_t(tiles_x)); }
+    if (t < ntiles) { const uint32_t rep = uint32_t(tilek::entry_tile(a.remap[t])); on = a.blk_k[rep] != 0 && (uint32_t(t) % uint32_t(tiles_x)) == (rep % uint32_t(tiles_x)); }
     const unsigned long long pos = tdxk::block_reserve(on ? 1u : 0u, a.count);
     if (on) a.list[pos] = uint32_t(t);
 }
@@ -648,7 +648,7 @@ static __global__ __launch_bounds__(256) void macro_fill_kernel(FillArgs a0, Fil
     const unsigned long long n = *a.count;
     const int tid = int(threadIdx.x), lx = tid & 63, wv = tid >> 6;
     for (unsigned long long it = blockIdx.x; it < n; it += gridDim.x) {
-        const int t = int(a.list[it]), rep = int(a.remap[t]), k = int(a.blk_k[rep]);
+        const int t = int(a.list[it]), rep = tilek::entry_tile(a.remap[t]), k = int(a.blk_k[rep]);
         const int W = k * tilek::TS;
         const int X0 = (rep % tiles_x) * tilek::TS, Y0 = (rep / tiles_x) * tilek::TS;
         const int yt = (t / tiles_x) * tilek::TS - Y0;   // this row of tiles inside the block

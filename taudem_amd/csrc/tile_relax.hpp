@@ -61,8 +61,9 @@ struct TileGeom {
     unsigned long long cnt_tag;
     int act_filter;         // 1: a moved rim cell raises a neighbour's flag only if it can improve a cell of it (relax_tile_reg; TDX_ACT_FILTER_OFF=1: every moved rim cell does)
     // MACRO BLOCKS (optional; flats.hpp: open water of a level field).  An aligned K x K block of tiles that an operator can solve in closed form is ONE node
-    // of the schedule: every activation of one of its tiles is redirected to its first tile (remap[t], identity elsewhere), and that tile - blk_k[t] = K, zero
-    // elsewhere - is handed to Op::macro_update instead of the tile kernel.  nullptr: no blocks.
+    // of the schedule: every activation of one of its tiles is redirected to its first tile - remap[t] = that tile's index + log2 K in bits 27-28 (a list entry:
+    // entry_tile / entry_blk_k) for EVERY tile of a block, t itself elsewhere - and the entries of blocks are served by Op::macro_update (macro_role) instead of
+    // the tile kernel.  blk_k[t] = K for a block's first tile, zero elsewhere.  nullptr: no blocks.
     const uint32_t* remap;
     const uint8_t* blk_k;
 };
@@ -157,6 +158,12 @@ struct TileLds {   // LDS of one workgroup
 // itself, which nobody else writes).  FLAG_FULL: look at every cell (first activation, capped activation, or a
 // strip halo ROW inside the tile's area was rewritten by the exchange).
 constexpr uint32_t FLAG_HALO = 1u, FLAG_FULL = 2u;
+// A list entry / an activation target is a tile index (below 2^27: a strip holds at most 2^32 cells = 2^20 tiles of 64 x 64, 2^24 of 16 x 16) and, for the first
+// tile of a MACRO BLOCK (TileGeom::remap), the block's edge as log2 K in bits 27-28: who looks at an entry knows without a further load whether it is a block's.
+constexpr uint32_t TILE_IDX_MASK = 0x07ffffffu;
+constexpr int TILE_BLK_SHIFT = 27;
+__device__ __forceinline__ int entry_tile(uint32_t e) { return int(e & TILE_IDX_MASK); }
+__device__ __forceinline__ int entry_blk_k(uint32_t e) { const unsigned c = (e >> TILE_BLK_SHIFT) & 3u; return c ? 1 << c : 0; }
 
 // A cell that receives its value from OUTSIDE the relaxation (an outlet seed of the upstream closure) is news for every tile that holds one of its
 // 8 neighbours: the relaxation itself only reports cells that MOVE on a rim, so a seed on the first / last row or column of its tile must activate
@@ -827,7 +834,7 @@ __device__ __forceinline__ int activation_target(int res, int tile, const TileGe
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int ntx = tx + ddx[tid], nty = ty + ddy[tid];
         if (ntx >= 0 && ntx < g.tiles_x && nty >= 0 && nty < g.tiles_y) target = nty * g.tiles_x + ntx;
-        if (g.remap != nullptr && target >= 0) target = int(g.remap[target]);   // a tile of a macro block: the block's first tile stands for it
+        if (g.remap != nullptr && target >= 0) target = int(g.remap[target]);   // a tile of a macro block: the block's first tile stands for it (+ the block bits)
     }
     if (tid == 8 && (res & RES_CAPPED)) { target = tile; *flag = FLAG_FULL; }   // not yet at its fixed point: run again, everything dirty
     return target;
@@ -835,7 +842,7 @@ __device__ __forceinline__ int activation_target(int res, int tile, const TileGe
 __device__ __forceinline__ void flag_neighbours(int res, int tile, const TileGeom& g, uint32_t* __restrict__ flags_next, TileLds& L) {
     uint32_t flag;
     const int target = activation_target(res, tile, g, &flag);
-    if (target >= 0 && atomicMax(&flags_next[target], flag) == 0u) L.pend[atomicAdd(&L.npend, 1u)] = uint32_t(target);
+    if (target >= 0 && atomicMax(&flags_next[entry_tile(uint32_t(target))], flag) == 0u) L.pend[atomicAdd(&L.npend, 1u)] = uint32_t(target);
 }
 // ---- schedule 1: rounds, ONE launch per round.  Workgroups pull the tiles of the current round's list from a device
 // cursor (1 ... PULL_MAX list entries per atomic, depending on the size of the round), consume (read + clear) their
@@ -884,9 +891,15 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
             __syncthreads();
         }
         for (unsigned it = first; it < last; it++) {
-            int tile = fixed ? int(entry0) : int(L.pulled[it - first]);
+            const uint32_t ent = fixed ? entry0 : L.pulled[it - first];
+            int tile = entry_tile(ent);
             bool full = flags_cur[tile] >= FLAG_FULL;
             int res;
+            if (entry_blk_k(ent)) {   // a macro block: served by the block workgroups of this launch (macro_role); here only its flag is taken down
+                __syncthreads();      // (every lane has read the flag)
+                if (threadIdx.x == 0) flags_cur[tile] = 0u;
+                continue;
+            }
             // REQUIREMENT of the hand-over below: while a schedule is in a solo round NOTHING else reads or writes the field it relaxes - true for every
             // caller (one field per schedule; the pair / fused runs of flats.hpp drive two DIFFERENT fields, the dependency sweeps own their work array).
             // A caller that shares a field between two concurrent schedules must switch it off (TileGeom::chain_max = 0).
@@ -911,8 +924,8 @@ __device__ __forceinline__ void round_driver(const uint32_t* __restrict__ list, 
                 __syncthreads();
                 const int ch = L.chain;
                 if (ch == -1) break;
-                if (g.blk_k != nullptr && g.blk_k[ch & 0x7fffffff] != 0) break;   // a macro block is never entered by hand-over: it is flagged for its own workgroups (below)
-                tile = ch & 0x7fffffff;   // (the next body()'s first barrier comes after every lane has read L.chain)
+                if (entry_blk_k(uint32_t(ch))) break;   // a macro block is never entered by hand-over: it is flagged for its own workgroups (below)
+                tile = entry_tile(uint32_t(ch));   // (the next body()'s first barrier comes after every lane has read L.chain)
                 full = ch < 0;
             }
             if (res & (RES_CHANGED | RES_CAPPED)) flag_neighbours(res, tile, g, flags_next, L);
@@ -958,23 +971,9 @@ __device__ __forceinline__ void macro_role(const Op& op, const TileGeom& g, cons
                                            unsigned long long* __restrict__ dbg) {
     const unsigned nact = unsigned(count[0]);
     if (threadIdx.x == 0) L.npend = 0u;
-    // 64 list entries per look (at most PULL_MAX = 64 blocks to remember), STRIDED over the list: neighbouring entries - blocks activated by the same front - go
-    // to different workgroups (a workgroup that took 64 consecutive entries served a dozen blocks one after the other while the others idled: 500 us per round)
-    for (unsigned base = bid; base < nact; base += nblocks * 64u) {
-        __syncthreads();                                   // (L.pulled of the previous batch has been read)
-        if (threadIdx.x == 0) L.next = 0u;
-        __syncthreads();
-        if (threadIdx.x < 64u) {
-            const unsigned i = base + nblocks * threadIdx.x;
-            const uint32_t e = i < nact ? list[i] : 0u;
-            const unsigned kk = i < nact ? unsigned(g.blk_k[e]) : 0u;
-            if (kk != 0u) L.pulled[atomicAdd(&L.next, 1u)] = e | (kk << 27);   // (tile indices stay below 2^27: 2^32 cells / 4096 per tile = 2^20)
-        }
-        __syncthreads();
-        const unsigned nb = L.next;
-        if (dbg && threadIdx.x == 0 && nb) atomicMax(dbg + 15, (unsigned long long)nb);   // TDX_DEBUG_ROUNDS=1: most blocks one workgroup served in one look
+    auto serve = [&](unsigned nb) {   // the blocks in L.pulled[0 .. nb): update, then append what they activated to the next round's list
         for (unsigned b = 0; b < nb; b++) {
-            const int tile = int(L.pulled[b] & 0x7ffffffu), kb = int(L.pulled[b] >> 27);
+            const int tile = entry_tile(L.pulled[b]), kb = entry_blk_k(L.pulled[b]);
             const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0ull;
             (void)op.macro_update(g, tile, kb, lds, L, flags_next, dbg);   // (ends with a barrier)
             if (dbg && threadIdx.x == 0) { atomicAdd(dbg + 13, __builtin_readcyclecounter() - tc0); atomicAdd(dbg + 14, 1ull); }   // cycles in block updates, updates
@@ -986,6 +985,58 @@ __device__ __forceinline__ void macro_role(const Op& op, const TileGeom& g, cons
             __syncthreads();
             if (threadIdx.x == 0) L.npend = 0u;
         }
+    };
+    // A round of up to 4096 entries - every round but the first few: EVERY block workgroup numbers the round's blocks in list order (16 entries per thread, one
+    // workgroup-wide prefix count) and serves the blocks whose number is its own modulo the number of block workgroups: no workgroup serves two blocks while
+    // another idles (with list entries dealt out by index, 150 blocks on 1 024 workgroups met two to four at a time in one of them: rounds of 35 - 76 us).
+    if (nact <= 4096u) {
+        constexpr int PER = 16;
+        uint32_t ent[PER];
+        unsigned kk[PER];
+        const unsigned first = threadIdx.x * PER;
+        (void)first;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { const unsigned i = unsigned(j) * NTHR + threadIdx.x; ent[j] = i < nact ? list[i] : 0u; }   // (coalesced; any numbering all workgroups agree on will do)
+        unsigned mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { kk[j] = unsigned(entry_blk_k(ent[j])); mine += kk[j] != 0u; }
+        // exclusive prefix of `mine` over the workgroup's 256 threads
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off, 64); if ((threadIdx.x & 63) >= unsigned(off)) incl += t; }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 63) L.pend[threadIdx.x >> 6] = incl;   // (the pend array is idle here)
+        if (threadIdx.x == 0) L.next = 0u;
+        __syncthreads();
+        unsigned before = incl - mine;
+        for (unsigned w = 0; w < (threadIdx.x >> 6); w++) before += L.pend[w];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if (kk[j] != 0u) {
+                if (before % nblocks == bid) { const unsigned slot = atomicAdd(&L.next, 1u); if (slot < unsigned(PULL_MAX)) L.pulled[slot] = ent[j]; }
+                before++;
+            }
+        __syncthreads();
+        if (dbg && threadIdx.x == 0 && L.next) atomicMax(dbg + 15, (unsigned long long)L.next);
+        serve(L.next < unsigned(PULL_MAX) ? L.next : unsigned(PULL_MAX));   // (at most 4096 / 4 blocks over >= 256 workgroups: never more than 4 each)
+        return;
+    }
+    // 64 list entries per look (at most PULL_MAX = 64 blocks to remember), STRIDED over the list: neighbouring entries - blocks activated by the same front - go
+    // to different workgroups (a workgroup that took 64 consecutive entries served a dozen blocks one after the other while the others idled: 500 us per round)
+    for (unsigned base = bid; base < nact; base += nblocks * 64u) {
+        __syncthreads();                                   // (L.pulled of the previous batch has been read)
+        if (threadIdx.x == 0) L.next = 0u;
+        __syncthreads();
+        if (threadIdx.x < 64u) {
+            const unsigned i = base + nblocks * threadIdx.x;
+            const uint32_t e = i < nact ? list[i] : 0u;
+            if (i < nact && entry_blk_k(e)) L.pulled[atomicAdd(&L.next, 1u)] = e;
+        }
+        __syncthreads();
+        const unsigned nb = L.next;
+        if (dbg && threadIdx.x == 0 && nb) atomicMax(dbg + 15, (unsigned long long)nb);   // TDX_DEBUG_ROUNDS=1: most blocks one workgroup served in one look
+        serve(nb);
     }
 }
 
@@ -1007,9 +1058,6 @@ __global__ __launch_bounds__(NTHR, relax_waves<Op>::value) void relax_kernel(Op 
     }
     const unsigned nblocks = grid_tiles != 0u ? grid_tiles : gridDim.x;
     round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) {
-        if constexpr (REG && has_macro<Op>::value) {   // the first tile of a macro block: left to the block workgroups of this launch
-            if (g.blk_k != nullptr && __builtin_amdgcn_readfirstlane(int(g.blk_k[tile])) != 0) { __syncthreads(); return 0; }
-        }
         if constexpr (REG && has_plain<Op>::value) {   // tiles whose masks only say "may move" take the uniform form of the operator (flats.hpp)
             if (!__builtin_amdgcn_readfirstlane(int(op.tile_masked(tile)))) return relax_tile_reg(op.plain(), g, tile, sV, L, dbg);
         }
@@ -1178,11 +1226,13 @@ static __global__ void async_start_kernel(AsyncCtl c, const unsigned long long* 
 
 // round 0: activation flags -> tile list (the flags stay: the relaxation kernel consumes them); count must be zero on entry
 static __global__ __launch_bounds__(256) void first_list_kernel(const uint32_t* __restrict__ flags, int ntiles, uint32_t* __restrict__ list,
-                                                                unsigned long long* __restrict__ count) {
+                                                                unsigned long long* __restrict__ count, const uint32_t* __restrict__ remap) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const bool on = t < ntiles && flags[t] != 0u;
     const unsigned long long pos = block_reserve(on ? 1u : 0u, count);   // one atomic per block: 1024 wave-level atomics on one counter cost 50 us
-    if (on) list[pos] = uint32_t(t);
+    uint32_t e = uint32_t(t);
+    if (on && remap != nullptr && entry_tile(remap[t]) == t) e = remap[t];   // (a macro block's first tile carries the block bits: TileGeom::remap)
+    if (on) list[pos] = e;
 }
 
 // Round 0 of TWO schedules that start from the same activation flags (the two level fields of a flat iteration, flats.hpp), in ONE launch: both first flag
@@ -1195,12 +1245,13 @@ static __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* 
     const int t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t f = t < ntiles ? flags0[t] : 0u;
     // (macro blocks, TileGeom::remap: only a block's first tile is a node of the schedule - every tile of a block is flagged by the classification, so it is)
-    const uint32_t fa = (remapA != nullptr && t < ntiles && remapA[t] != uint32_t(t)) ? 0u : f, fb = (remapB != nullptr && t < ntiles && remapB[t] != uint32_t(t)) ? 0u : f;
+    const uint32_t ra = (remapA != nullptr && t < ntiles) ? remapA[t] : uint32_t(t), rb = (remapB != nullptr && t < ntiles) ? remapB[t] : uint32_t(t);
+    const uint32_t fa = entry_tile(ra) != t ? 0u : f, fb = entry_tile(rb) != t ? 0u : f;
     if (t < ntiles) { flagsA[t] = fa; flagsB[t] = fb; flagsA1[t] = 0u; flagsB1[t] = 0u; }
     const unsigned long long pa = block_reserve(fa != 0u ? 1u : 0u, countA);
-    if (fa != 0u) listA[pa] = uint32_t(t);
+    if (fa != 0u) listA[pa] = ra;    // (a block's first tile: with the block bits)
     const unsigned long long pb = block_reserve(fb != 0u ? 1u : 0u, countB);
-    if (fb != 0u) listB[pb] = uint32_t(t);
+    if (fb != 0u) listB[pb] = rb;
 }
 // Round 0 with EVERY tile active (the first relaxation of a PitRemove level): flags, list, count ring and the second flag half in one launch instead of
 // three fills and first_list_kernel.
@@ -1336,7 +1387,7 @@ struct RoundRunner {
         }
         TDX_HIP_CHECK(ctx, hipMemsetAsync(sc.counts, 0, size_t(2 * COUNT_RING) * sizeof(unsigned long long), s));
         TDX_HIP_CHECK(ctx, hipMemsetAsync(flags_of(1), 0, size_t(ntiles) * 4, s));
-        hipLaunchKernelGGL(first_list_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, list_of(0), sc.counts);
+        hipLaunchKernelGGL(first_list_kernel, dim3(cgrid), dim3(256), 0, s, sc.flags, ntiles, list_of(0), sc.counts, g.remap);
         r = 0; parity = 0;
         r_enq = 0; parity_enq = 0; n_enq = 0; n_col = 0;
         return TDX_OK;
