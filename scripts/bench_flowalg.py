@@ -11,6 +11,7 @@ import taudem_amd as T
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=16384)
 ap.add_argument("--only", default="", help="comma-separated tool names (default: all)")
+ap.add_argument("--digest", action="store_true", help="also CRC-32 of every result raster (schedule experiments: the bits must not move)")
 a = ap.parse_args()
 n = a.size
 ctx = T.Context(0)
@@ -35,6 +36,9 @@ def timed(name, fn):
     torch.cuda.synchronize()
     out = fn()
     res[name] = out[-1]["ms_total"]
+    if a.digest:
+        import zlib
+        res[name + "_crc"] = [zlib.crc32(o.cpu().numpy().tobytes()) for o in out[:-1] if torch.is_tensor(o)]
 timed("aread8_weighted", lambda: ctx.aread8(p, weights=w, stats=True))
 timed("d8flowpathextremeup", lambda: ctx.d8flowpathextremeup(p, w, stats=True))
 timed("gridnet", lambda: ctx.gridnet(p, -32768, 30.0, 30.0, stats=True))

@@ -175,12 +175,11 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     }
 };
 
-constexpr int QCAP = 512;
 constexpr int QFWD = 128;   // forward policies: only a fork whose branches become ready at once uses the queue
 template <class Alg, int TSZ>
 struct Lds {
-    static constexpr int QLEN = Alg::kMaxRelease <= 2 ? QFWD : QCAP;
     static constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH;
+    static constexpr int QLEN = Alg::kMaxRelease <= 2 ? QFWD : 1;   // (reverse policies run sweep_tile_rev: no walks, no queue; their Lds serves the verifier)
     typename Alg::Cell v[LH * LH];
     typename Alg::Aux aux[Alg::HAS_AUX ? TS * TS : 1];
     float dist[Alg::HAS_DIST ? TS * 9 : 1];
@@ -192,7 +191,7 @@ struct Lds {
     // around its decrements (a cell that is not there decrements the lane's spare word)
     uint32_t tw[Alg::kMaxRelease <= 2 ? TS * TS : 1];
     uint32_t spare[Alg::kMaxRelease <= 2 ? 64 : 1];
-    uint16_t q[2][Alg::kMaxRelease <= 2 ? QFWD : QCAP];   // ready cells handed on to the next phase (a finished cell may release several)
+    uint16_t q[2][QLEN];   // ready cells handed on to the next phase (a finished cell may release several)
     unsigned nq[2];
     int rim;
     int over;                    // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
@@ -445,6 +444,133 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     return res;
 }
 
+// ---- reverse policies (kMaxRelease > 2: DinfUpDependence, DinfRevAccum) -------------------------------------------------------
+// A cell waits for its at most TWO receivers and a finished cell releases up to eight senders: a wide front, for which lockstep sweeps
+// to the end beat the walks (docs/experiments_r02_r04.md).  Measured in round 6 (profiles/r06o_reverse_round_times.txt): a round took
+// ~280 us whether 130 or 5 000 tiles were active - the time of the slowest tile, up to ~48 sweeps of >= 5 us each, because every sweep
+// re-read the info word and all eight neighbour records of each pending cell and every evaluation recomputed the two fp64 proportions
+// (two divisions + the sector table) inside a divergent branch.  Here everything a pending cell needs is made ONCE per activation and
+// kept in registers - the window offsets of its two receivers, whether each counts, the two proportions, its own input record - so a
+// sweep is two LDS loads per pending cell (all issued before the first use), two pattern compares and, for a ready cell, a multiply-add
+// per receiver.  Only the work array goes through LDS.  The policy supplies
+//   rev_row(inf, aux, a2, k, on, p)   receivers in ascending k (the reference's order), which of them count, their proportions
+//   eval2(aux, on, p, n) -> Cell      the value from the receivers' records
+// and keeps eval() for the verifier, which re-evaluates every cell from the final records with the original expression.
+template <class Alg, int TSZ>
+struct LdsRev {
+    static constexpr int LH = Dim<TSZ>::LH;
+    typename Alg::Cell v[LH * LH];
+    int rim;
+};
+
+template <class Alg, int TSZ>
+__device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileGeom& g, int tile, LdsRev<Alg, TSZ>& S, const Arrays<Alg>& A) {
+    using Cell = typename Alg::Cell;
+    using Aux = typename Alg::Aux;
+    constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL, NSTAGE = Dim<TSZ>::NSTAGE;
+    const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
+    const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    const int x0 = tx * TS, y0 = ty * TS;
+    if (tid == 0) S.rim = 0;
+    uint32_t si[RPL];
+    Aux sa[RPL];
+    double srow[RPL];
+    unsigned oki = 0;
+    {   // every load before the first LDS store; addresses clamped, validity applied afterwards
+        Cell s0[NSTAGE];
+        unsigned ok = 0;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT, ec = e < LH * LH ? e : LH * LH - 1;
+            const int wy = ec / LH, wx = ec - wy * LH;
+            const int gx = x0 - 1 + wx, gy = y0 - 1 + wy;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) ok |= 1u << i;
+            const int gxc = gx < 0 ? 0 : (gx >= g.nx ? g.nx - 1 : gx), gyc = gy < 0 ? 0 : (gy >= g.ny ? g.ny - 1 : gy);
+            s0[i] = A.v[size_t(gyc) * size_t(g.nx) + size_t(gxc)];
+        }
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            const int gx = x0 + lx, gy = y0 + ry0 + r;
+            if (gx < g.nx && gy < g.ny) oki |= 1u << r;
+            const int gyc = gy >= g.ny ? g.ny - 1 : gy;
+            const size_t idx = size_t(gyc) * size_t(g.nx) + size_t(gx >= g.nx ? g.nx - 1 : gx);
+            si[r] = A.info[idx];
+            sa[r] = A.aux[idx];
+            srow[r] = A.rows[gyc];
+        }
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int e = tid + i * NT;
+            if (e < LH * LH) S.v[e] = ((ok >> i) & 1u) ? s0[i] : Alg::outside();
+        }
+    }
+    __syncthreads();
+    unsigned pendmask = 0, rimcell = 0;
+    int off0[RPL], off1[RPL];
+    bool on0[RPL], on1[RPL];
+    double p0[RPL], p1[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int ly = ry0 + r, cl = (ly + 1) * LH + lx + 1;
+        const int gx = x0 + lx, gy = y0 + ly;
+        const unsigned inf = ((oki >> r) & 1u) ? si[r] : 0u;
+        off0[r] = cl; off1[r] = cl; on0[r] = false; on1[r] = false; p0[r] = 0.; p1[r] = 0.;
+        if (gx < g.nx && gy >= g.y_own0 && gy < g.y_own1 && pending(Alg::head(S.v[cl])) && !(inf & INFO_DEAD)) {
+            pendmask |= 1u << r;
+            int k[2];
+            bool on[2];
+            double p[2];
+            Alg::rev_row(inf, sa[r], srow[r], k, on, p);
+            on0[r] = on[0]; on1[r] = on[1]; p0[r] = p[0]; p1[r] = p[1];
+            if (on[0]) off0[r] = cl + d2(k[0]) * LH + d1(k[0]);
+            if (on[1]) off1[r] = cl + d2(k[1]) * LH + d1(k[1]);
+            // the senders a finished cell releases in a neighbouring tile: that tile looks again
+            int rb = 0;
+            if (lx == 0 || lx == TS - 1 || ly == 0 || ly == TS - 1) {
+                for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
+                    const int kk = __ffs(int(m));
+                    const int nx2 = lx + d1(kk), ny2 = ly + d2(kk);
+                    if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rb |= rim_bit<TS>(nx2, ny2);
+                }
+            }
+            rimcell |= unsigned(rb) << (8 * r);
+        }
+    }
+    static_assert(RPL <= 4, "rim bits of a lane's cells are packed one byte per row");
+    const unsigned pend0 = pendmask;
+    int rim = 0;
+    for (;;) {
+        Cell n0[RPL], n1[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; r++) { n0[r] = S.v[off0[r]]; n1[r] = S.v[off1[r]]; }
+        bool prog = false;
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            if (!((pendmask >> r) & 1u)) continue;
+            if ((on0[r] && pending(Alg::head(n0[r]))) || (on1[r] && pending(Alg::head(n1[r])))) continue;
+            const bool on[2] = {on0[r], on1[r]};
+            const double p[2] = {p0[r], p1[r]};
+            const Cell n[2] = {n0[r], n1[r]};
+            S.v[(ry0 + r + 1) * LH + lx + 1] = alg.eval2(sa[r], on, p, n);
+            rim |= int((rimcell >> (8 * r)) & 255u);
+            pendmask &= ~(1u << r);
+            prog = true;
+        }
+        if (!__syncthreads_or(prog ? 1 : 0)) break;
+    }
+    bool wrote = false;
+    for (unsigned m = pend0 & ~pendmask; m; m &= m - 1u) {
+        const int r = __ffs(int(m)) - 1, ly = ry0 + r;
+        A.v[size_t(y0 + ly) * size_t(g.nx) + size_t(x0 + lx)] = S.v[(ly + 1) * LH + lx + 1];
+        wrote = true;
+    }
+    if (rim) atomicOr(&S.rim, rim);
+    const int any = __syncthreads_or(wrote ? 1 : 0);
+    const int res = any ? (tilek::RES_CHANGED | S.rim) : 0;
+    __syncthreads();   // S is reused by the next tile
+    return res;
+}
+
 // MINW: waves per SIMD the register allocation is held to (= 256-thread tiles per CU of the 32 x 32 geometry; policy constant kMinWaves32):
 // 4 is what the kernels take by themselves (107-117 VGPRs); 5 (<= 102 VGPRs) puts a fifth tile on a CU where the LDS allows it - measured
 // per policy at 16384^2 (profiles/r03k_*): GridNet 64.0 -> 60.0 ms (3 spilled registers; with the target words of round 4 eleven, and 4 is as fast: 59 ms), DinfUpDependence 381 -> 376 ms (2), DinfRevAccum
@@ -453,9 +579,14 @@ template <class Alg, int TSZ, int MINW = 4>
 __global__ __launch_bounds__(Dim<TSZ>::NT, MINW) void sweep_kernel(Alg alg, tilek::TileGeom g, const uint32_t* __restrict__ list, unsigned long long* __restrict__ count,
                                                    uint32_t* __restrict__ flags_cur, uint32_t* __restrict__ flags_next, uint32_t* __restrict__ list_next,
                                                    unsigned pull_max, Arrays<Alg> A) {
-    __shared__ Lds<Alg, TSZ> S;
     __shared__ tilek::TileLds L;
-    tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A); });
+    if constexpr (Alg::kMaxRelease > 2) {
+        __shared__ LdsRev<Alg, TSZ> S;
+        tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool) { return sweep_tile_rev<Alg, TSZ>(alg, g, tile, S, A); });
+    } else {
+        __shared__ Lds<Alg, TSZ> S;
+        tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A); });
+    }
 }
 
 // the pending pattern that is left (cells on or below a cycle, cells fed by the p == 0 quirk) becomes `value`

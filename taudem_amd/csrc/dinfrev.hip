@@ -63,6 +63,18 @@ __device__ __forceinline__ Recv receivers(unsigned inf) {
     return r;
 }
 
+// what a pending cell needs in the lockstep form of the reverse sweep (d8sweep::sweep_tile_rev), made once per activation: its receivers
+// in ascending k, which of them count (prop > 0, inside the raster, with an angle) and their proportions
+__device__ __forceinline__ void rev_row_dinf(unsigned inf, float angle, double a2, int (&k)[2], bool (&on)[2], double (&p)[2]) {
+    const Recv r = receivers(inf);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        k[t] = r.k[t];
+        on[t] = r.on[t] && ((inf >> (r.k[t] - 1)) & 1u) != 0u;
+        p[t] = on[t] ? prop_dev(angle, r.k[t], a2) : 0.;
+    }
+}
+
 struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
     using Cell = float;
     using Aux = float2;                          // {angle, disturbance grid value (int bits)}
@@ -75,6 +87,15 @@ struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
     static __device__ __forceinline__ float head(float c) { return c; }
     static __host__ __device__ __forceinline__ float outside() { return -1.0f; }
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { return (inf >> 16) & 0xFFu; }
+    static __device__ __forceinline__ void rev_row(unsigned inf, const Aux& a, double a2, int (&k)[2], bool (&on)[2], double (&p)[2]) { rev_row_dinf(inf, a.x, a2, k, on, p); }
+    __device__ __forceinline__ Cell eval2(const Aux& a, const bool (&on)[2], const double (&p)[2], const Cell (&n)[2]) const {
+        if (__float_as_int(a.y) >= 1) return 1.0f;
+        float dep = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            if (on[t]) dep = dep + (float)(n[t] * p[t]);
+        return dep;
+    }
     template <class L>
     __device__ __forceinline__ void eval(L& S, int c, int cl, int ly, unsigned inf, const Cell (&nb)[9]) const {
         const float2 a = S.aux[c];
@@ -110,6 +131,19 @@ struct RevAccAlg {   // src/DinfRevAccum.cpp:176-199; record = {racc, dmax}
     static __device__ __forceinline__ float head(const float2& c) { return c.x; }
     static __host__ __device__ __forceinline__ float2 outside() { return make_float2(TDX_ANG_NODATA, TDX_ANG_NODATA); }
     static __device__ __forceinline__ unsigned rel_mask(unsigned inf) { return (inf >> 16) & 0xFFu; }
+    static __device__ __forceinline__ void rev_row(unsigned inf, const Aux& a, double a2, int (&k)[2], bool (&on)[2], double (&p)[2]) { rev_row_dinf(inf, a.x, a2, k, on, p); }
+    __device__ __forceinline__ Cell eval2(const Aux& a, const bool (&on)[2], const double (&p)[2], const Cell (&n)[2]) const {
+        if (is_nodata_f(a.y, w_nodata)) return make_float2(TDX_ANG_NODATA, TDX_ANG_NODATA);
+        float racc = a.y, dmax = a.y;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (!on[t] || is_nodata_f(n[t].x, TDX_ANG_NODATA)) continue;   // (a receiver whose weight was nodata)
+            const float valn = (float)(p[t] * n[t].x);
+            racc = racc + valn;
+            if (n[t].y > dmax) dmax = n[t].y;
+        }
+        return make_float2(racc, dmax);
+    }
     template <class L>
     __device__ __forceinline__ void eval(L& S, int c, int cl, int ly, unsigned inf, const Cell (&nb)[9]) const {
         const float2 a = S.aux[c];
