@@ -9,7 +9,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 sw = [(r['Kernel_Name'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) for r in rows if 'sweep_kernel' in r['Kernel_Name'] and 'dsweep' not in r['Kernel_Name']]
 log = open('gpurun_out/rv.log').read()
 runs = re.findall(r"d8 sweep rounds\((\d+) tiles of (\d+)\):([ \d]*)", log)
-out = open('gpurun_out/r06o_reverse_round_times.txt', 'w')
+out = open('gpurun_out/r06r_reverse_round_times.txt', 'w')
 out.write(f"dinfrevaccum at 16384^2: {len(sw)} sweep launches traced, {len(runs)} printed runs (warm-up call + timed call)\n")
 names = sorted(set(n for n, _, _ in sw))
 for n in names: out.write(f"  kernel {n[:110]}: {sum(1 for a in sw if a[0]==n)} launches, {sum(a[1] for a in sw if a[0]==n)/1e3:.1f} ms\n")
@@ -21,6 +21,6 @@ step = max(1, len(half)//16)
 for a in range(0, len(half), step):
     seg = half[a:a+step]; cs = counts[a:a+step]
     out.write(f"   launches {a:5d}..{a+len(seg)-1:5d}: {sum(d for _,d,_ in seg)/1e3:7.2f} ms, mean {sum(d for _,d,_ in seg)/len(seg):7.1f} us per launch, tiles per round ~{(sum(cs)//max(1,len(cs)))}, grid {seg[0][2]}\n")
-print(open('gpurun_out/r06o_reverse_round_times.txt').read())
+print(open('gpurun_out/r06r_reverse_round_times.txt').read())
 PY
 rm -rf gpurun_out/rv

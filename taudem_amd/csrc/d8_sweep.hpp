@@ -93,6 +93,17 @@ __device__ __forceinline__ int rim_bit(int nx2, int ny2) {
     return ny2 < 0 ? (nx2 < 0 ? 16 : (nx2 >= TS ? 32 : 1)) : (ny2 >= TS ? (nx2 < 0 ? 64 : (nx2 >= TS ? 128 : 2)) : (nx2 < 0 ? 4 : 8));
 }
 
+// the same for a whole set of neighbours (bit k - 1 of `m`: neighbour k), without a loop or a branch: a loop over the set bits with d1 / d2 / rim_bit per
+// neighbour was ~40 instructions per bit, run by every wave (each holds cells of the tile's first and last column) for the largest set in the wave.
+// Neighbours to the north are k = 2, 3, 4, south 6, 7, 8, west 4, 5, 6, east 1, 2, 8.
+template <int TS>
+__device__ __forceinline__ int rim_bits_of_mask(unsigned m, int lx, int ly) {
+    const unsigned mN = ly == 0 ? m & 0x0Eu : 0u, mS = ly == TS - 1 ? m & 0xE0u : 0u, mW = lx == 0 ? m & 0x38u : 0u, mE = lx == TS - 1 ? m & 0x83u : 0u;
+    const unsigned ns = mN | mS, we = mW | mE;
+    return ((mN & ~we) ? 1 : 0) | ((mS & ~we) ? 2 : 0) | ((mW & ~ns) ? 4 : 0) | ((mE & ~ns) ? 8 : 0) | ((mN & mW) ? 16 : 0) | ((mN & mE) ? 32 : 0) | ((mS & mW) ? 64 : 0) |
+           ((mS & mE) ? 128 : 0);
+}
+
 // ---- value policies -------------------------------------------------------------------------------------------------------
 // A policy defines the per-cell record (`Cell`) that lives in the work array and, tile + ring, in LDS.  Its first 32 bits carry
 // the pending pattern.  A record is read and written with ONE load / store instruction, so a tile that stages its ring while the
@@ -456,22 +467,31 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
 //   rev_row(inf, aux, a2, k, on, p)   receivers in ascending k (the reference's order), which of them count, their proportions
 //   eval2(aux, on, p, n) -> Cell      the value from the receivers' records
 // and keeps eval() for the verifier, which re-evaluates every cell from the final records with the original expression.
+#ifdef TDX_REV_CLOCKS
+static __device__ unsigned long long g_rev_clk[40];
+#endif
 template <class Alg, int TSZ>
 struct LdsRev {
     static constexpr int LH = Dim<TSZ>::LH;
     typename Alg::Cell v[LH * LH];
     int rim;
+    int wrote;
+    int vote[3];
 };
 
 template <class Alg, int TSZ>
-__device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileGeom& g, int tile, LdsRev<Alg, TSZ>& S, const Arrays<Alg>& A) {
+__device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileGeom& g, int tile, LdsRev<Alg, TSZ>& S, const Arrays<Alg>& A, bool clk_on = true) {
     using Cell = typename Alg::Cell;
     using Aux = typename Alg::Aux;
     constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL, NSTAGE = Dim<TSZ>::NSTAGE;
     const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
-    if (tid == 0) S.rim = 0;
+    if (tid == 0) { S.rim = 0; S.wrote = 0; S.vote[0] = 0; S.vote[1] = 0; S.vote[2] = 0; }
+#ifdef TDX_REV_CLOCKS
+    const unsigned long long tc0 = wall_clock64();
+    unsigned long long tc1 = 0, tc2 = 0, tc3 = 0, nstretch = 0;
+#endif
     uint32_t si[RPL];
     Aux sa[RPL];
     double srow[RPL];
@@ -505,6 +525,9 @@ __device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileG
         }
     }
     __syncthreads();
+#ifdef TDX_REV_CLOCKS
+    tc1 = wall_clock64();
+#endif
     unsigned pendmask = 0, rimcell = 0;
     int off0[RPL], off1[RPL];
     bool on0[RPL], on1[RPL];
@@ -525,39 +548,62 @@ __device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileG
             if (on[0]) off0[r] = cl + d2(k[0]) * LH + d1(k[0]);
             if (on[1]) off1[r] = cl + d2(k[1]) * LH + d1(k[1]);
             // the senders a finished cell releases in a neighbouring tile: that tile looks again
-            int rb = 0;
-            if (lx == 0 || lx == TS - 1 || ly == 0 || ly == TS - 1) {
-                for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
-                    const int kk = __ffs(int(m));
-                    const int nx2 = lx + d1(kk), ny2 = ly + d2(kk);
-                    if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) rb |= rim_bit<TS>(nx2, ny2);
-                }
-            }
+            const int rb = rim_bits_of_mask<TS>(Alg::rel_mask(inf), lx, ly);
             rimcell |= unsigned(rb) << (8 * r);
         }
     }
     static_assert(RPL <= 4, "rim bits of a lane's cells are packed one byte per row");
     const unsigned pend0 = pendmask;
     int rim = 0;
-    for (;;) {
-        Cell n0[RPL], n1[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; r++) { n0[r] = S.v[off0[r]]; n1[r] = S.v[off1[r]]; }
+    // The waves sweep their own cells WITHOUT a barrier between sweeps: a receiver's record read meanwhile is the pending pattern or the
+    // complete result (one LDS store), and pending -> result is the only transition, so a sweep can only be late, never wrong.  A vote
+    // every REV_INNER sweeps ends the activation: nobody evaluated a cell in a whole stretch, and every wave made at least one full sweep
+    // after the barrier that published the last result.  (A dependency chain inside one wave's rows advances at LDS latency; the vote is a
+    // flag word per stretch - three, so that clearing one never meets its setters or its readers - and a barrier that waits for LDS only.)
+    // REV_INNER: the last stretch of an activation finds nothing and is wasted, so it is short (measured at 16384^2, DinfUpDependence / DinfRevAccum:
+    // 2: 93.8 / 85.4 ms, 4: 93.5 / 84.6, 8: 98.0 / 86.9, 16: 111 / 99.5, 32: 137 / 112; a vote per sweep, the first form: 115 / 101).
+    constexpr int REV_INNER = 4;
+#ifdef TDX_REV_CLOCKS
+    tc2 = wall_clock64();
+#endif
+    for (int stretch = 0;; stretch++) {
+#ifdef TDX_REV_CLOCKS
+        nstretch++;
+#endif
         bool prog = false;
+#pragma unroll 1
+        for (int it = 0; it < REV_INNER; it++) {
+            if (!__any(pendmask != 0u)) break;
+            asm volatile("" ::: "memory");   // the records are read again in every sweep
+            Cell n0[RPL], n1[RPL];
 #pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            if (!((pendmask >> r) & 1u)) continue;
-            if ((on0[r] && pending(Alg::head(n0[r]))) || (on1[r] && pending(Alg::head(n1[r])))) continue;
-            const bool on[2] = {on0[r], on1[r]};
-            const double p[2] = {p0[r], p1[r]};
-            const Cell n[2] = {n0[r], n1[r]};
-            S.v[(ry0 + r + 1) * LH + lx + 1] = alg.eval2(sa[r], on, p, n);
-            rim |= int((rimcell >> (8 * r)) & 255u);
-            pendmask &= ~(1u << r);
-            prog = true;
+            for (int r = 0; r < RPL; r++) { n0[r] = S.v[off0[r]]; n1[r] = S.v[off1[r]]; }
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                if (!((pendmask >> r) & 1u)) continue;
+                if ((on0[r] && pending(Alg::head(n0[r]))) || (on1[r] && pending(Alg::head(n1[r])))) continue;
+                const bool on[2] = {on0[r], on1[r]};
+                const double p[2] = {p0[r], p1[r]};
+                const Cell n[2] = {n0[r], n1[r]};
+                S.v[(ry0 + r + 1) * LH + lx + 1] = alg.eval2(sa[r], on, p, n);
+                rim |= int((rimcell >> (8 * r)) & 255u);
+                pendmask &= ~(1u << r);
+                prog = true;
+            }
         }
-        if (!__syncthreads_or(prog ? 1 : 0)) break;
+        const int slot = stretch % 3;
+        if (prog) S.vote[slot] = 1;
+        tdx_barrier_lds();
+        const int any = S.vote[slot];
+        if (tid == 0) S.vote[(slot + 2) % 3] = 0;
+        if (!any) break;
     }
+#ifdef TDX_REV_CLOCKS
+    tc3 = wall_clock64();
+#endif
+    // write back what this activation evaluated (one store per record).  "Did anybody write" goes through LDS and a barrier that waits for LDS only:
+    // __syncthreads_or() would sit out the acknowledgement of every store above, and nobody in this launch depends on them having landed (a neighbour that
+    // stages its ring meanwhile sees the old or the new record; the next round is another launch; the solo hand-over of round_driver fences for itself).
     bool wrote = false;
     for (unsigned m = pend0 & ~pendmask; m; m &= m - 1u) {
         const int r = __ffs(int(m)) - 1, ly = ry0 + r;
@@ -565,9 +611,18 @@ __device__ __forceinline__ int sweep_tile_rev(const Alg& alg, const tilek::TileG
         wrote = true;
     }
     if (rim) atomicOr(&S.rim, rim);
-    const int any = __syncthreads_or(wrote ? 1 : 0);
-    const int res = any ? (tilek::RES_CHANGED | S.rim) : 0;
-    __syncthreads();   // S is reused by the next tile
+    if (wrote) S.wrote = 1;
+    tdx_barrier_lds();
+    const int res = S.wrote ? (tilek::RES_CHANGED | S.rim) : 0;
+    tdx_barrier_lds();   // S is reused by the next tile
+#ifdef TDX_REV_CLOCKS
+    if (tid == 0 && clk_on) {
+        const unsigned long long tc4 = wall_clock64();
+        atomicAdd(&g_rev_clk[0], tc1 - tc0); atomicAdd(&g_rev_clk[1], tc2 - tc1); atomicAdd(&g_rev_clk[2], tc3 - tc2); atomicAdd(&g_rev_clk[3], tc4 - tc3);
+        atomicAdd(&g_rev_clk[4], nstretch); atomicAdd(&g_rev_clk[5], 1ull); atomicMax(&g_rev_clk[6], tc3 - tc2); atomicMax(&g_rev_clk[7], nstretch);
+        { const unsigned long long us = (tc3 - tc2) / 100; atomicAdd(&g_rev_clk[8 + (us < 15 ? us : 15)], 1ull); atomicAdd(&g_rev_clk[24 + (nstretch < 15 ? nstretch : 15)], 1ull); }
+    }
+#endif
     return res;
 }
 
@@ -582,7 +637,12 @@ __global__ __launch_bounds__(Dim<TSZ>::NT, MINW) void sweep_kernel(Alg alg, tile
     __shared__ tilek::TileLds L;
     if constexpr (Alg::kMaxRelease > 2) {
         __shared__ LdsRev<Alg, TSZ> S;
+#ifdef TDX_REV_CLOCKS
+        const bool clk_on = unsigned(count[0]) <= 1200u;
+        tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool) { return sweep_tile_rev<Alg, TSZ>(alg, g, tile, S, A, clk_on); });
+#else
         tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool) { return sweep_tile_rev<Alg, TSZ>(alg, g, tile, S, A); });
+#endif
     } else {
         __shared__ Lds<Alg, TSZ> S;
         tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A); });
@@ -854,6 +914,22 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         if (changed == 0) break;
         if (outer_out) (*outer_out)++;
     }
+#ifdef TDX_REV_CLOCKS
+    if constexpr (Alg::kMaxRelease > 2) {
+        unsigned long long h[40];
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rev_clk), sizeof h);
+        fprintf(stderr, "rev clocks (100 MHz ticks -> us): activations %llu  stage %.2f  setup %.2f  sweeps %.2f (max %.2f)  writeback %.2f us per activation; stretches %.2f (max %llu)\n", h[5],
+                h[0] / 100.0 / h[5], h[1] / 100.0 / h[5], h[2] / 100.0 / h[5], h[6] / 100.0, h[3] / 100.0 / h[5], double(h[4]) / h[5], h[7]);
+        fprintf(stderr, "  sweep phase us histogram (0..14, 15+):");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", h[8 + i]);
+        fprintf(stderr, "\n  stretches histogram (0..14, 15+):");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", h[24 + i]);
+        fprintf(stderr, "\n");
+        memset(h, 0, sizeof h);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_rev_clk), h, sizeof h);
+    }
+#endif
     if (verify_enabled()) return verify(ctx, st, alg, A);
     return TDX_OK;
 }

@@ -8,20 +8,17 @@
 
 struct RowProp { double a2; double dx; };   // a2 = atan2(dyc[j], dxc[j]) from the host libm
 
-// aref[i] of prop() (src/commonLib.cpp:78-79)
+// aref[i] of prop() (src/commonLib.cpp:78-79): { -a2, 0, a2, pi/2, pi - a2, pi, pi + a2, 3pi/2, 2pi - a2, 2pi }, i = 0 .. 9.
+// Without a branch: as a switch this became a tree of divergent branches (the index differs from lane to lane), ~15 exec-mask blocks per
+// call and 24 calls per lane in the set-up of a reverse-sweep activation - 5.5 us of its ~25 (round 6).  Even i: a constant base plus or
+// minus a2 (x - a2 and x + (-a2) are the same operation; -a2 itself for i = 0, a2 for i = 2), odd i: one of five constants.
 __device__ __forceinline__ double aref_at(int i, double a2) {
-    switch (i) {
-        case 0: return -a2;
-        case 1: return 0.;
-        case 2: return a2;
-        case 3: return (double)(0.5 * TDX_PI);
-        case 4: return TDX_PI - a2;
-        case 5: return (double)TDX_PI;
-        case 6: return TDX_PI + a2;
-        case 7: return (double)(1.5 * TDX_PI);
-        case 8: return 2. * TDX_PI - a2;
-        default: return (double)(2. * TDX_PI);
-    }
+    const int h = i >> 1;
+    const double t = (h & 1) ? a2 : -a2;
+    const double base = h < 4 ? (double)TDX_PI : (double)(2. * TDX_PI);
+    const double even = h < 2 ? t : base + t;
+    const double odd = h == 0 ? 0. : (h == 1 ? (double)(0.5 * TDX_PI) : (h == 2 ? (double)TDX_PI : (h == 3 ? (double)(1.5 * TDX_PI) : (double)(2. * TDX_PI))));
+    return (i & 1) ? odd : even;
 }
 
 // prop() (src/commonLib.cpp:76-91)
@@ -30,9 +27,10 @@ __device__ __forceinline__ double prop_dev(float a, int k, double a2) {
     if (k <= 0) k = k + 8;
     if (k == 1 && a > TDX_PI) a = (float)(a - 2.0 * TDX_PI);
     const double lo = aref_at(k - 1, a2), mid = aref_at(k, a2), hi = aref_at(k + 1, a2);
-    if (a > lo && a < hi) {
-        if (a > mid) p = (hi - a) / (hi - mid);
-        else p = (a - lo) / (mid - lo);
+    if (a > lo && a < hi) {   // (one division: numerator and denominator selected first - lanes on either side of `mid` share it)
+        const bool upper = a > mid;
+        const double num = upper ? hi - a : a - lo, den = upper ? hi - mid : mid - lo;
+        p = num / den;
     }
     if (p < 1e-5) return -1.;
     return p;
