@@ -40,7 +40,9 @@ struct Dim {
     static constexpr int TS = TSZ, LH = TSZ + 2, NT = TSZ == 64 ? 1024 : 256, RPL = TSZ * TSZ / NT, NSTAGE = (LH * LH + NT - 1) / NT;
 };
 constexpr int LH = tilek::TS + 2;   // (row pitch of the staged window of the 64 x 64 geometry: not used by the engine itself)
-constexpr int BULK_SWEEPS = 12;
+constexpr int BULK_SWEEPS = 12;   // (the D-infinity limited accumulations: dinflim.hip)
+constexpr int BULK_SWEEPS_D8 = 3;  // one-receiver policies: the sources and the first confluences in lockstep, the rest by walks (measured at 16384^2, weighted AreaD8 / GridNet:
+                                   // 1: 49.8 / 55.5 ms, 2: 49.8 / 54.6, 3: 49.6 / 54.7, 4: 50.1 / 54.9, 6: 50.3 / 56.1, 8: 51.1 / 57.3, 12: 52.4 / 58.0, 16: 53.2 / 58.7)
 constexpr uint32_t PENDING_BITS = 0x7FC0DEADu;   // a quiet NaN no arithmetic produces: "participating, not evaluated yet"
 constexpr unsigned INFO_CON = 1u << 8, INFO_PART = 1u << 13, INFO_DEAD = 1u << 14, INFO_OWNMASK = 1u << 24;
 constexpr int16_t P_OUTSIDE = 16, P_SINK = 32;   // re-coded directions of outlets mode (aread8.hip)
@@ -115,7 +117,7 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
     static constexpr bool HAS_AUX = true;
     static constexpr bool HAS_DIST = false;
     static constexpr bool HAS_ROWS = false;
-    static constexpr int kBulkSweeps = BULK_SWEEPS;
+    static constexpr int kBulkSweeps = BULK_SWEEPS_D8;
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;     // rounds run on 32 x 32 tiles until this few are active (measured at 16384^2: 6000 -> 16 is 2-3 % faster for every forward tool)
     static constexpr int kMinWaves32 = 4;
@@ -157,7 +159,7 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr bool HAS_AUX = false;
     static constexpr bool HAS_DIST = true;
     static constexpr bool HAS_ROWS = false;
-    static constexpr int kBulkSweeps = BULK_SWEEPS;
+    static constexpr int kBulkSweeps = BULK_SWEEPS_D8;
     static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
@@ -206,6 +208,8 @@ struct Lds {
     unsigned nq[2];
     int rim;
     int over;                    // the queue overflowed: the tile runs again (ready cells are re-discovered from the values)
+    int wrote;                   // some lane wrote a result back in this activation
+    int vote[3];                 // "did anybody evaluate a cell in this sweep": one word per sweep, three in rotation (clearing one never meets its setters or readers)
 };
 
 template <class Alg>
@@ -291,16 +295,26 @@ __device__ __forceinline__ void stage_tile(const tilek::TileGeom& g, int tile, L
     }
 }
 
+#ifdef TDX_REV_CLOCKS
+static __device__ unsigned long long g_rev_clk[40];   // phase clocks of the tile routines (a build-time probe: -DTDX_REV_CLOCKS on one object file)
+#endif
 template <class Alg, int TSZ>
-__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg, TSZ>& S, const Arrays<Alg>& A) {
+__device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom& g, int tile, bool full, Lds<Alg, TSZ>& S, const Arrays<Alg>& A, bool clk_on = true) {
+#ifdef TDX_REV_CLOCKS
+    const unsigned long long fc0 = wall_clock64();
+    unsigned long long fc1 = 0, fc2 = 0, fc3 = 0, fc4 = 0;
+#endif
     using Cell = typename Alg::Cell;
     constexpr int TS = Dim<TSZ>::TS, LH = Dim<TSZ>::LH, NT = Dim<TSZ>::NT, RPL = Dim<TSZ>::RPL;
     const int tid = threadIdx.x, lx = tid % TS, ry0 = (tid / TS) * RPL;
     const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
     const int x0 = tx * TS, y0 = ty * TS;
-    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; }
+    if (tid == 0) { S.rim = 0; S.over = 0; S.nq[0] = 0u; S.nq[1] = 0u; S.wrote = 0; S.vote[0] = 0; S.vote[1] = 0; S.vote[2] = 0; }
     stage_tile<Alg, TSZ>(g, tile, S, A);
     __syncthreads();
+#ifdef TDX_REV_CLOCKS
+    fc1 = wall_clock64();
+#endif
     unsigned pendmask = 0;   // own cells that are pending (participating, owned by this rank, not evaluated yet) and can become ready
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
@@ -349,9 +363,18 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
                     prog = true;
                 }
             }
-            if (!__syncthreads_or(prog ? 1 : 0)) break;
+            // the vote through an LDS word and a barrier that waits for LDS only (__syncthreads_or: a reduction, two full barriers and a wait for every memory operation)
+            const int slot = sweep % 3;
+            if (prog) S.vote[slot] = 1;
+            tdx_barrier_lds();
+            const int any = S.vote[slot];
+            if (tid == 0) S.vote[(slot + 2) % 3] = 0;
+            if (!any) break;
         }
     }
+#ifdef TDX_REV_CLOCKS
+    fc2 = wall_clock64();
+#endif
     // ---- pending contributors of the cells that are left
     unsigned readymask = 0;
     uint8_t* cnt8 = reinterpret_cast<uint8_t*>(S.cnt);
@@ -371,6 +394,9 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
     __syncthreads();
     // ---- walks: a lane follows a chain as long as it finishes the last pending contributor of a released cell; further cells
     // released by the same step go to the hand-over queue, which the workgroup drains in phases
+#ifdef TDX_REV_CLOCKS
+    fc3 = wall_clock64();
+#endif
     auto walk_generic = [&](int c, int phase) {
         unsigned inf = S.info[c];
         for (;;) {
@@ -441,6 +467,9 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         __syncthreads();                        // q[phase] has been read by everybody
         if (tid == 0) S.nq[phase] = 0u;         // (nobody pushes into it before the next barrier)
     }
+#ifdef TDX_REV_CLOCKS
+    fc4 = wall_clock64();
+#endif
     // ---- write back what this activation evaluated (one store per record)
     bool wrote = false;
     for (unsigned m = pend0; m; m &= m - 1u) {
@@ -449,9 +478,19 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         if (!pending(Alg::head(v))) { A.v[size_t(y0 + ly) * size_t(g.nx) + size_t(x0 + lx)] = v; wrote = true; }
     }
     if (rim) atomicOr(&S.rim, rim);
-    const int any = __syncthreads_or(wrote ? 1 : 0);
-    const int res = (any ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
-    __syncthreads();   // S is reused by the next tile
+    // "did anybody write" through LDS and a barrier that waits for LDS only: __syncthreads_or() sits out the acknowledgement of every global store above, and
+    // nobody in this launch depends on them having landed (see sweep_tile_rev and dinf_sweep_tile.inc); the workgroup stages its next tile meanwhile
+    if (wrote) S.wrote = 1;
+    tdx_barrier_lds();
+    const int res = (S.wrote ? (tilek::RES_CHANGED | S.rim) : 0) | (S.over ? tilek::RES_CAPPED : 0);
+    tdx_barrier_lds();   // S is reused by the next tile
+#ifdef TDX_REV_CLOCKS
+    if (tid == 0 && clk_on) {
+        const unsigned long long fc5 = wall_clock64();
+        atomicAdd(&g_rev_clk[0], fc1 - fc0); atomicAdd(&g_rev_clk[1], fc2 - fc1); atomicAdd(&g_rev_clk[2], fc3 - fc2); atomicAdd(&g_rev_clk[3], fc4 - fc3);
+        atomicAdd(&g_rev_clk[4], fc5 - fc4); atomicAdd(&g_rev_clk[5], 1ull); atomicAdd(&g_rev_clk[6], full ? 1ull : 0ull);
+    }
+#endif
     return res;
 }
 
@@ -467,9 +506,6 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
 //   rev_row(inf, aux, a2, k, on, p)   receivers in ascending k (the reference's order), which of them count, their proportions
 //   eval2(aux, on, p, n) -> Cell      the value from the receivers' records
 // and keeps eval() for the verifier, which re-evaluates every cell from the final records with the original expression.
-#ifdef TDX_REV_CLOCKS
-static __device__ unsigned long long g_rev_clk[40];
-#endif
 template <class Alg, int TSZ>
 struct LdsRev {
     static constexpr int LH = Dim<TSZ>::LH;
@@ -645,7 +681,12 @@ __global__ __launch_bounds__(Dim<TSZ>::NT, MINW) void sweep_kernel(Alg alg, tile
 #endif
     } else {
         __shared__ Lds<Alg, TSZ> S;
+#ifdef TDX_REV_CLOCKS
+        const bool clk_on = unsigned(count[0]) >= 50000u;   // the bulk rounds
+        tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A, clk_on); });
+#else
         tilek::round_driver(list, count, flags_cur, flags_next, list_next, pull_max, g, L, [&](int tile, bool full) { return sweep_tile<Alg, TSZ>(alg, g, tile, full, S, A); });
+#endif
     }
 }
 
@@ -915,6 +956,15 @@ static int run(tdx_context* ctx, const Strip& st, Alg alg, Arrays<Alg> A, uint32
         if (outer_out) (*outer_out)++;
     }
 #ifdef TDX_REV_CLOCKS
+    if constexpr (Alg::kMaxRelease <= 2) {
+        unsigned long long h[40];
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rev_clk), sizeof h);
+        if (h[5]) fprintf(stderr, "sweep clocks, rounds of >= 50000 tiles (us per activation): activations %llu (full %llu)  stage %.2f  lockstep %.2f  count %.2f  walks %.2f  writeback %.2f\n", h[5], h[6],
+                h[0] / 100.0 / h[5], h[1] / 100.0 / h[5], h[2] / 100.0 / h[5], h[3] / 100.0 / h[5], h[4] / 100.0 / h[5]);
+        memset(h, 0, sizeof h);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_rev_clk), h, sizeof h);
+    }
     if constexpr (Alg::kMaxRelease > 2) {
         unsigned long long h[40];
         hipDeviceSynchronize();
