@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 T=${1:-r06z}
-timeout 1700 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --timeout=1200 --timeout-method=thread --durations=8 2>&1 | tail -n 20 > gpurun_out/${T}_pytest_gpu.txt; tail -n 14 gpurun_out/${T}_pytest_gpu.txt
+[ "$2" = "nopytest" ] || timeout 1700 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --timeout=1200 --timeout-method=thread --durations=8 2>&1 | tail -n 20 > gpurun_out/${T}_pytest_gpu.txt; tail -n 14 gpurun_out/${T}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 2
 timeout 600 python bench.py > gpurun_out/${T}_bench_default.log 2>&1; tail -n 1 gpurun_out/${T}_bench_default.log > gpurun_out/${T}_bench_default.json; cut -c1-700 gpurun_out/${T}_bench_default.json
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T -o r -- python $R/bench.py --cpu-sample 0 --no-extras > $R/gpurun_out/prof_$T.log 2>&1)
