@@ -647,11 +647,7 @@ __device__ __forceinline__ int relax_tile_reg(const Op& op, const TileGeom& g, i
         const int sx = right ? x0 + TS : x0 - 1, sy = y0 - 1 + row;
         side_ok = tid < 2 * LH && sx >= 0 && sx < g.nx && sy >= 0 && sy < g.ny;
         const int sxc = sx < 0 ? 0 : (sx >= g.nx ? g.nx - 1 : sx), syc = sy < 0 ? 0 : (sy >= g.ny ? g.ny - 1 : sy);
-#ifdef TDX_EXPERIMENT_NO_SIDE_COLUMNS   // (timing experiment only - WRONG results: the halo columns read as one coalesced row instead of 132 cache lines)
-        raw_side = op.load_raw(size_t((long long)(y0 < g.ny ? y0 : 0) * row_pitch + gxc));
-#else
-        raw_side = op.load_raw(size_t((long long)syc * row_pitch + sxc));
-#endif
+        raw_side = op.load_raw(size_t((long long)syc * row_pitch + sxc));   // (132 cache lines for 132 cells - measured not to be what bounds a round: docs/experiments_r06.md section 2)
     }
     T v[RPW], cst[RPW];
     unsigned mk[RPW / 4] = {};
