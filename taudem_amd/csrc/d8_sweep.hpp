@@ -118,7 +118,6 @@ struct SumMaxMin {   // AreaD8 with weights, D8FlowPathExtremeUp (aread8.hip: D8
     static constexpr bool HAS_DIST = false;
     static constexpr bool HAS_ROWS = false;
     static constexpr int kBulkSweeps = BULK_SWEEPS_D8;
-    static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;     // rounds run on 32 x 32 tiles until this few are active (measured at 16384^2: 6000 -> 16 is 2-3 % faster for every forward tool)
     static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 1;          // cells a finished cell can release (<= 2: their in-tile indices are made once per activation, see Lds::tw)
@@ -160,7 +159,6 @@ struct GridNetAlg {   // src/gridnet.cpp:380-426; record = {plen, tlen, gord (in
     static constexpr bool HAS_DIST = true;
     static constexpr bool HAS_ROWS = false;
     static constexpr int kBulkSweeps = BULK_SWEEPS_D8;
-    static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 1;
@@ -342,10 +340,9 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
         return pb;
     };
     // ---- bulk: lockstep sweeps over the lane's own cells (ready = no contributor pending), no atomics.  Forward sweeps (one or two
-    // receivers per cell: long thin chains) run a dozen of them on a fresh tile and leave the stream cells to the walks; REVERSE
-    // sweeps fan out (a finished cell releases up to eight senders: a wide front, which would overflow the walks' hand-over queue
-    // again and again) and run them to the end on every activation.
-    if (full || Alg::kBulkOnHalo) {
+    // receivers per cell: long thin chains) run a few of them on a fresh tile (the policy's kBulkSweeps) and leave the stream cells to
+    // the walks.  (The REVERSE sweeps - a finished cell releases up to eight senders - have a routine of their own: sweep_tile_rev.)
+    if (full) {
         for (int sweep = 0; sweep < g.max_sweeps; sweep++) {   // (TileGeom::max_sweeps carries the policy's kBulkSweeps here; TDX_D8_BULK_SWEEPS overrides it - A/B hook)
             bool prog = false;
 #pragma unroll
@@ -397,35 +394,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
 #ifdef TDX_REV_CLOCKS
     fc3 = wall_clock64();
 #endif
-    auto walk_generic = [&](int c, int phase) {
-        unsigned inf = S.info[c];
-        for (;;) {
-            const int ly = c / TS, cx = c % TS, cl = (ly + 1) * LH + cx + 1;
-            Cell nb[9];
-            load_nbrs(cl, nb);
-            alg.eval(S, c, cl, ly, inf, nb);
-            int next = -1;
-            unsigned ninf = 0;
-            for (unsigned m = Alg::rel_mask(inf); m; m &= m - 1u) {
-                const int k = __ffs(int(m));
-                const int nx2 = cx + d1(k), ny2 = ly + d2(k);
-                if (nx2 < 0 || nx2 >= TS || ny2 < 0 || ny2 >= TS) { rim |= rim_bit<TS>(nx2, ny2); continue; }
-                const int tc = ny2 * TS + nx2, sh = 8 * (tc & 3);
-                const unsigned old = __hip_atomic_fetch_sub(&S.cnt[tc >> 2], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned tinf = S.info[tc];
-                if (((old >> sh) & 255u) != 1u) continue;   // somebody else finishes its last contributor
-                if (next < 0) { next = tc; ninf = tinf; }
-                else {
-                    const unsigned slot = atomicAdd(&S.nq[phase ^ 1], 1u);
-                    if (slot < unsigned(Lds<Alg, TSZ>::QLEN)) S.q[phase ^ 1][slot] = uint16_t(tc);
-                    else S.over = 1;
-                }
-            }
-            if (next < 0) break;
-            c = next; inf = ninf;
-        }
-    };
-    auto walk_fwd = [&](int c, int phase) {   // kMaxRelease <= 2: the released cells come from the tile's target words
+    auto walk_fwd = [&](int c, int phase) {   // the released cells (at most two) come from the tile's target words
         unsigned inf = S.info[c], tw = S.tw[c];
         uint32_t* const spare = &S.spare[tid & 63];
         for (;;) {
@@ -454,10 +423,7 @@ __device__ __forceinline__ int sweep_tile(const Alg& alg, const tilek::TileGeom&
             tw = last0 ? tw0 : tw1;
         }
     };
-    auto walk = [&](int c, int phase) {
-        if constexpr (Alg::kMaxRelease <= 2) walk_fwd(c, phase);
-        else walk_generic(c, phase);
-    };
+    auto walk = [&](int c, int phase) { walk_fwd(c, phase); };
     for (unsigned m = readymask; m; m &= m - 1u) walk((ry0 + (__ffs(int(m)) - 1)) * TS + lx, 0);
     for (int phase = 1;; phase ^= 1) {
         __syncthreads();                        // every push into q[phase] has landed

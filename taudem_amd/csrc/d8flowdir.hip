@@ -17,7 +17,7 @@
 //                                   8-connected flat cells; s(c) = Tr - q(c) + 1
 //                        The sweep counts T, Tr of the reference's loops are reconstructed from the
 //                        level counts (they leak into the artificial elevations of pits and into s).
-//   classification       d8_classify_stream_kernel (a dense queue: one pass over the strip) / flatk::classify_kernel
+//   classification       flatk::classify_stream_kernel<LV, D8Codes> (a dense queue: one pass over the strip) / flatk::classify_kernel
 //                        (a list): seeds of both fields, eligibility masks, activation flags of the tiles
 //   d8_setflow2_kernel   setFlow2 (src/d8.cpp:412-454) per flat cell on the artificial surface
 //                        (d8_setflow2_stream_kernel for a dense queue; it also writes the next iteration's list)
@@ -218,125 +218,14 @@ __device__ __forceinline__ bool dont_cross_d8(const int16_t* __restrict__ P, siz
     }
 }
 
-// Classification for flat resolution as ONE streaming pass (replaces marker reset + list gathers): the flat queue is
-// exactly {p == 0} in every outer iteration (resolved cells leave it, nothing enters it), so queue membership, the
-// level-1/2 seeds of incfall, the seeds of incrise and both eligibility masks are a function of the 3x3 windows of
-// Z and P.  Every owned cell gets its markers (lvl / rq: -1 outside the queue) and masks; lanes walk 16-row column
-// segments with both windows in registers (6 row loads per output row).  Semantics: flatk::classify_kernel.
-// (62-column window like d8_slope_kernel: a lane loads ONE value per row and array, the west / east neighbours are lane shifts; the 2 x 18 row
-// loads of a lane are issued back to back.  The first version read three overlapping cells per row and array inside the row loop: 1.36 ms.)
-constexpr int CLS_COLS = 62;
-template <class LV>
-__global__ __launch_bounds__(256) void d8_classify_stream_kernel(const float* __restrict__ Z, const int16_t* __restrict__ P, int nx, int ny,
-                                                                 int y_own0, int y_own1, int tiles_x, LV* __restrict__ lvl,
-                                                                 LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
-                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap,
-                                                                 uint8_t* __restrict__ notfull) {
-    using tilek::lane_left;
-    using tilek::lane_right;
-    const int bx = tdxk::xcd_block_x(nbx, xmap);
-    if (bx < 0) return;
-    const int lx = threadIdx.x & 63;
-    const int x = bx * CLS_COLS - 1 + lx;
-    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * SLOPE_ROWS) + (threadIdx.x >> 6) * SLOPE_ROWS);
-    const bool mine = lx >= 1 && lx <= CLS_COLS && x < nx;
-    const bool inx = x >= 0 && x < nx;
-    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
-    float z[SLOPE_ROWS + 2];
-    int pw[SLOPE_ROWS + 2];
-#pragma unroll
-    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
-        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
-        const size_t o = size_t(yc) * size_t(nx) + size_t(xc);
-        z[j] = Z[o];
-        pw[j] = P[o];
-    }
-    // The direction codes in ONE-HOT form (bit c for a code c in 0 .. 8, nothing for nodata / outside): "in the queue" is bit 0, "has a direction" bits 1 .. 8,
-    // dontCross two bit tests - and the per-neighbour case analysis below integer and / or on 0 / 1 values.  (As nested if / else on comparisons it compiled to
-    // ~145 vector and ~200 scalar instructions per cell row - lane-mask algebra and branches - and the pass waited for its instructions, not for memory:
-    // profiles/r04zzzz_pmc_sq_summary.json.)
-    unsigned ow[SLOPE_ROWS + 2];
-#pragma unroll
-    for (int j = 0; j < SLOPE_ROWS + 2; j++) {
-        const int y = ybase - 1 + j;
-        const bool in = inx && y >= 0 && y < ny;   // (never looked at from a flat cell: flat cells are interior cells)
-        if (!in) z[j] = 0.f;
-        ow[j] = in ? (1u << min(unsigned(pw[j]), 31u)) & 0x1FFu : 0u;
-    }
-    int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
-    int masked_row = -1;                  // ... a flat cell whose incfall mask shuts out an in-queue neighbour (flatk::LevelPlainT)
-    unsigned fall_all = 0xFFu, rise_all = 0xFFu;   // AND of this lane's masks: 0xFF = every cell of its column segment may move and look at all eight neighbours (flats.hpp: OPEN WATER)
-#pragma unroll
-    for (int r = 0; r < SLOPE_ROWS; r++) {
-        const int y = ybase + r;
-        const float zn1 = z[r], zc1 = z[r + 1], zs1 = z[r + 2];
-        const unsigned on1 = ow[r], oc1 = ow[r + 1], os1 = ow[r + 2];
-        const float zn0 = lane_left(zn1, 0.f), zn2 = lane_right(zn1, 0.f), zc0 = lane_left(zc1, 0.f), zc2 = lane_right(zc1, 0.f);
-        const float zs0 = lane_left(zs1, 0.f), zs2 = lane_right(zs1, 0.f);
-        const unsigned on0 = lane_left(on1, 0u), on2 = lane_right(on1, 0u), oc0 = lane_left(oc1, 0u), oc2 = lane_right(oc1, 0u);
-        const unsigned os0 = lane_left(os1, 0u), os2 = lane_right(os1, 0u);
-        if (mine && y < y_own1) {
-            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
-            LV l = -1, q = -1;
-            unsigned fm = 0, rm = 0;
-            if (oc1 & 1u) {   // a flat cell: interior, all eight neighbours valid
-                const float z0 = zc1;
-                bool higher = false;
-                unsigned lowi = 0, fmq = 0;   // fmq: bits 0-7 the incfall mask, bit 8 the quirk (an equal neighbour that is neither in the queue nor has a direction)
-                // neighbour k: elevation, one-hot code, "does not cross" (0 / 1; dontCross(k), src/d8.cpp:54-100, from the cardinal neighbours' codes).  Per neighbour,
-                // as in flatk::classify_kernel: higher |= zd < 0; rm bit if in the queue; and unless the step crosses a flow path:
-                // zd >= 0 towards a cell with a direction -> low; else zd == 0 -> fm bit (in the queue) or the quirk.  zd == 0 implies zd >= 0, so the
-                // second case only sees cells without a direction.
-#define TDX_CLS(K, ZN, ON, NC)                                                                                   \
-    {                                                                                                             \
-        const float zd = z0 - (ZN);                                                                               \
-        const unsigned inq = (ON) & 1u, isdir = min((ON) & 0x1FEu, 1u), oth = ((ON) & 0x1FFu) ? 0u : 1u;          \
-        higher |= zd < 0;                                                                                         \
-        rm |= inq << ((K) - 1);                                                                                   \
-        lowi |= zd >= 0 ? ((NC) & isdir) : 0u;                                                                    \
-        fmq |= zd == 0 ? ((0u - (NC)) & ((inq << ((K) - 1)) | (oth << 8))) : 0u;                                  \
-    }
-                TDX_CLS(1, zc2, oc2, 1u)
-                TDX_CLS(2, zn2, on2, (((oc2 >> 4) | (on1 >> 8)) & 1u) ^ 1u)
-                TDX_CLS(3, zn1, on1, 1u)
-                TDX_CLS(4, zn0, on0, (((on1 >> 6) | (oc0 >> 2)) & 1u) ^ 1u)
-                TDX_CLS(5, zc0, oc0, 1u)
-                TDX_CLS(6, zs0, os0, (((os1 >> 4) | (oc0 >> 8)) & 1u) ^ 1u)
-                TDX_CLS(7, zs1, os1, 1u)
-                TDX_CLS(8, zs2, os2, (((oc2 >> 6) | (os1 >> 2)) & 1u) ^ 1u)
-#undef TDX_CLS
-                const bool low = lowi != 0u, quirk = (fmq >> 8) != 0u;
-                fm = fmq & 0xFFu;
-                l = low ? 1 : (quirk ? 2 : 0);
-                q = higher ? 1 : 0;
-                const int tr = y / tilek::TS;
-                if (!low && fm != rm) masked_row = tr;
-                if (low) fm = 0;       // a level-1 cell can never improve
-                if (higher) rm = 0;
-                if (flag_row0 < 0) flag_row0 = tr; else if (tr != flag_row0) flag_row1 = tr;
-            }
-            lvl[idx] = l;
-            rq[idx] = q;
-            fmask[idx] = uint8_t(fm);
-            rmask[idx] = uint8_t(rm);
-            fall_all &= fm;
-            rise_all &= rm;
-        }
-    }
-    if (notfull != nullptr && mine) {   // the tile rows this lane's segment lies in are not full for a field unless every cell of the segment is (rows beyond the owned ones never are)
-        const int ylast = ybase + SLOPE_ROWS - 1;
-        const int tr0 = ybase / tilek::TS, tr1 = (ylast < ny ? ylast : ny - 1) / tilek::TS;
-        const bool short_seg = ylast >= y_own1;
-        if (fall_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS)] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS)] = 1; }
-        if (rise_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS) + 1] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS) + 1] = 1; }
-    }
-    if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
-    if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
-    if (masked_row >= 0) {   // rare (dontCross at a lake shore): all the tile rows this lane touched, a superset is harmless
-        tile_masked[flag_row0 * tiles_x + x / tilek::TS] = 1;
-        if (flag_row1 >= 0) tile_masked[flag_row1 * tiles_x + x / tilek::TS] = 1;
-    }
-}
+// (the streaming classification of flat resolution is flatk::classify_stream_kernel, flats.hpp: shared with DinfFlowDir)
+// the direction codes in one-hot form: bit c for a code c in 0 .. 8, nothing for nodata / any other value
+struct D8Codes {
+    using Raw = int;
+    const int16_t* P;
+    __device__ __forceinline__ int load(size_t o) const { return P[o]; }
+    static __device__ __forceinline__ unsigned onehot(int p) { return (1u << min(unsigned(p), 31u)) & 0x1FFu; }
+};
 
 struct D8Traits {
     const int16_t* P;
@@ -646,9 +535,9 @@ static int d8flowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, flo
             D8Traits tr{d_p};
             const float* zc = zcur;
             const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked, uint8_t* notfull) {
-                const int nbx = (st.nx + CLS_COLS - 1) / CLS_COLS;
-                const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * SLOPE_ROWS - 1) / (4 * SLOPE_ROWS));
-                hipLaunchKernelGGL((d8_classify_stream_kernel<LV>), grid, dim3(256), 0, s, zc, d_p, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
+                const int nbx = (st.nx + flatk::CLS_COLS - 1) / flatk::CLS_COLS;
+                const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * flatk::CLS_ROWS - 1) / (4 * flatk::CLS_ROWS));
+                hipLaunchKernelGGL((flatk::classify_stream_kernel<LV, D8Codes>), grid, dim3(256), 0, s, zc, D8Codes{d_p}, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq, fmask,
                                    rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0, notfull);
             };
             if (sparse && markers_ready) {

@@ -190,6 +190,20 @@ struct DinfTraits {
 
 __device__ __forceinline__ bool dinf_is_flat(float a) { return !is_nodata_f(a, TDX_ANG_NODATA) && a < 0.0f; }
 
+// The angle raster as the one-hot codes of flatk::classify_stream_kernel: bit 0 = in the queue (a flat cell: angle -1), bits 1 .. 8 = has a direction
+// (angle >= 0), and - the reference's dontCross compares the FLOAT angle of the cardinal neighbours with the D8 codes 2, 4, 6, 8 (src/dinf.cpp:58-105,
+// DinfTraits::dont_cross) - an angle that IS 2, 4, 6 or 8 sets that code's bit, any other angle bit 1; nothing for nodata.
+struct DinfCodes {
+    using Raw = float;
+    const float* ANG;
+    __device__ __forceinline__ float load(size_t o) const { return ANG[o]; }
+    static __device__ __forceinline__ unsigned onehot(float a) {
+        if (is_nodata_f(a, TDX_ANG_NODATA)) return 0u;
+        if (a < 0.0f) return 1u;
+        return a == 2.0f ? 1u << 2 : (a == 4.0f ? 1u << 4 : (a == 6.0f ? 1u << 6 : (a == 8.0f ? 1u << 8 : 1u << 1)));
+    }
+};
+
 // flat queue + markers (8 cells per lane, one atomic per block)
 template <class LV>
 __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __restrict__ ANG, size_t first, size_t n, LV* __restrict__ lvl,
@@ -212,7 +226,9 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (c0 + i < n && dinf_is_flat(a[i])) mask |= 1u << i;
-    if (sizeof(LV) == 2 && c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {   // eight int16 markers = one 16-byte store
+    if (lvl == nullptr) {
+        // (a dense queue: the streaming classification writes every owned cell's markers itself - only the list is wanted)
+    } else if (sizeof(LV) == 2 && c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {   // eight int16 markers = one 16-byte store
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) w[j] = (((mask >> (2 * j)) & 1u) ? 0u : 0xFFFFu) | (((mask >> (2 * j + 1)) & 1u) ? 0u : 0xFFFF0000u);   // 0 in the queue, -1 outside
@@ -388,12 +404,18 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
         if (rc != TDX_OK) return rc;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
         const size_t own_first = size_t(st.y0) * size_t(inx), own_end = size_t(st.y1) * size_t(inx);
-        hipLaunchKernelGGL((dinf_collect_flats_kernel<LV>), dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
-                           qlist, d_cnt);
-        rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
-        if (rc != TDX_OK) return rc;
-        rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
-        if (rc != TDX_OK) return rc;
+        // (on ONE strip a dense first queue is classified by the streaming pass, which writes the markers of every cell: the list alone is built here.  With
+        // neighbours the markers are always written and exchanged: a neighbour whose own queue is sparse classifies from its list and reads this rank's
+        // boundary-row markers, and every rank must make the same collectives)
+        const bool dense_first = !st.multi() && getenv("TDX_FLATS_LIST") == nullptr && nq > n / 16;
+        hipLaunchKernelGGL((dinf_collect_flats_kernel<LV>), dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end,
+                           dense_first ? static_cast<LV*>(nullptr) : lvl, rq, qlist, d_cnt);
+        if (!dense_first) {
+            rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
+            if (rc != TDX_OK) return rc;
+            rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
+            if (rc != TDX_OK) return rc;
+        }
         int64_t last = total;
         bool first = true;
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
@@ -404,7 +426,19 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
             first = false;
             FlatLevels fl;
             DinfTraits tr{d_ang};
-            rc = flats_bfs<DinfTraits, LV>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, nullptr, iteration);
+            // A dense queue (the first iteration: a third of the raster at BASELINE.json configs[2]) is classified by the streaming pass D8FlowDir uses - markers and
+            // masks of every owned cell from the 3 x 3 windows of the elevations and the angles - which also marks the tiles that are not full, so that the level
+            // fields' open water runs as blocks (flats.hpp); later iterations work from the list.  The choice is this rank's own: both forms write the same values.
+            const float* zc = zcur;
+            const StreamClassifyFn classify = [&](const tilek::TileGeom& g, uint8_t* fmask, uint8_t* rmask, uint32_t* tile_flags, uint8_t* tile_masked, uint8_t* notfull) {
+                const int nbx = (st.nx + flatk::CLS_COLS - 1) / flatk::CLS_COLS;
+                const dim3 grid(tdx_xcd_grid_x(unsigned(nbx)), (st.y1 - st.y0 + 4 * flatk::CLS_ROWS - 1) / (4 * flatk::CLS_ROWS));
+                hipLaunchKernelGGL((flatk::classify_stream_kernel<LV, DinfCodes>), grid, dim3(256), 0, s, zc, DinfCodes{d_ang}, st.nx, st.ny_arr, st.y0, st.y1, g.tiles_x, lvl, rq,
+                                   fmask, rmask, tile_flags, tile_masked, nbx, tdx_xcd_map() ? 1 : 0, notfull);
+            };
+            const bool force_list = getenv("TDX_FLATS_LIST") != nullptr;   // (test hook, read per call: the list classification for a dense queue too)
+            const bool dense = !force_list && nq > n / 16;
+            rc = flats_bfs<DinfTraits, LV>(ctx, tr, zcur, st, qlist, nq, fbuf, &fl, stats, dense ? &classify : nullptr, iteration);
             if (rc != TDX_OK) return rc;
             ctx->phase = ph.directions;
             {

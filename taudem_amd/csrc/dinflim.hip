@@ -62,7 +62,6 @@ struct ConcLimAlg {   // src/DinfConcLimAccum.cpp:226-262; record = {ctpt, q, dm
     using Aux = float;                           // indicator grid value (int bits)
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
     static constexpr int kBulkSweeps = 6;   // (measured at 16384^2, ConcLim / TransLim: 3: 130.6 / 147.6 ms, 6: 129.3 / 144.9, 12: 131.6 / 146.0)
-    static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 2;
@@ -104,7 +103,6 @@ struct TransLimAlg {   // src/DinfTransLimAccum.cpp:236-307; record = {tla, csou
     using Aux = float2;                          // {tsup, tc}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
     static constexpr int kBulkSweeps = 6;   // (measured at 16384^2, ConcLim / TransLim: 3: 130.6 / 147.6 ms, 6: 129.3 / 144.9, 12: 131.6 / 146.0)
-    static constexpr bool kBulkOnHalo = false;
     static constexpr unsigned kBulkUntil = 16;
     static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 2;

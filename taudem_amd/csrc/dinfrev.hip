@@ -79,8 +79,7 @@ struct UpDepAlg {   // src/DinfUpDependence.cpp:184-208
     using Cell = float;
     using Aux = float2;                          // {angle, disturbance grid value (int bits)}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
-    static constexpr int kBulkSweeps = 1 << 20;      // to the end: the reverse sweep is a wide front (d8_sweep.hpp)
-    static constexpr bool kBulkOnHalo = true;
+    static constexpr int kBulkSweeps = 0;            // (not used: the reverse sweeps run d8sweep::sweep_tile_rev, lockstep sweeps to the end of every activation)
     static constexpr int kMinWaves32 = 5;
     static constexpr int kMaxRelease = 8;
     static constexpr unsigned kBulkUntil = 64;       // a wide front of thousands of tiles to the very end: several small tiles per CU beat one large one (489 -> 380 ms at 16384^2)
@@ -122,8 +121,7 @@ struct RevAccAlg {   // src/DinfRevAccum.cpp:176-199; record = {racc, dmax}
     using Cell = float2;
     using Aux = float2;                          // {angle, weight}
     static constexpr bool HAS_AUX = true, HAS_DIST = false, HAS_ROWS = true;
-    static constexpr int kBulkSweeps = 1 << 20;      // to the end: the reverse sweep is a wide front (d8_sweep.hpp)
-    static constexpr bool kBulkOnHalo = true;
+    static constexpr int kBulkSweeps = 0;            // (not used: the reverse sweeps run d8sweep::sweep_tile_rev, lockstep sweeps to the end of every activation)
     static constexpr unsigned kBulkUntil = 64;
     static constexpr int kMinWaves32 = 4;
     static constexpr int kMaxRelease = 8;

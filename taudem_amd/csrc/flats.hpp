@@ -112,6 +112,126 @@ __global__ __launch_bounds__(256) void classify_kernel(Traits tr, const float* _
     }
 }
 
+// Classification for flat resolution as ONE streaming pass (replaces marker reset + list gathers): the flat queue is
+// exactly {p == 0} (D-infinity: {angle == -1}) in every outer iteration (resolved cells leave it, nothing enters it), so queue membership, the
+// level-1/2 seeds of incfall, the seeds of incrise and both eligibility masks are a function of the 3x3 windows of
+// Z and the direction raster.  Every owned cell gets its markers (lvl / rq: -1 outside the queue) and masks; lanes walk 16-row column
+// segments with both windows in registers (6 row loads per output row).  Semantics: flatk::classify_kernel.
+// (62-column window like d8_slope_kernel: a lane loads ONE value per row and array, the west / east neighbours are lane shifts; the 2 x 18 row
+// loads of a lane are issued back to back.  The first version read three overlapping cells per row and array inside the row loop: 1.36 ms.)
+constexpr int CLS_COLS = 62, CLS_ROWS = 16;
+template <class LV, class Src>
+__global__ __launch_bounds__(256) void classify_stream_kernel(const float* __restrict__ Z, Src src, int nx, int ny,
+                                                                 int y_own0, int y_own1, int tiles_x, LV* __restrict__ lvl,
+                                                                 LV* __restrict__ rq, uint8_t* __restrict__ fmask, uint8_t* __restrict__ rmask,
+                                                                 uint32_t* __restrict__ tile_flags, uint8_t* __restrict__ tile_masked, int nbx, int xmap,
+                                                                 uint8_t* __restrict__ notfull) {
+    using tilek::lane_left;
+    using tilek::lane_right;
+    const int bx = tdxk::xcd_block_x(nbx, xmap);
+    if (bx < 0) return;
+    const int lx = threadIdx.x & 63;
+    const int x = bx * CLS_COLS - 1 + lx;
+    const int ybase = __builtin_amdgcn_readfirstlane(y_own0 + blockIdx.y * (4 * CLS_ROWS) + (threadIdx.x >> 6) * CLS_ROWS);
+    const bool mine = lx >= 1 && lx <= CLS_COLS && x < nx;
+    const bool inx = x >= 0 && x < nx;
+    const int xc = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+    float z[CLS_ROWS + 2];
+    typename Src::Raw pw[CLS_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < CLS_ROWS + 2; j++) {
+        const int y = ybase - 1 + j, yc = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        const size_t o = size_t(yc) * size_t(nx) + size_t(xc);
+        z[j] = Z[o];
+        pw[j] = src.load(o);
+    }
+    // The direction codes in ONE-HOT form (bit c for a code c in 0 .. 8, nothing for nodata / outside): "in the queue" is bit 0, "has a direction" bits 1 .. 8,
+    // dontCross two bit tests - and the per-neighbour case analysis below integer and / or on 0 / 1 values.  (As nested if / else on comparisons it compiled to
+    // ~145 vector and ~200 scalar instructions per cell row - lane-mask algebra and branches - and the pass waited for its instructions, not for memory:
+    // profiles/r04zzzz_pmc_sq_summary.json.)
+    unsigned ow[CLS_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < CLS_ROWS + 2; j++) {
+        const int y = ybase - 1 + j;
+        const bool in = inx && y >= 0 && y < ny;   // (never looked at from a flat cell: flat cells are interior cells)
+        if (!in) z[j] = 0.f;
+        ow[j] = in ? Src::onehot(pw[j]) : 0u;
+    }
+    int flag_row0 = -1, flag_row1 = -1;   // tile rows (of the relaxation's tile grid) in which this lane saw a flat cell
+    int masked_row = -1;                  // ... a flat cell whose incfall mask shuts out an in-queue neighbour (flatk::LevelPlainT)
+    unsigned fall_all = 0xFFu, rise_all = 0xFFu;   // AND of this lane's masks: 0xFF = every cell of its column segment may move and look at all eight neighbours (flats.hpp: OPEN WATER)
+#pragma unroll
+    for (int r = 0; r < CLS_ROWS; r++) {
+        const int y = ybase + r;
+        const float zn1 = z[r], zc1 = z[r + 1], zs1 = z[r + 2];
+        const unsigned on1 = ow[r], oc1 = ow[r + 1], os1 = ow[r + 2];
+        const float zn0 = lane_left(zn1, 0.f), zn2 = lane_right(zn1, 0.f), zc0 = lane_left(zc1, 0.f), zc2 = lane_right(zc1, 0.f);
+        const float zs0 = lane_left(zs1, 0.f), zs2 = lane_right(zs1, 0.f);
+        const unsigned on0 = lane_left(on1, 0u), on2 = lane_right(on1, 0u), oc0 = lane_left(oc1, 0u), oc2 = lane_right(oc1, 0u);
+        const unsigned os0 = lane_left(os1, 0u), os2 = lane_right(os1, 0u);
+        if (mine && y < y_own1) {
+            const size_t idx = size_t(y) * size_t(nx) + size_t(x);
+            LV l = -1, q = -1;
+            unsigned fm = 0, rm = 0;
+            if (oc1 & 1u) {   // a flat cell: interior, all eight neighbours valid
+                const float z0 = zc1;
+                bool higher = false;
+                unsigned lowi = 0, fmq = 0;   // fmq: bits 0-7 the incfall mask, bit 8 the quirk (an equal neighbour that is neither in the queue nor has a direction)
+                // neighbour k: elevation, one-hot code, "does not cross" (0 / 1; dontCross(k), src/d8.cpp:54-100, from the cardinal neighbours' codes).  Per neighbour,
+                // as in flatk::classify_kernel: higher |= zd < 0; rm bit if in the queue; and unless the step crosses a flow path:
+                // zd >= 0 towards a cell with a direction -> low; else zd == 0 -> fm bit (in the queue) or the quirk.  zd == 0 implies zd >= 0, so the
+                // second case only sees cells without a direction.
+#define TDX_CLS(K, ZN, ON, NC)                                                                                   \
+    {                                                                                                             \
+        const float zd = z0 - (ZN);                                                                               \
+        const unsigned inq = (ON) & 1u, isdir = min((ON) & 0x1FEu, 1u), oth = ((ON) & 0x1FFu) ? 0u : 1u;          \
+        higher |= zd < 0;                                                                                         \
+        rm |= inq << ((K) - 1);                                                                                   \
+        lowi |= zd >= 0 ? ((NC) & isdir) : 0u;                                                                    \
+        fmq |= zd == 0 ? ((0u - (NC)) & ((inq << ((K) - 1)) | (oth << 8))) : 0u;                                  \
+    }
+                TDX_CLS(1, zc2, oc2, 1u)
+                TDX_CLS(2, zn2, on2, (((oc2 >> 4) | (on1 >> 8)) & 1u) ^ 1u)
+                TDX_CLS(3, zn1, on1, 1u)
+                TDX_CLS(4, zn0, on0, (((on1 >> 6) | (oc0 >> 2)) & 1u) ^ 1u)
+                TDX_CLS(5, zc0, oc0, 1u)
+                TDX_CLS(6, zs0, os0, (((os1 >> 4) | (oc0 >> 8)) & 1u) ^ 1u)
+                TDX_CLS(7, zs1, os1, 1u)
+                TDX_CLS(8, zs2, os2, (((oc2 >> 6) | (os1 >> 2)) & 1u) ^ 1u)
+#undef TDX_CLS
+                const bool low = lowi != 0u, quirk = (fmq >> 8) != 0u;
+                fm = fmq & 0xFFu;
+                l = low ? 1 : (quirk ? 2 : 0);
+                q = higher ? 1 : 0;
+                const int tr = y / tilek::TS;
+                if (!low && fm != rm) masked_row = tr;
+                if (low) fm = 0;       // a level-1 cell can never improve
+                if (higher) rm = 0;
+                if (flag_row0 < 0) flag_row0 = tr; else if (tr != flag_row0) flag_row1 = tr;
+            }
+            lvl[idx] = l;
+            rq[idx] = q;
+            fmask[idx] = uint8_t(fm);
+            rmask[idx] = uint8_t(rm);
+            fall_all &= fm;
+            rise_all &= rm;
+        }
+    }
+    if (notfull != nullptr && mine) {   // the tile rows this lane's segment lies in are not full for a field unless every cell of the segment is (rows beyond the owned ones never are)
+        const int ylast = ybase + CLS_ROWS - 1;
+        const int tr0 = ybase / tilek::TS, tr1 = (ylast < ny ? ylast : ny - 1) / tilek::TS;
+        const bool short_seg = ylast >= y_own1;
+        if (fall_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS)] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS)] = 1; }
+        if (rise_all != 0xFFu || short_seg) { notfull[2 * (size_t(tr0) * tiles_x + x / tilek::TS) + 1] = 1; if (tr1 != tr0) notfull[2 * (size_t(tr1) * tiles_x + x / tilek::TS) + 1] = 1; }
+    }
+    if (flag_row0 >= 0) tile_flags[flag_row0 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    if (flag_row1 >= 0) tile_flags[flag_row1 * tiles_x + x / tilek::TS] = tilek::FLAG_FULL;
+    if (masked_row >= 0) {   // rare (dontCross at a lake shore): all the tile rows this lane touched, a superset is harmless
+        tile_masked[flag_row0 * tiles_x + x / tilek::TS] = 1;
+        if (flag_row1 >= 0) tile_masked[flag_row1 * tiles_x + x / tilek::TS] = 1;
+    }
+}
+
 // level field in the marker convention above: values <= 0 read as +inf; only cells with a mask move.  S = storage type of the field in
 // HBM (the values in registers are 32-bit either way): int16 for the two level fields, where a candidate level saturates at LVL_SAT -
 // the fixed point of the saturating operator is min(level, LVL_SAT) per cell, i.e. the exact field whenever every level fits, and
@@ -862,9 +982,11 @@ static int flats_bfs(tdx_context* ctx, Traits tr, const float* Z, const Strip& s
     uint32_t* flagsB = pair ? static_cast<uint32_t*>(ctx->scratch(TDX_S_L, size_t(ntiles) * 4 * (1 + tilek::SCHED_LIST_WORDS))) : nullptr;
     unsigned long long* countsB = pair ? static_cast<unsigned long long*>(ctx->scratch(TDX_S_M, size_t(tilek::COUNT_RING) * 16)) : nullptr;
     if (pair && (!flagsB || !countsB)) return TDX_ERR_NOMEM;
-    // OPEN WATER (macro blocks of full tiles, see above): with the streaming classification (a dense first queue: D8FlowDir's first iteration), int16 fields, the
-    // register tile kernel.  (From the list classification - DinfFlowDir, later iterations - the per-tile "full" marks were built and measured in round 6: a wave's 64
-    // list entries span three or four tiles, the marks cost more than the rounds they save - DinfFlowDir 24.2 -> 32.6 ms at 16384^2; profiles/r06l_macro_dinf_ab.txt.)  TDX_FLATS_MACRO=0 switches it off, =2 / 4 / 8 sets the largest block edge (read per call: A/B and test hook).
+    // OPEN WATER (macro blocks of full tiles, see above): with the streaming classification (a dense queue: the first iteration of D8FlowDir and of DinfFlowDir), int16
+    // fields, the register tile kernel.  (From the LIST classification - later iterations - per-tile "full" marks were built and measured in round 6: a wave's 64
+    // list entries span three or four tiles, the marks cost more than the rounds they save - DinfFlowDir 24.2 -> 32.6 ms at 16384^2, profiles/r06l_macro_dinf_ab.txt;
+    // with the streaming classification DinfFlowDir gains instead: 24.3 -> 22.3 ms, profiles/r06ae_*.)  TDX_FLATS_MACRO=0 switches it off, =2 / 4 / 8 sets the largest
+    // block edge (read per call: A/B and test hook).
     int macro_k = 0;
     if constexpr (sizeof(LV) == 2) {
         const char* e_macro = getenv("TDX_FLATS_MACRO");
