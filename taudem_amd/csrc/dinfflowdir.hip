@@ -226,9 +226,7 @@ __global__ __launch_bounds__(256) void dinf_collect_flats_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (c0 + i < n && dinf_is_flat(a[i])) mask |= 1u << i;
-    if (lvl == nullptr) {
-        // (a dense queue: the streaming classification writes every owned cell's markers itself - only the list is wanted)
-    } else if (sizeof(LV) == 2 && c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {   // eight int16 markers = one 16-byte store
+    if (sizeof(LV) == 2 && c0 + 8 <= n && ((reinterpret_cast<uintptr_t>(lvl + c0) | reinterpret_cast<uintptr_t>(rq + c0)) & 15u) == 0) {   // eight int16 markers = one 16-byte store
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) w[j] = (((mask >> (2 * j)) & 1u) ? 0u : 0xFFFFu) | (((mask >> (2 * j + 1)) & 1u) ? 0u : 0xFFFF0000u);   // 0 in the queue, -1 outside
@@ -404,18 +402,12 @@ static int dinfflowdir_levels(tdx_context* ctx, const Strip& st, float* d_fel, f
         if (rc != TDX_OK) return rc;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
         const size_t own_first = size_t(st.y0) * size_t(inx), own_end = size_t(st.y1) * size_t(inx);
-        // (on ONE strip a dense first queue is classified by the streaming pass, which writes the markers of every cell: the list alone is built here.  With
-        // neighbours the markers are always written and exchanged: a neighbour whose own queue is sparse classifies from its list and reads this rank's
-        // boundary-row markers, and every rank must make the same collectives)
-        const bool dense_first = !st.multi() && getenv("TDX_FLATS_LIST") == nullptr && nq > n / 16;
-        hipLaunchKernelGGL((dinf_collect_flats_kernel<LV>), dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end,
-                           dense_first ? static_cast<LV*>(nullptr) : lvl, rq, qlist, d_cnt);
-        if (!dense_first) {
-            rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
-            if (rc != TDX_OK) return rc;
-            rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
-            if (rc != TDX_OK) return rc;
-        }
+        hipLaunchKernelGGL((dinf_collect_flats_kernel<LV>), dim3(tdx_blocks_for(own_end - own_first, 2048)), dim3(256), 0, s, d_ang, own_first, own_end, lvl, rq,
+                           qlist, d_cnt);
+        rc = strip_exchange<LV>(ctx, st, lvl, LV(-1));   // queue membership of the neighbours' boundary rows
+        if (rc != TDX_OK) return rc;
+        rc = strip_exchange<LV>(ctx, st, rq, LV(-1));
+        if (rc != TDX_OK) return rc;
         int64_t last = total;
         bool first = true;
         unsigned long long nq_old = 0;      // cells of the previous iteration's queue (in qnext after the swap)
