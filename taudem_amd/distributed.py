@@ -388,6 +388,30 @@ class StripPipeline:
         del keep
         return sca, st.as_dict()
 
+    def dinfupdependence(self, ang, dg, nodata=-3.402823466e38, dx=1.0, dy=1.0):
+        """dep = depgrd(ang, dg) on this strip (src/DinfUpDependence.cpp:52): dg int32, dep float32 (nodata -1)."""
+        torch = self.torch
+        dxc, dyc = self._cells(dx, dy)
+        dep = self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_dinfupdependence_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local, float(nodata),
+                                                       C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), _tptr(dg, torch.int32, self.shape, "dg"),
+                                                       _tptr(dep, torch.float32, self.shape, "dep"), C.byref(st)), self.ctx._h)
+        return dep, st.as_dict()
+
+    def dinfrevaccum(self, ang, w, nodata=-3.402823466e38, w_nodata=-9999.0, dx=1.0, dy=1.0):
+        """racc, dmax = dsaccum(ang, w) on this strip (src/DinfRevAccum.cpp:51)."""
+        torch = self.torch
+        dxc, dyc = self._cells(dx, dy)
+        racc, dmax = self.empty(torch.float32), self.empty(torch.float32)
+        st = TdxStats()
+        torch.cuda.synchronize(self.ctx.device)
+        check(self.ctx._lib.tdx_dinfrevaccum_strip(self.ctx._h, self._cp, _tptr(ang, torch.float32, self.shape, "ang"), self.nx, self.ny_local, float(nodata),
+                                                   C.c_void_p(dxc.ctypes.data), C.c_void_p(dyc.ctypes.data), _tptr(w, torch.float32, self.shape, "w"), float(w_nodata),
+                                                   _tptr(racc, torch.float32, self.shape, "racc"), _tptr(dmax, torch.float32, self.shape, "dmax"), C.byref(st)), self.ctx._h)
+        return racc, dmax, st.as_dict()
+
     def dinfdecayaccum(self, ang, dm, nodata=-3.402823466e38, dm_nodata=-9999.0, dx=1.0, dy=1.0, weights=None, contcheck=True, outlets=None, out=None):
         torch = self.torch
         dxc, dyc = self._cells(dx, dy)

@@ -52,6 +52,10 @@ def test_random_cut_random_raster(seed, oracle, monkeypatch):
     outl = (ox.astype(np.int32), oy.astype(np.int32))
     ao_o = oracle.aread8(p_o, -32768, contcheck=False, outlets=outl)
     d_o = oracle.dinfdecayaccum(ang_o, dm, dx=30.0, dy=25.0, weights=w, contcheck=False, outlets=outl)
+    # the reverse sweeps (round 6: a tile routine of their own): a disturbance grid of scattered cells, the weights as the accumulated quantity
+    dg = (rng.random((ny, nx)) < 0.02).astype(np.int32)
+    dep_o = oracle.dinfupdependence(ang_o, dg, dx=30.0, dy=25.0)
+    racc_o, dmax_o = oracle.dinfrevaccum(ang_o, w, dx=30.0, dy=25.0)
     monkeypatch.setenv("TDX_AD8_BIG_THRESHOLD", str(thr))
     monkeypatch.setenv("TDX_SWEEP_EAGER_ROUNDS", str(eager))
     monkeypatch.setenv("TDX_REACH_EAGER_ROUNDS", str(eager))
@@ -79,11 +83,13 @@ def test_random_cut_random_raster(seed, oracle, monkeypatch):
             lo = pipe.local_outlets(outl[0], outl[1], y0)
             ao, _ = pipe.aread8(p, -32768, contcheck=False, outlets=lo)
             dd, _ = pipe.dinfdecayaccum(ang, dmt, dx=30.0, dy=25.0, weights=wt, contcheck=False, outlets=lo)
+            dep, _ = pipe.dinfupdependence(ang, put(dg, torch.int32), dx=30.0, dy=25.0)
+            racc, dmax, _ = pipe.dinfrevaccum(ang, wt, dx=30.0, dy=25.0)
             return {k: v[sl].cpu().numpy() for k, v in (("fel", fel), ("p", p), ("sd8", sd8), ("ang", ang), ("slp", slp), ("ad8", a), ("ad8_w", aw), ("sca", sca),
-                                                        ("ad8_o", ao), ("dsca_o", dd))}
+                                                        ("ad8_o", ao), ("dsca_o", dd), ("dep", dep), ("racc", racc), ("dmax", dmax))}
         res = grp.run(rank_main)
     what = f"seed {seed}: {ny} x {nx} in {world} strips, {holes} holes, big-cell threshold {thr}, {eager} rounds between exchanges"
     for key, ref in (("fel", fel_o), ("p", p_o), ("sd8", sd8_o), ("ang", ang_o), ("slp", slp_o), ("ad8", a_o), ("ad8_w", aw_o), ("sca", sca_o), ("ad8_o", ao_o),
-                     ("dsca_o", d_o)):
+                     ("dsca_o", d_o), ("dep", dep_o), ("racc", racc_o), ("dmax", dmax_o)):
         got = np.concatenate([r[key] for r in res], axis=0)
         assert bits_equal(got, ref), describe_diff(got, ref, f"{what}: {key}")
