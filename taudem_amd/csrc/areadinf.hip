@@ -666,10 +666,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
     TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     float* ang_use = d_ang;
     if (n_outlets >= 0) {
+        ctx->phase = "outlets' closure";
         rc = dinf_outlet_recode(ctx, st, d_ang, ang_nodata, d_rows, outlet_x, outlet_y, n_outlets, &ang_use, stats);
         if (rc != TDX_OK) return rc;
         TDX_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
     }
+    ctx->phase = "set-up";
     uint32_t* info32 = nullptr;
     double2* d_P = nullptr;
     if (!use_walk) {
@@ -794,9 +796,10 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
         hipLaunchKernelGGL(tilek::fill_u32_kernel, dim3(tdx_blocks_for(ntiles, 256)), dim3(256), 0, s, flags, tilek::FLAG_FULL, ntiles);   // round 0: every tile
         bool bulk = bulk_until > 0 && ntiles32 > bulk_until;
         for (;;) {
-            bool left = false;
+            bool left = false, bulk_just_ran = false;
             int par = 0;
             if (bulk) {
+                ctx->phase = "bulk rounds";
                 // bulk phase on 32 x 32 tiles: every 32-tile under an active 64-tile starts active
                 hipLaunchKernelGGL(dsweep::flags_down_kernel, dim3(tdx_blocks_for(ntiles32, 256)), dim3(256), 0, s, flags, geom.tiles_x, flags32, geom32.tiles_x,
                                    geom32.tiles_y, bulk_sh);
@@ -809,8 +812,12 @@ int run_dinf_accum(tdx_context* ctx, Alg alg, const Strip& st, float* d_ang, flo
                                        geom.tiles_x, bulk_sh);
                 }
                 bulk = false;   // (strip re-activations are few tiles: 64 x 64)
+                bulk_just_ran = true;
             } else left = true;
-            if (left) {
+            // (with neighbours the bulk phase is followed by an exchange at once: the tail's first rounds then see what the neighbours' bulk phases finished,
+            // and the segment trace shows the two phases apart - the step time is the same either way: 311.4 against 311.2 ms projected at BASELINE.json configs[4])
+            if (left && !(bulk_just_ran && st.multi())) {
+                ctx->phase = "tail rounds";
                 // Multi-strip tail: at most `eager` rounds between two exchanges.  A strip that runs to its local fixed point first makes every flow path
                 // that crosses a strip boundary wait for the longest chain ANYWHERE in the strip it enters - at BASELINE.json configs[4] 47 crossings x
                 // ~10 ms (profiles/r05b_projection_decay.txt); with frequent exchanges the paths advance side by side, as on one GPU.
